@@ -1,0 +1,90 @@
+"""Deterministic synthetic squiggle batches (SURVEY.md section 8(d) recipe).
+
+Pure numpy, host side; used by tests, tools/gen_golden.py and bench.py to make
+inputs of the shapes BASELINE.json names.  No reference code involved: the
+reference ships no generator (its only data is example/test.fast5).
+
+Squiggle model: event levels ~ N(500, 80) raw units, dwell 1 + Poisson(8)
+samples, additive N(0, 8) noise, rounded and clipped to int16; a stall plateau
+near the start, with p = 0.5 a second plateau later in the read, and four spike
+samples from {-5, 0, 950, 1100} so the outlier filter has work to do.
+"""
+import numpy as np
+
+SEED_C2 = 20260927   # segmenter 10 000 x 4 000
+SEED_C3 = 20260928   # MotifSeq 10 000 x 4 000 vs example model
+SEED_C4 = 20260929   # MotifSeq 1 M x 4 000 (+ rank)
+SEED_C5 = 20260930   # MotifSeq 100 k x 20 000 (+ rank)
+
+SPIKES = np.array([-5, 0, 950, 1100], dtype=np.int16)
+
+
+def squiggle_batch(n_reads, n_samples, seed, motif=None, chunk=8192):
+    """int16 [n_reads, n_samples] synthetic squiggles.
+
+    motif: optional float vector (normalised units); round(motif*93.4 + 511) is
+    implanted at a random offset in ~50 % of the reads (positive controls).
+    """
+    out = np.empty((n_reads, n_samples), dtype=np.int16)
+    rng = np.random.default_rng(seed)
+    for lo in range(0, n_reads, chunk):
+        hi = min(n_reads, lo + chunk)
+        out[lo:hi] = _chunk(rng, hi - lo, n_samples, motif)
+    return out
+
+
+def _chunk(rng, R, M, motif):
+    E = M // 4 + 16                                   # events: mean dwell 9 >> 4
+    levels = rng.normal(500.0, 80.0, size=(R, E))
+    dwell = 1 + rng.poisson(8.0, size=(R, E))
+    starts = np.cumsum(dwell, axis=1)                 # first sample of event k+1
+    mark = np.zeros((R, M + 1), dtype=np.int32)
+    np.put_along_axis(mark, np.minimum(starts, M), 1, axis=1)
+    # several events can clip to column M; that column is dropped
+    ev = np.cumsum(mark[:, :M], axis=1)
+    sig = np.take_along_axis(levels, ev, axis=1)
+    sig += rng.normal(0.0, 8.0, size=(R, M))
+
+    col = np.arange(M)[None, :]
+    # stall plateau
+    s0 = rng.integers(0, 60, size=(R, 1))
+    l0 = rng.integers(100, 600, size=(R, 1))
+    m0 = (col >= s0) & (col < s0 + l0)
+    sig = np.where(m0, rng.normal(505.0, 12.0, size=(R, M)), sig)
+    # optional second plateau (positions scale with read length past 4 000)
+    scale = max(1, M // 4000)
+    has2 = rng.random(size=(R, 1)) < 0.5
+    s1 = rng.integers(1200 * scale, 3400 * scale, size=(R, 1))
+    l1 = rng.integers(160, 500, size=(R, 1))
+    m1 = has2 & (col >= s1) & (col < s1 + l1)
+    sig = np.where(m1, rng.normal(495.0, 10.0, size=(R, M)), sig)
+
+    sig = np.clip(np.rint(sig), -32768, 32767).astype(np.int16)
+
+    if motif is not None:
+        mot = np.clip(np.rint(np.asarray(motif, dtype=np.float64) * 93.4 + 511.0),
+                      -32768, 32767).astype(np.int16)
+        N = mot.size
+        if N < M:
+            hit = rng.random(size=R) < 0.5
+            off = rng.integers(0, M - N, size=R)
+            rows = np.nonzero(hit)[0]
+            idx = off[rows, None] + np.arange(N)[None, :]
+            sig[rows[:, None], idx] = mot[None, :]
+
+    # four spikes per read
+    pos = rng.integers(0, M, size=(R, 4))
+    val = SPIKES[rng.integers(0, 4, size=(R, 4))]
+    np.put_along_axis(sig, pos, val, axis=1)
+    return sig
+
+
+def synthetic_motif(n_points, seed=7):
+    """A seeded k-mer-like level sequence expanded by dwell (normalised units),
+    shaped like what MotifSeq.py:354-379 builds from a scrappie model."""
+    rng = np.random.default_rng(seed)
+    vals = []
+    while len(vals) < n_points:
+        level = float(np.float32(rng.normal(0.0, 1.1)))
+        vals.extend([level] * int(rng.integers(6, 13)))
+    return np.asarray(vals[:n_points], dtype=np.float64)
