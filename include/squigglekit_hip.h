@@ -1,0 +1,155 @@
+/*
+ * squigglekit_hip.h -- C ABI of libsquigglekit_hip.so (MI355X / gfx950).
+ *
+ * The reference (Psy-Fer/SquiggleKit) has no FFI: its hot path sits behind two
+ * in-process Python call boundaries,
+ *     segmenter.get_segs(sig, args)          /root/reference/segmenter.py:399
+ *     mlpy.dtw_subsequence(model, sig)       /root/reference/MotifSeq.py:437
+ * wrapped by per-read loops (segmenter.py:189-230, MotifSeq.py:261-298) that
+ * filter (scale_outliers) and normalise each read first.  This header is what
+ * a ctypes binding at those two call sites binds instead (INTEGRATION.md shows
+ * the stub).  Batch entry points take many reads per call because one read is
+ * far too little work for a GPU; the single-pair entry points keep the
+ * reference's one-call-per-read shape.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; caller owns every buffer; the library
+ *     keeps no caller pointer after a call returns.
+ *   - every function returns SK_OK (0) or a negative sk_status; the message is
+ *     available from sk_last_error() (thread local).
+ *   - "host" entry points take host pointers and do H2D / kernels / D2H;
+ *     "_dev" entry points take device pointers obtained from sk_dev_alloc()
+ *     and leave results in HBM (what bench.py times).
+ *   - no CPU fallback exists: without a usable HIP device every compute entry
+ *     point fails with SK_ERR_NO_DEVICE.
+ */
+#ifndef SQUIGGLEKIT_HIP_H
+#define SQUIGGLEKIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sk_status {
+    SK_OK              =  0,
+    SK_ERR_INVALID     = -1,   /* bad argument (NULL, negative size, bad params)        */
+    SK_ERR_NO_DEVICE   = -2,   /* no HIP device / sk_init not called / device lost      */
+    SK_ERR_HIP         = -3,   /* a HIP runtime call failed (message has the detail)    */
+    SK_ERR_NOMEM       = -4,   /* device or host allocation failed                      */
+    SK_ERR_UNSUPPORTED = -5,   /* shape outside what the kernels cover (message says)   */
+    SK_ERR_OVERFLOW    = -6    /* max_segs too small for at least one read              */
+} sk_status;
+
+/* scale modes of MotifSeq.py -l/--scale (MotifSeq.py:96) */
+enum { SK_SCALE_MEDMAD = 0, SK_SCALE_ZSCALE = 1 };
+
+/* flags in sk_hit.flags */
+enum {
+    SK_FLAG_EMPTY      = 1,    /* no sample survived scale_outliers: dist = NaN, start=end=-1 */
+    SK_FLAG_DEGENERATE = 2     /* medmad with MAD == 0 (reference divides by zero)            */
+};
+
+/* get_segs parameters: the argparse flags of segmenter.py:65-96 that reach
+ * scale_outliers (segmenter.py:311-318) and get_segs (segmenter.py:399-470). */
+typedef struct sk_seg_params {
+    int32_t error;       /* -e/--error      default 5    */
+    int32_t corrector;   /* -c/--corrector  default 50   */
+    int32_t window;      /* -w/--window     default 150  */
+    int32_t seg_dist;    /* -d/--seg_dist   default 50   */
+    double  std_scale;   /* -t/--std_scale  default 0.75 */
+    double  stall_len;   /* -l/--stall_len  default 0.25 */
+    int32_t lim_low;     /* -lim_low        default 0    */
+    int32_t lim_hi;      /* -lim_hi         default 900  */
+} sk_seg_params;
+
+/* One MotifSeq hit: what get_region_multi (MotifSeq.py:431-449) derives from
+ * dist, path[1][0], path[1][-1].  24 bytes. */
+typedef struct sk_hit {
+    double  dist;        /* cost[-1, argmin]                                   */
+    int32_t start;       /* path[1][0]   (index into the FILTERED signal)      */
+    int32_t end;         /* path[1][-1]  (argmin of the last row)              */
+    int32_t n;           /* samples that survived scale_outliers               */
+    int32_t flags;       /* SK_FLAG_*                                          */
+} sk_hit;
+
+/* ---- runtime --------------------------------------------------------- */
+const char *sk_version(void);
+const char *sk_last_error(void);
+int  sk_device_count(void);                 /* >= 0, or negative sk_status                */
+int  sk_init(int device);                   /* bind the calling thread to `device`        */
+int  sk_shutdown(void);                     /* free every per-device context              */
+int  sk_sync(void);                         /* wait for the bound device's stream         */
+int  sk_device_name(char *buf, int cap);    /* marketing/gcn name of the bound device     */
+
+/* ---- device memory (for *_dev entry points) --------------------------- */
+void *sk_dev_alloc(size_t bytes);           /* NULL on failure                            */
+int   sk_dev_free(void *dptr);
+int   sk_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
+int   sk_dev_download(void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- segmenter path --------------------------------------------------- */
+/* Replaces, per read r: scale_outliers(sig) (segmenter.py:209,311-318) then
+ * get_segs(sig, args) (segmenter.py:211,399-470).
+ *   sig[r*stride .. r*stride+len[r])  raw samples of read r (caller applies
+ *                                      the [:Num] cut of segmenter.py:207)
+ *   segs[r][k][0..1]                   k-th [start,end] in FILTERED coordinates
+ *   nsegs[r]                           number found; 0 == the reference's False
+ * Returns SK_ERR_OVERFLOW if some nsegs[r] > max_segs (nsegs is still exact,
+ * segs truncated). */
+int sk_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
+                         const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs);
+/* float64 samples (pA TSVs; segmenter.py:198-199), ragged: read r is
+ * sig[off[r] .. off[r+1]). */
+int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
+                         const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs);
+/* device-resident form of sk_segment_batch_i16 (all pointers device). */
+int sk_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                       const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs);
+
+/* ---- MotifSeq path ---------------------------------------------------- */
+/* Replaces, per read r: scale_outliers (MotifSeq.py:274,317-324), medmad
+ * (:192-200) or zscale (:186-191), then mlpy.dtw_subsequence(motif, sig)
+ * (:437) reduced to what the caller uses (:438-439): dist, start, end.
+ * motif: nmotif float64 points (model[name], MotifSeq.py:354-428). */
+int sk_motifseq_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
+                          const double *motif, int32_t nmotif, int32_t scale_mode,
+                          int32_t scale_low, int32_t scale_hi, sk_hit *out);
+int sk_motifseq_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
+                          const double *motif, int32_t nmotif, int32_t scale_mode,
+                          int32_t scale_low, int32_t scale_hi, sk_hit *out);
+/* device-resident form (d_sig, d_len, d_out device; motif host). */
+int sk_motifseq_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                        const double *motif, int32_t nmotif, int32_t scale_mode,
+                        int32_t scale_low, int32_t scale_hi, sk_hit *d_out);
+
+/* The mlpy boundary itself: dtw_subsequence(x, y) on already-normalised
+ * float64 signals (MotifSeq.py:437).  Batch form: read r is y[off[r]..off[r+1]). */
+int sk_dtw_subsequence_batch(const double *x, int32_t nx, const double *y, const int64_t *off,
+                             int32_t nreads, sk_hit *out);
+/* Single pair, the reference's call shape.  cost_last_row (may be NULL, else
+ * ny doubles) receives cost[-1, :] (what view_region plots, MotifSeq.py:507). */
+int sk_dtw_subsequence(const double *x, int32_t nx, const double *y, int32_t ny,
+                       double *dist, int32_t *start, int32_t *end, double *cost_last_row);
+
+/* Normalised signal of one read exactly as the reference hands it to
+ * dtw_subsequence (used by MotifSeq -x/--sig_extract, MotifSeq.py:446-447).
+ * out must hold len doubles; *n_out receives the filtered length. */
+int sk_normalise_i16(const int16_t *sig, int32_t len, int32_t scale_mode,
+                     int32_t scale_low, int32_t scale_hi, double *out, int32_t *n_out);
+
+/* ---- instrumentation -------------------------------------------------- */
+/* HIP-event durations (ms) of the kernels of the most recent *_dev / batch
+ * call on this thread's device: prep (filter+stats), main (DTW or segment walk). */
+int sk_last_kernel_ms(float *prep_ms, float *main_ms);
+/* Synthetic squiggle generator on the device (bench input; not a reference
+ * function): fills d_sig[nreads][nsamples] int16 deterministically from seed. */
+int sk_synth_squiggles_dev(int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
+                           uint64_t seed, const double *motif, int32_t nmotif);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQUIGGLEKIT_HIP_H */

@@ -1,0 +1,142 @@
+"""ctypes binding of libsquigglekit_hip.so (the C ABI in include/squigglekit_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 device is
+visible, every compute call raises.  Nothing here imports torch or the oracle.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libsquigglekit_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+class SquiggleKitError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("squigglekit_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+SK_ERR_OVERFLOW = -6
+SK_SCALE = {"medmad": 0, "zscale": 1}
+SK_FLAG_EMPTY, SK_FLAG_DEGENERATE = 1, 2
+
+
+class SegParams(C.Structure):
+    """sk_seg_params; defaults are the argparse defaults of segmenter.py:65-96."""
+    _fields_ = [("error", C.c_int32), ("corrector", C.c_int32), ("window", C.c_int32),
+                ("seg_dist", C.c_int32), ("std_scale", C.c_double), ("stall_len", C.c_double),
+                ("lim_low", C.c_int32), ("lim_hi", C.c_int32)]
+
+    def __init__(self, error=5, corrector=50, window=150, seg_dist=50, std_scale=0.75,
+                 stall_len=0.25, lim_low=0, lim_hi=900):
+        super().__init__(error, corrector, window, seg_dist, std_scale, stall_len, lim_low, lim_hi)
+
+    @classmethod
+    def from_args(cls, args):
+        """Build from an argparse Namespace shaped like segmenter.py's."""
+        return cls(args.error, args.corrector, args.window, args.seg_dist, args.std_scale,
+                   args.stall_len, getattr(args, "lim_low", 0), getattr(args, "lim_hi", 900))
+
+
+class Hit(C.Structure):
+    _fields_ = [("dist", C.c_double), ("start", C.c_int32), ("end", C.c_int32),
+                ("n", C.c_int32), ("flags", C.c_int32)]
+
+
+HIT_DTYPE = np.dtype([("dist", "<f8"), ("start", "<i4"), ("end", "<i4"),
+                      ("n", "<i4"), ("flags", "<i4")])
+
+# every symbol include/squigglekit_hip.h declares: name -> (restype, argtypes)
+_vp, _i16p, _i32p, _i64p, _dp = (C.c_void_p, C.POINTER(C.c_int16), C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_int64), C.POINTER(C.c_double))
+ABI = {
+    "sk_version": (C.c_char_p, []),
+    "sk_last_error": (C.c_char_p, []),
+    "sk_device_count": (C.c_int, []),
+    "sk_init": (C.c_int, [C.c_int]),
+    "sk_shutdown": (C.c_int, []),
+    "sk_sync": (C.c_int, []),
+    "sk_device_name": (C.c_int, [C.c_char_p, C.c_int]),
+    "sk_dev_alloc": (_vp, [C.c_size_t]),
+    "sk_dev_free": (C.c_int, [_vp]),
+    "sk_dev_upload": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "sk_dev_download": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "sk_segment_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, C.POINTER(SegParams),
+                                       _vp, _vp, C.c_int32]),
+    "sk_segment_batch_f64": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(SegParams), _vp, _vp, C.c_int32]),
+    "sk_segment_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, C.POINTER(SegParams),
+                                     _vp, _vp, C.c_int32]),
+    "sk_motifseq_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, _vp]),
+    "sk_motifseq_batch_f64": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, _vp]),
+    "sk_motifseq_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, _vp]),
+    "sk_dtw_subsequence_batch": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, _vp]),
+    "sk_dtw_subsequence": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _dp, _i32p, _i32p, _vp]),
+    "sk_normalise_i16": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _i32p]),
+    "sk_last_kernel_ms": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sk_synth_squiggles_dev": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, _vp, C.c_int32]),
+}
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-s", "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return SO_PATH
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library and bind every ABI symbol.  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise SquiggleKitError(-2, "%s not built (run `python -c 'import __graft_entry__ as g; "
+                                   "g.build()'` or `make -C squigglekit_amd/csrc`); there is no CPU "
+                                   "fallback" % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        for name, (res, argt) in ABI.items():
+            fn = getattr(L, name)            # AttributeError here == header/library drift
+            fn.restype = res
+            fn.argtypes = argt
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SquiggleKitError(rc, load().sk_last_error().decode(errors="replace"))
+
+
+_bound = None
+
+
+def init(device=None):
+    """Bind this thread to a GPU (default: $SK_DEVICE, else LOCAL_RANK, else 0)."""
+    global _bound
+    L = load()
+    if device is None:
+        device = int(os.environ.get("SK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    check(L.sk_init(int(device)))
+    _bound = int(device)
+    return _bound
+
+
+def ensure_init():
+    if _bound is None:
+        init()
+    return load()
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,196 @@
+"""Host-side mirror of the reference's two in-process boundaries, over the HIP C ABI.
+
+    get_segs(sig, args)            <->  segmenter.get_segs      (segmenter.py:399)
+    dtw_subsequence(x, y)          <->  mlpy.dtw_subsequence    (MotifSeq.py:437)
+
+plus the batch forms the GPU actually wants (many reads per call).  All arithmetic
+on samples happens in the HIP kernels; this module only marshals numpy buffers.
+Same names, argument meaning and "no segments -> False" behaviour as the
+reference so the parity tests read like calls into the reference.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import HIT_DTYPE, SegParams, SquiggleKitError, check, ptr
+
+
+# ----------------------------------------------------------------------------
+# packing helpers
+# ----------------------------------------------------------------------------
+def pack_i16(reads):
+    """list of 1-D integer arrays -> (int16 [R, stride] zero padded, int32 lens).
+    stride is a multiple of 8 so rows are 16-byte aligned (vector loads)."""
+    lens = np.array([len(r) for r in reads], dtype=np.int32)
+    stride = int(max(8, (int(lens.max()) + 7) // 8 * 8)) if len(reads) else 8
+    buf = np.zeros((len(reads), stride), dtype=np.int16)
+    for i, r in enumerate(reads):
+        buf[i, :len(r)] = r
+    return buf, lens
+
+
+def is_int16_exact(a):
+    """True if every value of the float/int array is an integer that fits int16."""
+    a = np.asarray(a)
+    if a.size == 0:
+        return True
+    if a.dtype.kind in "iu":
+        return bool(a.min() >= -32768 and a.max() <= 32767)
+    return bool(np.all(np.isfinite(a)) and np.all(a == np.rint(a))
+                and a.min() >= -32768 and a.max() <= 32767)
+
+
+# ----------------------------------------------------------------------------
+# segmenter path
+# ----------------------------------------------------------------------------
+def segment_batch(sig, lens=None, params=None, max_segs=64):
+    """scale_outliers + get_segs for every row of an int16 [R, stride] batch.
+
+    Returns (segs int32 [R, max_segs, 2], nsegs int32 [R]); grows max_segs and
+    retries on overflow.  Coordinates are in the FILTERED signal, like the
+    reference's (segmenter.py:209-211)."""
+    L = _lib.ensure_init()
+    sig = np.ascontiguousarray(sig, dtype=np.int16)
+    if sig.ndim != 2:
+        raise ValueError("sig must be [reads, samples]")
+    R, stride = sig.shape
+    lens = (np.full(R, stride, dtype=np.int32) if lens is None
+            else np.ascontiguousarray(lens, dtype=np.int32))
+    params = params or SegParams()
+    while True:
+        segs = np.zeros((R, max_segs, 2), dtype=np.int32)
+        nsegs = np.zeros(R, dtype=np.int32)
+        rc = L.sk_segment_batch_i16(ptr(sig), stride, ptr(lens), R, C.byref(params),
+                                    ptr(segs), ptr(nsegs), max_segs)
+        if rc == _lib.SK_ERR_OVERFLOW:
+            max_segs = int(nsegs.max()) + 8
+            continue
+        check(rc)
+        return segs, nsegs
+
+
+def segment_reads(reads, params=None):
+    """Fused scale_outliers + get_segs on a list of raw integer reads.
+    Returns, per read, a list of [start, end] or False (the reference's value)."""
+    if not len(reads):
+        return []
+    buf, lens = pack_i16(reads)
+    segs, nsegs = segment_batch(buf, lens, params)
+    return [segs[i, :nsegs[i]].tolist() if nsegs[i] else False for i in range(len(reads))]
+
+
+def get_segs(sig, args):
+    """Drop-in for segmenter.get_segs(sig, args): `sig` is already filtered
+    (segmenter.py:209), args carries error/corrector/window/seg_dist/std_scale/
+    stall_len.  Returns [[start, end], ...] or False."""
+    sig = np.asarray(sig)
+    if sig.size == 0:
+        return False
+    if not is_int16_exact(sig):
+        raise SquiggleKitError(-5, "float64 (pA) signals need sk_segment_batch_f64 (not built yet)")
+    s = sig.astype(np.int16)
+    p = SegParams(args.error, args.corrector, args.window, args.seg_dist, args.std_scale,
+                  args.stall_len, int(s.min()) - 1, int(s.max()) + 1)     # filter keeps everything
+    return segment_reads([s], p)[0]
+
+
+def test_segs(segs, args, err=None):
+    """segmenter.test_segs (segmenter.py:473-494): host-side acceptance filter.
+    Messages go to `err` (a file object) exactly as the reference writes them."""
+    import sys
+    import traceback
+    err = err or sys.stderr
+    try:
+        if args.stall:
+            if segs[0][0] > args.stall_start:
+                err.write("start seg too late!")
+                return False
+        if args.gap:
+            if segs[1][0] > segs[0][1] + args.gap_dist:
+                err.write("second seg too far!")
+                return False
+    except Exception:                                   # reference: bare except, read passes
+        err.write("something went wrong test_segs()")
+        traceback.print_exc(file=err)
+    return segs
+
+
+# ----------------------------------------------------------------------------
+# MotifSeq path
+# ----------------------------------------------------------------------------
+def motifseq_batch(sig, lens, motif, scale="medmad", scale_low=0, scale_hi=1200):
+    """scale_outliers + medmad/zscale + dtw_subsequence for every row of an
+    int16 [R, stride] batch.  Returns a HIT_DTYPE record array (dist, start,
+    end, n, flags); start/end index the FILTERED signal (MotifSeq.py:438-439)."""
+    L = _lib.ensure_init()
+    sig = np.ascontiguousarray(sig, dtype=np.int16)
+    R, stride = sig.shape
+    lens = (np.full(R, stride, dtype=np.int32) if lens is None
+            else np.ascontiguousarray(lens, dtype=np.int32))
+    motif = np.ascontiguousarray(motif, dtype=np.float64)
+    out = np.zeros(R, dtype=HIT_DTYPE)
+    check(L.sk_motifseq_batch_i16(ptr(sig), stride, ptr(lens), R, ptr(motif), motif.size,
+                                  _lib.SK_SCALE[scale], int(scale_low), int(scale_hi), ptr(out)))
+    return out
+
+
+def normalise(sig, scale="medmad", scale_low=0, scale_hi=1200):
+    """Filtered + normalised signal of one integer read, as MotifSeq hands it to
+    dtw_subsequence (MotifSeq.py:274-289)."""
+    L = _lib.ensure_init()
+    s = np.ascontiguousarray(sig, dtype=np.int16)
+    out = np.empty(max(1, s.size), dtype=np.float64)
+    n = C.c_int32(0)
+    check(L.sk_normalise_i16(ptr(s), s.size, _lib.SK_SCALE[scale], int(scale_low), int(scale_hi),
+                             ptr(out), C.byref(n)))
+    return out[:n.value].copy()
+
+
+class LastRowCost:
+    """What MotifSeq reads from mlpy's cost matrix: only `cost[-1, :]`
+    (MotifSeq.py:507-509).  The N x n matrix itself is never materialised."""
+
+    def __init__(self, last_row, nrows):
+        self._last = last_row
+        self.shape = (nrows, last_row.size)
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            row = key[0]
+            rest = key[1] if len(key) > 1 else slice(None)
+        else:
+            row, rest = key, slice(None)
+        if row in (-1, self.shape[0] - 1):
+            return self._last[rest]
+        raise IndexError("only the last row of the DTW cost matrix is kept on this path")
+
+
+def dtw_subsequence(x, y, last_row=False):
+    """Drop-in for mlpy.dtw_subsequence(x, y) as MotifSeq.py:437-439 consumes it:
+    returns (dist, cost, path) with path[1][0] == start and path[1][-1] == end.
+    `cost` supports cost[-1, :] when last_row=True, else it is None."""
+    L = _lib.ensure_init()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    dist, s, e = C.c_double(), C.c_int32(), C.c_int32()
+    row = np.empty(y.size, dtype=np.float64) if last_row else None
+    check(L.sk_dtw_subsequence(ptr(x), x.size, ptr(y), y.size, C.byref(dist), C.byref(s),
+                               C.byref(e), ptr(row) if last_row else None))
+    path = (np.array([0, x.size - 1]), np.array([s.value, e.value]))
+    return dist.value, (LastRowCost(row, x.size) if last_row else None), path
+
+
+def dtw_subsequence_batch(x, ys):
+    """dtw_subsequence(x, y) for a list of already-normalised float64 signals."""
+    L = _lib.ensure_init()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    off = np.zeros(len(ys) + 1, dtype=np.int64)
+    for i, y in enumerate(ys):
+        off[i + 1] = off[i] + len(y)
+    flat = (np.concatenate([np.asarray(y, dtype=np.float64) for y in ys])
+            if len(ys) else np.zeros(0))
+    flat = np.ascontiguousarray(flat, dtype=np.float64)
+    out = np.zeros(len(ys), dtype=HIT_DTYPE)
+    check(L.sk_dtw_subsequence_batch(ptr(x), x.size, ptr(flat), ptr(off), len(ys), ptr(out)))
+    return out

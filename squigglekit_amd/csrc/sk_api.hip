@@ -1,0 +1,312 @@
+// sk_api.hip -- the C-ABI entry points of include/squigglekit_hip.h.
+// Host logic only: argument checks, scratch sizing, H2D / launches / D2H on the bound
+// device's stream.  No arithmetic on sample data happens on the host.
+#include "sk_common.h"
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+int check_i16(const void *sig, int64_t stride, const int32_t *len, int32_t nreads)
+{
+    if (nreads < 0) return sk_fail(SK_ERR_INVALID, "nreads < 0");
+    if (nreads && (!sig || !len)) return sk_fail(SK_ERR_INVALID, "NULL sig/len");
+    if (stride <= 0) return sk_fail(SK_ERR_INVALID, "stride must be positive");
+    return SK_OK;
+}
+
+int check_seg_params(const sk_seg_params *p)
+{
+    if (!p) return sk_fail(SK_ERR_INVALID, "NULL sk_seg_params");
+    if (p->corrector < 0)
+        return sk_fail(SK_ERR_INVALID, "corrector must be >= 0 (the reference divides by zero otherwise)");
+    return SK_OK;
+}
+
+// clamp the outlier limits to what an int16 can hold (no sample can lie outside)
+void clamp_limits(int32_t *lo, int32_t *hi)
+{
+    if (*lo < -32769) *lo = -32769;
+    if (*hi > 32768) *hi = 32768;
+}
+
+__global__ void k_normalise_i16(const int16_t *__restrict__ comp, const sk_prep *__restrict__ prep,
+                                double *__restrict__ out)
+{
+    const sk_prep pr = prep[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pr.n; i += gridDim.x * blockDim.x)
+        out[i] = ((double)comp[i] - pr.center) / pr.scale;     // MotifSeq.py:199 / sklearn.scale
+}
+
+} // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ MotifSeq, device resident
+int sk_motifseq_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                        const double *motif, int32_t nmotif, int32_t scale_mode,
+                        int32_t scale_low, int32_t scale_hi, sk_hit *d_out)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    int rc = check_i16(d_sig, stride, d_len, nreads);
+    if (rc) return rc;
+    if (!motif || nmotif <= 0) return sk_fail(SK_ERR_INVALID, "empty motif");
+    if (scale_mode != SK_SCALE_MEDMAD && scale_mode != SK_SCALE_ZSCALE)
+        return sk_fail(SK_ERR_INVALID, "unknown scale mode %d", scale_mode);
+    if (nreads == 0) return SK_OK;
+    if (!d_out) return sk_fail(SK_ERR_INVALID, "NULL out");
+    clamp_limits(&scale_low, &scale_hi);
+    if ((rc = sk_reserve(c, &c->comp, (size_t)nreads * (size_t)stride * sizeof(int16_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
+
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nreads, scale_low, scale_hi,
+                            scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE, 0.0,
+                            (int16_t *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
+    if (rc) return rc;
+    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+
+    sk_sdtw_args a;
+    a.feed = SK_FEED_I16; a.samples = c->comp.p; a.stride = stride; a.off = nullptr;
+    a.prep = (const sk_prep *)c->prep.p; a.nreads = nreads; a.motif = motif; a.nmotif = nmotif;
+    a.out = d_out; a.last_row = nullptr;
+    rc = sk_launch_sdtw(c, &a);
+    if (rc) return rc;
+    c->ev_valid = true;
+    return SK_OK;
+}
+
+// ------------------------------------------------------------------ MotifSeq, host buffers
+int sk_motifseq_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
+                          const double *motif, int32_t nmotif, int32_t scale_mode,
+                          int32_t scale_low, int32_t scale_hi, sk_hit *out)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    int rc = check_i16(sig, stride, len, nreads);
+    if (rc) return rc;
+    if (nreads == 0) return SK_OK;
+    if (!out) return sk_fail(SK_ERR_INVALID, "NULL out");
+    const size_t sb = (size_t)nreads * (size_t)stride * sizeof(int16_t);
+    if ((rc = sk_reserve(c, &c->sig, sb))) return rc;
+    if ((rc = sk_reserve(c, &c->len, (size_t)nreads * sizeof(int32_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->out, (size_t)nreads * sizeof(sk_hit)))) return rc;
+    SK_HIP(hipMemcpyAsync(c->sig.p, sig, sb, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipMemcpyAsync(c->len.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    rc = sk_motifseq_dev_i16((const int16_t *)c->sig.p, stride, (const int32_t *)c->len.p, nreads, motif,
+                             nmotif, scale_mode, scale_low, scale_hi, (sk_hit *)c->out.p);
+    if (rc) return rc;
+    SK_HIP(hipMemcpyAsync(out, c->out.p, (size_t)nreads * sizeof(sk_hit), hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
+
+int sk_motifseq_batch_f64(const double *, const int64_t *, int32_t, const double *, int32_t, int32_t,
+                          int32_t, int32_t, sk_hit *)
+{
+    if (!sk_cur()) return SK_ERR_NO_DEVICE;
+    return sk_fail(SK_ERR_UNSUPPORTED, "float64 sample path not built yet");
+}
+
+// ------------------------------------------------------------------ mlpy boundary (pre-normalised f64)
+int sk_dtw_subsequence_batch(const double *x, int32_t nx, const double *y, const int64_t *off,
+                             int32_t nreads, sk_hit *out)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (nreads < 0 || nx <= 0 || !x) return sk_fail(SK_ERR_INVALID, "bad query");
+    if (nreads == 0) return SK_OK;
+    if (!y || !off || !out) return sk_fail(SK_ERR_INVALID, "NULL y/off/out");
+    const int64_t total = off[nreads] - off[0];
+    if (total < 0) return sk_fail(SK_ERR_INVALID, "offsets not increasing");
+    for (int32_t r = 0; r < nreads; r++) {
+        const int64_t n = off[r + 1] - off[r];
+        if (n < 0 || n > 0x7fffff00) return sk_fail(SK_ERR_INVALID, "bad length for read %d", r);
+    }
+    int rc;
+    if ((rc = sk_reserve(c, &c->sig, (size_t)(total > 0 ? total : 1) * sizeof(double)))) return rc;
+    if ((rc = sk_reserve(c, &c->off, (size_t)(nreads + 1) * sizeof(int64_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->out, (size_t)nreads * sizeof(sk_hit)))) return rc;
+    std::vector<int64_t> rel((size_t)nreads + 1);
+    for (int32_t r = 0; r <= nreads; r++) rel[r] = off[r] - off[0];
+    SK_HIP(hipMemcpyAsync(c->sig.p, y + off[0], (size_t)total * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipMemcpyAsync(c->off.p, rel.data(), rel.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));        // rel is about to go out of scope
+    sk_sdtw_args a;
+    a.feed = SK_FEED_F64_RAW; a.samples = c->sig.p; a.stride = 0; a.off = (const int64_t *)c->off.p;
+    a.prep = nullptr; a.nreads = nreads; a.motif = x; a.nmotif = nx; a.out = (sk_hit *)c->out.p;
+    a.last_row = nullptr;
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+    if ((rc = sk_launch_sdtw(c, &a))) return rc;
+    c->ev_valid = true;
+    SK_HIP(hipMemcpyAsync(out, c->out.p, (size_t)nreads * sizeof(sk_hit), hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
+
+int sk_dtw_subsequence(const double *x, int32_t nx, const double *y, int32_t ny,
+                       double *dist, int32_t *start, int32_t *end, double *cost_last_row)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (!x || !y || nx <= 0 || ny <= 0) return sk_fail(SK_ERR_INVALID, "empty x or y");
+    int rc;
+    if ((rc = sk_reserve(c, &c->sig, (size_t)ny * sizeof(double)))) return rc;
+    if ((rc = sk_reserve(c, &c->off, 2 * sizeof(int64_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->out, sizeof(sk_hit)))) return rc;
+    if (cost_last_row && (rc = sk_reserve(c, &c->misc, (size_t)ny * sizeof(double)))) return rc;
+    const int64_t rel[2] = {0, ny};
+    SK_HIP(hipMemcpyAsync(c->sig.p, y, (size_t)ny * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipMemcpyAsync(c->off.p, rel, sizeof rel, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    sk_sdtw_args a;
+    a.feed = SK_FEED_F64_RAW; a.samples = c->sig.p; a.stride = 0; a.off = (const int64_t *)c->off.p;
+    a.prep = nullptr; a.nreads = 1; a.motif = x; a.nmotif = nx; a.out = (sk_hit *)c->out.p;
+    a.last_row = cost_last_row ? (double *)c->misc.p : nullptr;
+    if ((rc = sk_launch_sdtw(c, &a))) return rc;
+    sk_hit h;
+    SK_HIP(hipMemcpyAsync(&h, c->out.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    if (cost_last_row)
+        SK_HIP(hipMemcpyAsync(cost_last_row, c->misc.p, (size_t)ny * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    if (dist) *dist = h.dist;
+    if (start) *start = h.start;
+    if (end) *end = h.end;
+    return SK_OK;
+}
+
+int sk_normalise_i16(const int16_t *sig, int32_t len, int32_t scale_mode,
+                     int32_t scale_low, int32_t scale_hi, double *out, int32_t *n_out)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (len < 0 || (len && (!sig || !out))) return sk_fail(SK_ERR_INVALID, "bad arguments");
+    if (scale_mode != SK_SCALE_MEDMAD && scale_mode != SK_SCALE_ZSCALE)
+        return sk_fail(SK_ERR_INVALID, "unknown scale mode %d", scale_mode);
+    if (len == 0) { if (n_out) *n_out = 0; return SK_OK; }
+    clamp_limits(&scale_low, &scale_hi);
+    const int64_t stride = ((int64_t)len + 7) & ~7ll;
+    int rc;
+    if ((rc = sk_reserve(c, &c->sig, (size_t)stride * 2))) return rc;
+    if ((rc = sk_reserve(c, &c->len, sizeof(int32_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->comp, (size_t)stride * 2))) return rc;
+    if ((rc = sk_reserve(c, &c->prep, sizeof(sk_prep)))) return rc;
+    if ((rc = sk_reserve(c, &c->misc, (size_t)len * sizeof(double)))) return rc;
+    SK_HIP(hipMemcpyAsync(c->sig.p, sig, (size_t)len * 2, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipMemcpyAsync(c->len.p, &len, sizeof len, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    rc = sk_launch_prep_i16(c, (const int16_t *)c->sig.p, stride, (const int32_t *)c->len.p, 1, scale_low,
+                            scale_hi, scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE, 0.0,
+                            (int16_t *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_normalise_i16, dim3(64), dim3(256), 0, c->stream, (const int16_t *)c->comp.p,
+                       (const sk_prep *)c->prep.p, (double *)c->misc.p);
+    SK_HIP(hipGetLastError());
+    sk_prep pr;
+    SK_HIP(hipMemcpyAsync(&pr, c->prep.p, sizeof pr, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    if (pr.n > 0)
+        SK_HIP(hipMemcpy(out, c->misc.p, (size_t)pr.n * sizeof(double), hipMemcpyDeviceToHost));
+    if (n_out) *n_out = pr.n;
+    return SK_OK;
+}
+
+// ------------------------------------------------------------------ segmenter
+int sk_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                       const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    int rc = check_i16(d_sig, stride, d_len, nreads);
+    if (rc) return rc;
+    if ((rc = check_seg_params(p))) return rc;
+    if (max_segs <= 0) return sk_fail(SK_ERR_INVALID, "max_segs must be positive");
+    if (nreads == 0) return SK_OK;
+    if (!d_segs || !d_nsegs) return sk_fail(SK_ERR_INVALID, "NULL segs/nsegs");
+    int32_t lo = p->lim_low, hi = p->lim_hi;
+    clamp_limits(&lo, &hi);
+    const int64_t words = (stride + 63) / 64;
+    if ((rc = sk_reserve(c, &c->comp, (size_t)nreads * (size_t)stride * sizeof(int16_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
+    if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * sizeof(uint64_t)))) return rc;
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nreads, lo, hi, SK_PREP_SEGMENT, p->std_scale,
+                            (int16_t *)c->comp.p, (sk_prep *)c->prep.p, (uint64_t *)c->mask.p, nreads);
+    if (rc) return rc;
+    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+    rc = sk_launch_segment_walk(c, (const uint64_t *)c->mask.p, nreads, nullptr, (const sk_prep *)c->prep.p,
+                                nreads, p, d_segs, d_nsegs, max_segs);
+    if (rc) return rc;
+    c->ev_valid = true;
+    return SK_OK;
+}
+
+int sk_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
+                         const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    int rc = check_i16(sig, stride, len, nreads);
+    if (rc) return rc;
+    if ((rc = check_seg_params(p))) return rc;
+    if (max_segs <= 0) return sk_fail(SK_ERR_INVALID, "max_segs must be positive");
+    if (nreads == 0) return SK_OK;
+    if (!segs || !nsegs) return sk_fail(SK_ERR_INVALID, "NULL segs/nsegs");
+    const size_t sb = (size_t)nreads * (size_t)stride * sizeof(int16_t);
+    const size_t gb = (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t);
+    if ((rc = sk_reserve(c, &c->sig, sb))) return rc;
+    if ((rc = sk_reserve(c, &c->len, (size_t)nreads * sizeof(int32_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->out, gb))) return rc;
+    if ((rc = sk_reserve(c, &c->out2, (size_t)nreads * sizeof(int32_t)))) return rc;
+    SK_HIP(hipMemcpyAsync(c->sig.p, sig, sb, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipMemcpyAsync(c->len.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    rc = sk_segment_dev_i16((const int16_t *)c->sig.p, stride, (const int32_t *)c->len.p, nreads, p,
+                            (int32_t *)c->out.p, (int32_t *)c->out2.p, max_segs);
+    if (rc) return rc;
+    SK_HIP(hipMemcpyAsync(segs, c->out.p, gb, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipMemcpyAsync(nsegs, c->out2.p, (size_t)nreads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    for (int32_t r = 0; r < nreads; r++)
+        if (nsegs[r] > max_segs)
+            return sk_fail(SK_ERR_OVERFLOW, "read %d has %d segments, max_segs is %d", r, nsegs[r], max_segs);
+    return SK_OK;
+}
+
+int sk_segment_batch_f64(const double *, const int64_t *, int32_t, const sk_seg_params *, int32_t *,
+                         int32_t *, int32_t)
+{
+    if (!sk_cur()) return SK_ERR_NO_DEVICE;
+    return sk_fail(SK_ERR_UNSUPPORTED, "float64 sample path not built yet");
+}
+
+// ------------------------------------------------------------------ bench input
+int sk_synth_squiggles_dev(int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
+                           uint64_t seed, const double *motif, int32_t nmotif)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (!d_sig || stride < nsamples || nreads < 0 || nsamples < 0)
+        return sk_fail(SK_ERR_INVALID, "bad arguments");
+    const int16_t *d_m = nullptr;
+    if (motif && nmotif > 0) {
+        std::vector<int16_t> mi((size_t)nmotif);
+        for (int i = 0; i < nmotif; i++) {
+            double v = rint(motif[i] * 93.4 + 511.0);
+            mi[i] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+        }
+        int rc = sk_reserve(c, &c->misc, mi.size() * 2);
+        if (rc) return rc;
+        SK_HIP(hipMemcpyAsync(c->misc.p, mi.data(), mi.size() * 2, hipMemcpyHostToDevice, c->stream));
+        SK_HIP(hipStreamSynchronize(c->stream));
+        d_m = (const int16_t *)c->misc.p;
+    }
+    int rc = sk_launch_synth(c, d_sig, stride, nreads, nsamples, seed, d_m, nmotif);
+    if (rc) return rc;
+    SK_HIP(hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,105 @@
+// sk_common.h -- internal declarations shared by the HIP translation units.
+// gfx950 only.  Not part of the public ABI (that is include/squigglekit_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdarg.h>
+#include <vector>
+#include "squigglekit_hip.h"
+
+#define SK_MAX_DEVICES 16
+#define SK_WAVE 64
+
+// Per-read result of the prep kernel; consumed by the DTW / segment kernels.
+// 48 bytes, one per read, lives in HBM.
+struct sk_prep {
+    int32_t n;        // samples surviving scale_outliers
+    int32_t flags;    // SK_FLAG_*
+    double  center;   // medmad: median            zscale: mean       segmenter: median
+    double  scale;    // medmad: MAD*1.4826        zscale: std (0->1) segmenter: std
+    double  top;      // segmenter: median + std*std_scale   (segmenter.py:413)
+    double  bot;      // segmenter: median - std*std_scale   (segmenter.py:414)
+};
+
+enum sk_prep_mode { SK_PREP_MEDMAD = 0, SK_PREP_ZSCALE = 1, SK_PREP_SEGMENT = 2 };
+
+// Growable device scratch buffer.
+struct sk_buf {
+    void  *p = nullptr;
+    size_t cap = 0;
+};
+
+struct sk_ctx {
+    int         device = -1;
+    bool        ready = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};   // prep start/stop, main start/stop
+    bool        ev_valid = false;
+    int         num_cu = 0;
+    // scratch (grown on demand, reused across calls)
+    sk_buf sig;       // staged input samples
+    sk_buf len;       // int32 per read
+    sk_buf off;       // int64 per read (+1) for ragged f64
+    sk_buf comp;      // compacted samples
+    sk_buf prep;      // sk_prep per read
+    sk_buf mask;      // in-band bit masks (segmenter)
+    sk_buf motif;     // laid-out motif rows
+    sk_buf out;       // sk_hit / segs staging
+    sk_buf out2;      // nsegs staging
+    sk_buf misc;
+    std::vector<double> motif_host;   // last laid-out motif (kept alive for async H2D)
+    std::vector<double> motif_src;    // the motif it was built from (upload cache key)
+};
+
+// ---- runtime (sk_runtime.hip) ----
+sk_ctx *sk_cur(void);                       // bound context or nullptr (error set)
+int  sk_fail(int code, const char *fmt, ...);
+int  sk_reserve(sk_ctx *c, sk_buf *b, size_t bytes);
+#define SK_HIP(call)                                                                    \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return sk_fail(SK_ERR_HIP, "%s failed: %s (%s:%d)", #call,                 \
+                           hipGetErrorString(e_), __FILE__, __LINE__);                  \
+    } while (0)
+
+// ---- prep (sk_prep.hip) ----
+// i16: rows of `stride` samples; comp gets the filtered samples of read r at
+// comp + r*stride.  mask (segmenter only) gets ceil(stride/64) words per read.
+int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len,
+                       int32_t nreads, int32_t lo, int32_t hi, int mode, double std_scale,
+                       int16_t *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_stride);
+// f64 ragged: read r is sig[off[r]..off[r+1]); comp uses the same offsets.
+int sk_launch_prep_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads,
+                       double lo, double hi, int mode, double std_scale,
+                       double *d_comp, sk_prep *d_prep, uint64_t *d_mask, const int64_t *d_mask_off);
+
+// ---- DTW (sk_sdtw.hip) ----
+// Input kinds for the sample feed.
+enum sk_feed { SK_FEED_I16 = 0,      // int16 filtered samples + (center, scale) from sk_prep
+               SK_FEED_F64_NORM = 1, // float64 filtered samples + (center, scale) from sk_prep
+               SK_FEED_F64_RAW = 2 };// float64 already normalised (mlpy boundary), ragged
+struct sk_sdtw_args {
+    int           feed;
+    const void   *samples;     // int16* or double*
+    int64_t       stride;      // row stride (feed I16), ignored when off != nullptr
+    const int64_t *off;        // ragged offsets (nreads+1) or nullptr
+    const sk_prep *prep;       // per-read n/center/scale (nullptr for F64_RAW: n from off)
+    int32_t       nreads;
+    const double *motif;       // HOST pointer, nmotif points
+    int32_t       nmotif;
+    sk_hit       *out;         // device, nreads records
+    double       *last_row;    // device, optional: cost[-1,:] of read 0 (single-pair call)
+};
+int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a);
+
+// ---- segment walk (sk_segment.hip) ----
+int sk_launch_segment_walk(sk_ctx *c, const uint64_t *d_mask, int64_t mask_stride,
+                           const int64_t *d_mask_off, const sk_prep *d_prep, int32_t nreads,
+                           const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs,
+                           int32_t max_segs);
+
+// ---- synth (sk_synth.hip) ----
+int sk_launch_synth(sk_ctx *c, int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
+                    uint64_t seed, const int16_t *d_motif_i16, int32_t nmotif);

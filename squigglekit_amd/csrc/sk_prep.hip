@@ -1,0 +1,357 @@
+// sk_prep.hip -- per-read filter + statistics ("prep") kernels for gfx950.
+//
+// Covers, per read (one 256-thread workgroup per read):
+//   scale_outliers      segmenter.py:311-318 / MotifSeq.py:317-324   strict lo < x < hi, order kept
+//   np.median           segmenter.py:410, MotifSeq.py:194            LDS counting histogram + rank select
+//   MAD                 MotifSeq.py:195-196                          derived from the value histogram
+//   np.mean / np.std    segmenter.py:412, sklearn.scale (MotifSeq.py:187)
+//                       summed in numpy's exact order: 8192-element chunks accumulated serially,
+//                       each chunk by the pairwise tree (leaves <= 128: eight strided accumulators,
+//                       ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), serial tail) so top/bot are bit-exact
+//   top / bot           segmenter.py:413-414
+//   in-band bit mask    the `a < top and a > bot` test of segmenter.py:431 for every sample
+//
+// int16 samples are integers, so median and MAD are exact in half-integer arithmetic and the
+// sum for the mean is exact in int64; only sum((x-mean)^2) depends on the order of additions.
+// HBM traffic per read: M*2 B in, n*2 B out (compacted samples, needed in order by the DTW /
+// segment kernels), 48 B of statistics, n/8 B of mask (segmenter only).
+#include "sk_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int NWAVE = TPB / 64;
+constexpr int NPY_BUFSIZE = 8192;     // numpy ufunc buffer: reduction chunk
+constexpr int PW_BLOCK = 128;         // numpy pairwise leaf size
+constexpr int MAX_NODES = 256;        // heap of the pairwise tree of one chunk (8 levels)
+
+// Fixed scratch at the front of dynamic LDS.
+struct Scratch {
+    int       wsum[2][NWAVE];         // per-wave counts (double buffered by iteration parity)
+    long long wred[NWAVE];
+    int       sel[4];                 // rank-select results
+    int       nleaf;
+    int       node_start[MAX_NODES];
+    int       node_len[MAX_NODES];
+    int       leaf_id[MAX_NODES];
+    double    node_sum[MAX_NODES];
+    double    bcast[2];
+};
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Block-wide exclusive scan of one int per thread; returns exclusive prefix, *total = block sum.
+__device__ __forceinline__ int block_excl_scan(int v, int *wsum /*[NWAVE]*/, int *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = wave_incl_scan(v, lane);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NWAVE; i++) {
+        int s = wsum[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+// Find the bins holding ranks k1 <= k2 of a histogram (counts sum to n).  Result in sc->sel[0..1].
+// Every thread scans a contiguous slice of bins.
+__device__ void rank_select2(const unsigned *hist, int nbins, int k1, int k2, Scratch *sc, int parity)
+{
+    const int per = (nbins + TPB - 1) / TPB;
+    const int b0 = threadIdx.x * per;
+    const int b1 = min(nbins, b0 + per);
+    int local = 0;
+    for (int b = b0; b < b1; b++) local += (int)hist[b];
+    int total;
+    int pre = block_excl_scan(local, sc->wsum[parity], &total);
+    if (local > 0) {
+        if (k1 >= pre && k1 < pre + local) {
+            int acc = pre;
+            for (int b = b0; b < b1; b++) { acc += (int)hist[b]; if (k1 < acc) { sc->sel[0] = b; break; } }
+        }
+        if (k2 >= pre && k2 < pre + local) {
+            int acc = pre;
+            for (int b = b0; b < b1; b++) { acc += (int)hist[b]; if (k2 < acc) { sc->sel[1] = b; break; } }
+        }
+    }
+    __syncthreads();
+}
+
+// Sum of term(i), i in [0, m), in the order numpy's pairwise_sum uses (m <= 8192).
+// term(i) must be a pure function.  All 256 threads call; result returned to every thread.
+template <typename Term>
+__device__ double pairwise_chunk(int m, Scratch *sc, Term term)
+{
+    const int tid = threadIdx.x;
+    if (m < 8) {                                   // numpy: plain serial loop from 0.0
+        if (tid == 0) {
+            double res = 0.0;
+            for (int i = 0; i < m; i++) res += term(i);
+            sc->bcast[0] = res;
+        }
+        __syncthreads();
+        double r = sc->bcast[0];
+        __syncthreads();
+        return r;
+    }
+    // ---- build the split tree top-down (heap order: node 1 = whole chunk) ------------
+    if (tid == 1) { sc->node_start[1] = 0; sc->node_len[1] = m; }
+    if (tid != 1 && tid < MAX_NODES) { sc->node_start[tid] = 0; sc->node_len[tid] = 0; }
+    __syncthreads();
+    for (int lvl = 1; lvl < 8; lvl++) {            // nodes [2^lvl, 2^(lvl+1))
+        const int lo = 1 << lvl;
+        if (tid >= lo && tid < 2 * lo) {
+            const int par = tid >> 1;
+            const int plen = sc->node_len[par];
+            if (plen > PW_BLOCK) {
+                int n2 = plen / 2;
+                n2 -= n2 % 8;
+                if (tid & 1) { sc->node_start[tid] = sc->node_start[par] + n2; sc->node_len[tid] = plen - n2; }
+                else         { sc->node_start[tid] = sc->node_start[par];      sc->node_len[tid] = n2; }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- leaf list -------------------------------------------------------------------
+    const int mylen = (tid < MAX_NODES && tid >= 1) ? sc->node_len[tid] : 0;
+    const int isleaf = (mylen > 0 && mylen <= PW_BLOCK) ? 1 : 0;
+    int nleaf;
+    const int slot = block_excl_scan(isleaf, sc->wsum[0], &nleaf);
+    if (isleaf) sc->leaf_id[slot] = tid;
+    __syncthreads();
+    // ---- leaf sums: 8 threads per leaf, lane j owns accumulator r[j] ------------------
+    const int grp = tid >> 3, j = tid & 7;
+    for (int li = grp; li < ((nleaf + 31) & ~31); li += TPB / 8) {
+        const bool act = li < nleaf;
+        const int node = act ? sc->leaf_id[li] : 0;
+        const int s = act ? sc->node_start[node] : 0;
+        const int len = act ? sc->node_len[node] : 0;
+        double r = 0.0;
+        if (act) {
+            r = term(s + j);
+            const int full = len - (len % 8);
+            for (int i = 8; i < full; i += 8) r += term(s + i + j);
+        }
+        r += __shfl_xor(r, 1);                      // (r0+r1) (r2+r3) (r4+r5) (r6+r7)
+        r += __shfl_xor(r, 2);                      // ((r0+r1)+(r2+r3)) ...
+        r += __shfl_xor(r, 4);
+        if (act && j == 0) {
+            for (int i = len - (len % 8); i < len; i++) r += term(s + i);
+            sc->node_sum[node] = r;
+        }
+    }
+    __syncthreads();
+    // ---- combine bottom-up: parent = left + right ------------------------------------
+    for (int lvl = 6; lvl >= 0; lvl--) {
+        const int lo = 1 << lvl;
+        if (tid >= lo && tid < 2 * lo && sc->node_len[tid] > PW_BLOCK)
+            sc->node_sum[tid] = sc->node_sum[2 * tid] + sc->node_sum[2 * tid + 1];
+        __syncthreads();
+    }
+    double res = sc->node_sum[1];
+    __syncthreads();
+    return res;
+}
+
+// np.add.reduce order over n terms: serial over 8192-chunks of pairwise sums.
+template <typename Term>
+__device__ double numpy_sum(int n, Scratch *sc, Term term)
+{
+    double res = 0.0;
+    for (int base = 0; base < n; base += NPY_BUFSIZE) {
+        const int m = min(NPY_BUFSIZE, n - base);
+        res += pairwise_chunk(m, sc, [&](int i) { return term(base + i); });
+    }
+    return res;
+}
+
+// ------------------------------------------------------------------------------------------
+// int16 reads
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB)
+void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *__restrict__ len, int nreads,
+                int lo, int hi, int mode, double std_scale, int vec_ok,
+                int16_t *__restrict__ comp, sk_prep *__restrict__ prep,
+                uint64_t *__restrict__ maskT, int64_t mask_rows)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    Scratch *sc = (Scratch *)lds_raw;
+    unsigned *hist = (unsigned *)(lds_raw + sizeof(Scratch));
+    const int nbins = max(0, hi - lo - 1);                 // values lo+1 .. hi-1
+    unsigned *dev = hist + nbins;                          // medmad: 2*nbins+1 bins of |2x - 2med|
+    const int ndev = (mode == SK_PREP_MEDMAD) ? 2 * nbins + 1 : 0;
+
+    const int r = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int M = len[r];
+    const int16_t *row = sig + (int64_t)r * stride;
+    int16_t *crow = comp + (int64_t)r * stride;
+
+    for (int b = tid; b < nbins + ndev; b += TPB) hist[b] = 0u;
+    if (tid < 4) sc->sel[tid] = 0;
+    __syncthreads();
+
+    // ---- pass A: filter, compact (order preserving), histogram, exact integer sum ----
+    long long isum = 0;
+    int run = 0;                                           // survivors so far (block uniform)
+    int parity = 0;
+    for (int base = 0; base < M; base += TPB * 8, parity ^= 1) {
+        const int i0 = base + tid * 8;
+        int16_t v[8];
+        if (vec_ok && i0 + 8 <= M) {
+            const int4 q = *(const int4 *)(row + i0);
+            v[0] = (int16_t)(q.x & 0xffff); v[1] = (int16_t)(q.x >> 16);
+            v[2] = (int16_t)(q.y & 0xffff); v[3] = (int16_t)(q.y >> 16);
+            v[4] = (int16_t)(q.z & 0xffff); v[5] = (int16_t)(q.z >> 16);
+            v[6] = (int16_t)(q.w & 0xffff); v[7] = (int16_t)(q.w >> 16);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = (i0 + k < M) ? row[i0 + k] : (int16_t)lo;   // lo is filtered out
+        }
+        unsigned keep = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int x = v[k];
+            if (i0 + k < M && x > lo && x < hi) keep |= 1u << k;
+        }
+        const int cnt = __popc(keep);
+        const int inc = wave_incl_scan(cnt, lane);
+        if (lane == 63) sc->wsum[parity][w] = inc;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < NWAVE; i++) {
+            const int s = sc->wsum[parity][i];
+            if (i < w) wbase += s;
+            tot += s;
+        }
+        int o = run + wbase + inc - cnt;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (keep & (1u << k)) {
+                const int x = v[k];
+                crow[o++] = (int16_t)x;
+                atomicAdd(&hist[x - lo - 1], 1u);
+                isum += x;
+            }
+        }
+        run += tot;
+    }
+    const int n = run;
+    __syncthreads();                                       // histogram + compacted samples complete
+
+    sk_prep pr;
+    pr.n = n; pr.flags = 0; pr.center = 0.0; pr.scale = 1.0; pr.top = 0.0; pr.bot = 0.0;
+    if (n == 0) {
+        pr.flags = SK_FLAG_EMPTY;
+        const double qnan = __builtin_nan("");
+        pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
+        if (tid == 0) prep[r] = pr;
+        return;
+    }
+
+    // ---- median: ranks (n-1)/2 and n/2 of the value histogram -------------------------
+    rank_select2(hist, nbins, (n - 1) / 2, n / 2, sc, 0);
+    const int med2 = (sc->sel[0] + lo + 1) + (sc->sel[1] + lo + 1);    // 2 * median, exact
+    const double median = (double)med2 * 0.5;
+    __syncthreads();
+
+    if (mode == SK_PREP_MEDMAD) {
+        // MAD from the value histogram: |x - med| = |2x - med2| / 2
+        for (int b = tid; b < nbins; b += TPB) {
+            const unsigned cb = hist[b];
+            if (cb) atomicAdd(&dev[abs(2 * (b + lo + 1) - med2)], cb);
+        }
+        __syncthreads();
+        rank_select2(dev, ndev, (n - 1) / 2, n / 2, sc, 1);
+        const double mad = (double)(sc->sel[0] + sc->sel[1]) * 0.25;   // (d1/2 + d2/2) / 2, exact
+        pr.center = median;
+        pr.scale = mad * 1.4826;                                       // MotifSeq.py:196
+        if (mad == 0.0) pr.flags |= SK_FLAG_DEGENERATE;
+        if (tid == 0) prep[r] = pr;
+        return;
+    }
+
+    // ---- mean (exact integer sum) and numpy-order std ----------------------------------
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) isum += __shfl_xor(isum, d);
+    if (lane == 0) sc->wred[w] = isum;
+    __syncthreads();
+    long long S = 0;
+#pragma unroll
+    for (int i = 0; i < NWAVE; i++) S += sc->wred[i];
+    const double mean = (double)S / (double)n;
+    const double ssq = numpy_sum(n, sc, [&](int i) {
+        const double d = (double)crow[i] - mean;
+        return d * d;
+    });
+    const double sd = sqrt(ssq / (double)n);
+
+    if (mode == SK_PREP_ZSCALE) {
+        pr.center = mean;
+        pr.scale = (sd == 0.0) ? 1.0 : sd;                 // sklearn _handle_zeros_in_scale
+        if (tid == 0) prep[r] = pr;
+        return;
+    }
+
+    // ---- segmenter thresholds + in-band mask (segmenter.py:413-414,431) -----------------
+    const double spread = sd * std_scale;
+    const double top = median + spread;
+    const double bot = median - spread;
+    pr.center = median; pr.scale = sd; pr.top = top; pr.bot = bot;
+    if (tid == 0) prep[r] = pr;
+    for (int base = 0; base < n; base += TPB) {
+        const int i = base + tid;
+        bool in = false;
+        if (i < n) {
+            const double a = (double)crow[i];
+            in = (a < top) && (a > bot);
+        }
+        const unsigned long long bits = __ballot(in);
+        if (lane == 0) maskT[(int64_t)(i >> 6) * mask_rows + r] = bits;
+    }
+}
+
+} // namespace
+
+int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len,
+                       int32_t nreads, int32_t lo, int32_t hi, int mode, double std_scale,
+                       int16_t *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_stride)
+{
+    if (nreads <= 0) return SK_OK;
+    const int64_t nbins = (int64_t)hi - (int64_t)lo - 1 > 0 ? (int64_t)hi - lo - 1 : 0;
+    const int64_t words = (mode == SK_PREP_MEDMAD) ? 3 * nbins + 1 : nbins;
+    const size_t lds = sizeof(Scratch) + (size_t)words * 4;
+    if (lds > 160 * 1024)
+        return sk_fail(SK_ERR_UNSUPPORTED,
+                       "outlier limits (%d, %d) span %lld integer values: the LDS histogram holds %d (%s)",
+                       lo, hi, (long long)nbins, (mode == SK_PREP_MEDMAD) ? 12900 : 38900,
+                       "narrow -scale_low/-scale_hi / -lim_low/-lim_hi");
+    const int vec_ok = (((uintptr_t)d_sig & 15) == 0 && (stride % 8) == 0) ? 1 : 0;
+    if (lds > 64 * 1024)
+        SK_HIP(hipFuncSetAttribute((const void *)k_prep_i16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_prep_i16, dim3(nreads), dim3(TPB), lds, c->stream, d_sig, stride, d_len, nreads,
+                       lo, hi, mode, std_scale, vec_ok, d_comp, d_prep, d_mask, mask_stride);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
+}
+
+int sk_launch_prep_f64(sk_ctx *, const double *, const int64_t *, int32_t, double, double, int, double,
+                       double *, sk_prep *, uint64_t *, const int64_t *)
+{
+    return sk_fail(SK_ERR_UNSUPPORTED, "float64 sample path not built yet");
+}

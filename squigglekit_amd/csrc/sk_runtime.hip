@@ -1,0 +1,188 @@
+// sk_runtime.hip -- device contexts, error reporting, device memory.
+// One context per device, created by sk_init(); each host thread is bound to
+// one device (thread_local), so a multi-GPU host drives one thread per GPU or,
+// as bench.py does, one process per GPU.
+#include "sk_common.h"
+#include <mutex>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char  g_err[512] = "";
+static thread_local int   g_cur = -1;
+static sk_ctx             g_ctx[SK_MAX_DEVICES];
+static std::mutex         g_mu;
+
+int sk_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+sk_ctx *sk_cur(void)
+{
+    if (g_cur < 0 || !g_ctx[g_cur].ready) {
+        sk_fail(SK_ERR_NO_DEVICE, "no device bound: call sk_init(device) first (no CPU fallback exists)");
+        return nullptr;
+    }
+    if (hipSetDevice(g_cur) != hipSuccess) {
+        sk_fail(SK_ERR_NO_DEVICE, "hipSetDevice(%d) failed", g_cur);
+        return nullptr;
+    }
+    return &g_ctx[g_cur];
+}
+
+int sk_reserve(sk_ctx *c, sk_buf *b, size_t bytes)
+{
+    (void)c;
+    if (bytes <= b->cap) return SK_OK;
+    if (b->p) { SK_HIP(hipFree(b->p)); b->p = nullptr; b->cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b->p, want);
+    if (e != hipSuccess) {
+        b->p = nullptr;
+        return sk_fail(SK_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b->cap = want;
+    return SK_OK;
+}
+
+extern "C" {
+
+const char *sk_version(void) { return "squigglekit-hip 0.1.0 (gfx950)"; }
+const char *sk_last_error(void) { return g_err; }
+
+int sk_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        sk_fail(SK_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+        return 0;
+    }
+    return n;
+}
+
+int sk_init(int device)
+{
+    int n = sk_device_count();
+    if (n <= 0) return sk_fail(SK_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n || device >= SK_MAX_DEVICES)
+        return sk_fail(SK_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    std::lock_guard<std::mutex> lk(g_mu);
+    sk_ctx *c = &g_ctx[device];
+    SK_HIP(hipSetDevice(device));
+    if (!c->ready) {
+        hipDeviceProp_t prop;
+        SK_HIP(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return sk_fail(SK_ERR_NO_DEVICE, "device %d is %s; this build targets gfx950 only",
+                           device, prop.gcnArchName);
+        c->device = device;
+        c->num_cu = prop.multiProcessorCount;
+        SK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        for (int i = 0; i < 4; i++) SK_HIP(hipEventCreate(&c->ev[i]));
+        c->ready = true;
+    }
+    g_cur = device;
+    return SK_OK;
+}
+
+static void free_buf(sk_buf *b) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+
+int sk_shutdown(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int d = 0; d < SK_MAX_DEVICES; d++) {
+        sk_ctx *c = &g_ctx[d];
+        if (!c->ready) continue;
+        (void)hipSetDevice(d);
+        (void)hipStreamSynchronize(c->stream);
+        sk_buf *bufs[] = {&c->sig, &c->len, &c->off, &c->comp, &c->prep, &c->mask,
+                          &c->motif, &c->out, &c->out2, &c->misc};
+        for (sk_buf *b : bufs) free_buf(b);
+        for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev[i]);
+        (void)hipStreamDestroy(c->stream);
+        *c = sk_ctx();
+    }
+    g_cur = -1;
+    return SK_OK;
+}
+
+int sk_sync(void)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    SK_HIP(hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
+
+int sk_device_name(char *buf, int cap)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (!buf || cap <= 0) return sk_fail(SK_ERR_INVALID, "bad buffer");
+    hipDeviceProp_t prop;
+    SK_HIP(hipGetDeviceProperties(&prop, c->device));
+    snprintf(buf, (size_t)cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return SK_OK;
+}
+
+void *sk_dev_alloc(size_t bytes)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return nullptr;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        sk_fail(SK_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+int sk_dev_free(void *dptr)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (dptr) SK_HIP(hipFree(dptr));
+    return SK_OK;
+}
+
+int sk_dev_upload(void *dst_dev, const void *src_host, size_t bytes)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (bytes && (!dst_dev || !src_host)) return sk_fail(SK_ERR_INVALID, "NULL pointer");
+    SK_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
+
+int sk_dev_download(void *dst_host, const void *src_dev, size_t bytes)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (bytes && (!dst_host || !src_dev)) return sk_fail(SK_ERR_INVALID, "NULL pointer");
+    SK_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
+
+int sk_last_kernel_ms(float *prep_ms, float *main_ms)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (!c->ev_valid) return sk_fail(SK_ERR_INVALID, "no timed call yet");
+    SK_HIP(hipEventSynchronize(c->ev[3]));
+    float a = 0.f, b = 0.f;
+    SK_HIP(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+    SK_HIP(hipEventElapsedTime(&b, c->ev[2], c->ev[3]));
+    if (prep_ms) *prep_ms = a;
+    if (main_ms) *main_ms = b;
+    return SK_OK;
+}
+
+} // extern "C"

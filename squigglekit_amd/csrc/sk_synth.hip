@@ -1,0 +1,107 @@
+// sk_synth.hip -- deterministic synthetic squiggle generator on the device.
+//
+// Bench tooling, not a reference function (the reference ships no generator).  Same squiggle
+// model as squigglekit_amd/synth.py: event levels ~ N(500, 80) with
+// dwell 1 + Poisson(8), N(0, 8) noise, a stall plateau near the start, with p = 0.5 a second
+// plateau, with p = 0.5 an implanted copy of the motif, and four spike samples from
+// {-5, 0, 950, 1100}.  Counter-based RNG (splitmix64 of seed/read/counter), one lane per read,
+// eight samples per 16-byte store.  The numbers differ from the numpy generator's; parity
+// tests never depend on them -- they read the generated batch back.
+#include "sk_common.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct Rng {
+    uint64_t key, ctr;
+    __device__ uint64_t next() { return mix64(key + (ctr++) * 0xD1342543DE82EF95ull); }
+    __device__ float uni() { return ((float)(next() >> 40) + 0.5f) * (1.0f / 16777216.0f); }   // (0,1)
+    __device__ int below(int n) { return (int)((next() >> 33) % (uint64_t)n); }
+    __device__ float gauss()
+    {
+        const float u1 = uni(), u2 = uni();
+        return sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
+    }
+    __device__ int poisson8()
+    {
+        const float limit = 3.3546263e-4f;      // exp(-8)
+        int k = 0;
+        float p = uni();
+        while (p > limit && k < 64) { k++; p *= uni(); }
+        return k;
+    }
+};
+
+__global__ __launch_bounds__(64)
+void k_synth(int16_t *__restrict__ sig, int64_t stride, int nreads, int M, uint64_t seed,
+             const int16_t *__restrict__ motif, int N)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nreads) return;
+    Rng g;
+    g.key = mix64(seed ^ mix64((uint64_t)r + 0x1234567ull));
+    g.ctr = 0;
+    const int scale = max(1, M / 4000);
+    const int s0 = g.below(60), l0 = 100 + g.below(500);
+    const bool has2 = g.uni() < 0.5f;
+    const int s1 = 1200 * scale + g.below(2200 * scale), l1 = 160 + g.below(340);
+    const bool hit = (motif != nullptr) && (N > 0) && (N < M) && (g.uni() < 0.5f);
+    const int moff = (N < M) ? g.below(M - N) : 0;
+    int spos[4], sval[4];
+    const int spikes[4] = {-5, 0, 950, 1100};
+    for (int k = 0; k < 4; k++) { spos[k] = g.below(M); sval[k] = spikes[g.below(4)]; }
+
+    int16_t *row = sig + (int64_t)r * stride;
+    float level = 500.0f + 80.0f * g.gauss();
+    int left = 1 + g.poisson8();
+    const bool vec = ((((uintptr_t)row) & 15) == 0);
+    for (int base = 0; base < M; base += 8) {
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = base + k;
+            if (left == 0) { level = 500.0f + 80.0f * g.gauss(); left = 1 + g.poisson8(); }
+            left--;
+            float x = level + 8.0f * g.gauss();
+            if (i >= s0 && i < s0 + l0) x = 505.0f + 12.0f * g.gauss();
+            if (has2 && i >= s1 && i < s1 + l1) x = 495.0f + 10.0f * g.gauss();
+            int q = (int)rintf(x);
+            q = min(32767, max(-32768, q));
+            if (hit && i >= moff && i < moff + N) q = motif[i - moff];
+#pragma unroll
+            for (int s = 0; s < 4; s++) if (i == spos[s]) q = sval[s];
+            v[k] = q;
+        }
+        if (vec && base + 8 <= M) {
+            int4 o;
+            o.x = (v[0] & 0xffff) | (v[1] << 16);
+            o.y = (v[2] & 0xffff) | (v[3] << 16);
+            o.z = (v[4] & 0xffff) | (v[5] << 16);
+            o.w = (v[6] & 0xffff) | (v[7] << 16);
+            *(int4 *)(row + base) = o;
+        } else {
+            for (int k = 0; k < 8 && base + k < M; k++) row[base + k] = (int16_t)v[k];
+        }
+    }
+}
+
+} // namespace
+
+int sk_launch_synth(sk_ctx *c, int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
+                    uint64_t seed, const int16_t *d_motif_i16, int32_t nmotif)
+{
+    if (nreads <= 0 || nsamples <= 0) return SK_OK;
+    const int grid = (nreads + 63) / 64;
+    hipLaunchKernelGGL(k_synth, dim3(grid), dim3(64), 0, c->stream, d_sig, stride, nreads, nsamples, seed,
+                       d_motif_i16, nmotif);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
+}

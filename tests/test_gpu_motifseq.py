@@ -1,0 +1,147 @@
+"""GPU parity: MotifSeq path (filter -> medmad/zscale -> subsequence DTW) vs the oracle.
+
+Bar: start/end exact, distance bit-identical (the north-star tolerance is 1e-5;
+FP64 min-plus is order independent so we assert equality and report the max
+deviation if that ever fails)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DIST_TOL = 1e-5   # BASELINE.json north_star tolerance
+
+
+def _assert_hits(got, want, label=""):
+    bad = np.nonzero((got["start"] != want["start"]) | (got["end"] != want["end"])
+                     | (got["n"] != want["n"]))[0]
+    assert bad.size == 0, "%s start/end/n mismatch at reads %s: got %s want %s" % (
+        label, bad[:5], got[bad[:5]], want[bad[:5]])
+    both_nan = np.isnan(got["dist"]) & np.isnan(want["dist"])
+    dev = np.where(both_nan, 0.0, np.abs(got["dist"] - want["dist"]))
+    assert np.all(dev <= DIST_TOL), "%s max |ddist| = %g" % (label, dev.max())
+    assert np.all((got["dist"] == want["dist"]) | both_nan), \
+        "%s distances within tol but not bit-identical (max dev %g)" % (label, dev.max())
+
+
+@pytest.mark.parametrize("nx", [1, 2, 5, 15, 16, 17, 31, 64, 100, 163, 200, 255, 256, 257, 320, 500, 777, 1024])
+def test_dtw_raw_vs_oracle(gpu, ora, nx):
+    """mlpy boundary: dtw_subsequence(x, y) on pre-normalised float64 signals."""
+    from squigglekit_amd import api
+    rng = np.random.default_rng(1000 + nx)
+    x = rng.normal(0, 1, nx)
+    ys = []
+    for ny in [1, 2, 3, 15, 16, 17, 63, 64, 65, 100, 257, 1000, 2500]:
+        ys.append(rng.normal(0, 1, ny))
+    # tie-heavy integer-valued cases exercise the back-trace tie order
+    xi = rng.integers(-2, 3, nx).astype(float)
+    yt = [rng.integers(-2, 3, ny).astype(float) for ny in [5, 40, 333, 1200]]
+    for q, sigs in ((x, ys), (xi, yt)):
+        got = api.dtw_subsequence_batch(q, sigs)
+        for i, y in enumerate(sigs):
+            d, s, e = ora.dtw_subsequence(q, y)
+            assert (got["start"][i], got["end"][i]) == (s, e), (nx, len(y), got[i], (d, s, e))
+            assert got["dist"][i] == d, (nx, len(y), got["dist"][i], d)
+            assert got["n"][i] == len(y)
+
+
+def test_dtw_single_pair_and_last_row(gpu, ora):
+    from squigglekit_amd import api
+    rng = np.random.default_rng(5)
+    x = rng.normal(0, 1, 163)
+    y = rng.normal(0, 1, 3000)
+    dist, cost, path = api.dtw_subsequence(x, y, last_row=True)
+    d, s, e, full = ora.dtw_subsequence(x, y, want_cost=True)
+    assert (dist, path[1][0], path[1][-1]) == (d, s, e)
+    assert np.array_equal(cost[-1, :], full[-1, :])
+    assert np.array_equal(cost[-1, ], full[-1, ])
+
+
+@pytest.mark.parametrize("scale", ["medmad", "zscale"])
+@pytest.mark.parametrize("nmotif", [163, 200])
+def test_motifseq_batch_synthetic(gpu, ora, example_model, scale, nmotif):
+    """C3-shaped batch (reduced read count so the oracle finishes in seconds)."""
+    from squigglekit_amd import api, synth
+    motif = example_model if nmotif == 163 else synth.synthetic_motif(nmotif)
+    sig = synth.squiggle_batch(384, 4000, synth.SEED_C3, motif=motif)
+    lens = np.full(sig.shape[0], sig.shape[1], dtype=np.int32)
+    got = api.motifseq_batch(sig, lens, motif, scale=scale)
+    want = ora.motifseq_batch_i16(sig, lens, motif, scale_mode=0 if scale == "medmad" else 1)
+    _assert_hits(got, want, "synthetic %s N=%d" % (scale, nmotif))
+
+
+def test_motifseq_ragged_and_edge_reads(gpu, ora, example_model):
+    from squigglekit_amd import api, synth
+    sig = synth.squiggle_batch(40, 2048, 77, motif=example_model)
+    lens = np.array([2048, 1, 2, 7, 8, 9, 63, 64, 65, 100, 163, 164, 500, 1000, 2047, 2048] * 2 + [2048] * 8,
+                    dtype=np.int32)
+    sig[20, :] = 0            # nothing survives the filter (0 < x strict)
+    sig[21, :] = 1500         # nothing survives (x < 1200 strict)
+    sig[22, :] = 500          # constant read: MAD == 0 -> degenerate under medmad
+    sig[23, :1000] = 1199; sig[23, 1000:] = 1
+    for scale in ("medmad", "zscale"):
+        got = api.motifseq_batch(sig, lens, example_model, scale=scale)
+        want = ora.motifseq_batch_i16(sig, lens, example_model, scale_mode=0 if scale == "medmad" else 1)
+        ok = np.ones(len(lens), dtype=bool)
+        if scale == "medmad":
+            ok &= ~(want["n"] > 0) | np.isfinite(want["dist"])      # MAD==0 rows: reference divides by 0
+        assert np.array_equal(got["n"], want["n"])
+        _assert_hits(got[ok], want[ok], "ragged " + scale)
+        assert got["flags"][20] & 1 and got["flags"][21] & 1
+        assert np.isnan(got["dist"][20]) and got["start"][20] == -1 and got["end"][20] == -1
+        if scale == "medmad":
+            assert got["flags"][22] & 2
+
+
+def test_motifseq_real_read_golden(gpu, ora, example_read):
+    """Rows the reference printed for example/test.fast5 (DTW digits from the oracle stub)."""
+    from squigglekit_amd import api
+    gold = load_golden("motifseq_cli.json.gz")
+    model32 = None
+    raw = example_read["signal"]
+    for run in gold["runs"]:
+        if run["tsv"] != "real_raw" or run["flags"][:1] != ["-l"]:
+            continue
+        scale = run["flags"][1]
+        row = run["stdout"].strip().split("\n")[1].split("\t")
+        # the reference built the model through convert_fasta (float32-valued currents)
+        if model32 is None:
+            vals = np.array(gold["model_expanded"]["values"])
+            model32 = vals.astype(np.float32).astype(np.float64)
+        got = api.motifseq_batch(raw[None, :], np.array([raw.size], dtype=np.int32), model32, scale=scale)
+        assert (int(row[3]), int(row[4])) == (got["start"][0], got["end"][0])
+        assert float(row[6]) == got["dist"][0]
+
+
+def test_normalise_matches_reference_vectors(gpu):
+    """Normalised signals vs what the reference's numpy/sklearn code produced."""
+    from squigglekit_amd import api, synth
+    gold = load_golden("motifseq_norm.json.gz")
+    model = np.array(load_golden("motifseq_cli.json.gz")["model_expanded"]["values"])
+    sig = synth.squiggle_batch(6, 4000, synth.SEED_C3, motif=model)
+    for v in gold["vectors"]:
+        y = api.normalise(sig[v["read"]], scale=v["mode"])
+        want = np.array(v["y"])
+        assert y.shape == want.shape
+        assert np.array_equal(y, want), (v["mode"], v["read"], np.abs(y - want).max())
+
+
+def test_long_reads_and_long_motif(gpu, ora):
+    """C5-shaped: 20 000-sample reads vs a 500-point motif (L=64 kernel)."""
+    from squigglekit_amd import api, synth
+    motif = synth.synthetic_motif(500, seed=11)
+    sig = synth.squiggle_batch(12, 20000, synth.SEED_C5, motif=motif)
+    lens = np.full(12, 20000, dtype=np.int32)
+    got = api.motifseq_batch(sig, lens, motif)
+    want = ora.motifseq_batch_i16(sig, lens, motif)
+    _assert_hits(got, want, "C5")
+
+
+def test_unsupported_and_invalid_are_loud(gpu):
+    from squigglekit_amd import api
+    from squigglekit_amd._lib import SquiggleKitError
+    sig = np.full((1, 64), 500, dtype=np.int16)
+    with pytest.raises(SquiggleKitError):
+        api.motifseq_batch(sig, None, np.zeros(2000))          # motif too long for this build
+    with pytest.raises(SquiggleKitError):
+        api.motifseq_batch(sig, None, np.zeros(0))

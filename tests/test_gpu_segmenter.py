@@ -1,0 +1,101 @@
+"""GPU parity: segmenter path (scale_outliers -> median/std thresholds -> get_segs
+state machine) vs goldens minted from the reference and vs the oracle.
+Bar: bit-exact segment boundaries."""
+import types
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(kw):
+    from squigglekit_amd._lib import SegParams
+    return SegParams(**kw)
+
+
+def test_kats_from_reference(gpu):
+    """Hand-checkable known-answer tests produced by /root/reference/segmenter.py."""
+    from squigglekit_amd import api
+    gold = load_golden("segmenter_get_segs.json.gz")
+    for k in gold["kats"]:
+        res = api.segment_reads([np.array(k["sig"], dtype=np.int16)], _params(k["params"]))[0]
+        assert res == k["segs"], (k["name"], res, k["segs"])
+
+
+def test_synthetic_reads_match_reference(gpu):
+    from squigglekit_amd import api, synth
+    import hashlib
+    gold = load_golden("segmenter_get_segs.json.gz")["synthetic"]
+    sig = synth.squiggle_batch(gold["reads"], gold["samples"], gold["seed"])
+    assert hashlib.sha256(sig.tobytes()).hexdigest() == gold["sha256"], "synthetic generator drifted"
+    lens = np.full(sig.shape[0], sig.shape[1] - 1, dtype=np.int32)      # Num=-1 drops the last sample
+    for run in gold["runs"]:
+        segs, nsegs = api.segment_batch(sig, lens, _params(run["params"]))
+        for r in range(sig.shape[0]):
+            got = segs[r, :nsegs[r]].tolist()
+            assert got == run["segs"][r], (run["params"], r, got, run["segs"][r])
+
+
+def test_real_read_golden(gpu, example_read):
+    from squigglekit_amd import api
+    gold = load_golden("segmenter_get_segs.json.gz")["real_read"]
+    raw = example_read["signal"]
+    want = [g for g in gold if g["kind"] == "raw"][0]
+    res = api.segment_reads([raw[:-1]])[0]
+    assert res == want["segs"]
+
+
+def test_get_segs_mirror(gpu, ora):
+    """api.get_segs(sig, args) has the reference's call shape (already-filtered sig)."""
+    from squigglekit_amd import api, synth
+    sig = synth.squiggle_batch(4, 3000, 99)
+    args = types.SimpleNamespace(error=5, corrector=50, window=150, seg_dist=50, std_scale=0.75, stall_len=0.25)
+    for r in range(4):
+        f = sig[r][(sig[r] > 0) & (sig[r] < 900)]
+        assert api.get_segs(f, args) == ora.get_segs(f)
+
+
+def test_vs_oracle_random_params_and_lengths(gpu, ora):
+    """Oracle comparison over ragged lengths and parameter corners (incl. live corrector)."""
+    from squigglekit_amd import api, synth
+    rng = np.random.default_rng(4242)
+    sig = synth.squiggle_batch(96, 6000, 31337)
+    lens = rng.integers(1, 6001, size=96).astype(np.int32)
+    lens[:6] = [1, 2, 63, 64, 65, 6000]
+    sig[7, :] = 0                       # empty after filter
+    sig[8, :] = 500                     # std == 0 -> empty band
+    variants = [dict(), dict(error=10, corrector=0), dict(error=12, corrector=3, window=30),
+                dict(window=10, seg_dist=0, stall_len=0.0), dict(std_scale=3.0),
+                dict(error=0), dict(window=1, error=0, seg_dist=1000),
+                dict(lim_low=400, lim_hi=600), dict(stall_len=1.5)]
+    for kw in variants:
+        p = _params(kw)
+        segs, nsegs = api.segment_batch(sig, lens, p, max_segs=16)
+        okw = {k: v for k, v in kw.items() if k not in ("lim_low", "lim_hi")}
+        osegs, onsegs = ora.segment_batch_i16(sig, lens, ora.SegParams(**okw), lo=p.lim_low, hi=p.lim_hi,
+                                              max_segs=segs.shape[1])
+        assert np.array_equal(nsegs, onsegs), (kw, np.nonzero(nsegs != onsegs)[0][:5])
+        for r in range(96):
+            assert np.array_equal(segs[r, :nsegs[r]], osegs[r, :nsegs[r]]), (kw, r)
+
+
+def test_long_read_chunks_numpy_sum_order(gpu, ora):
+    """n > 8192 exercises numpy's chunked pairwise summation inside np.std."""
+    from squigglekit_amd import api, synth
+    sig = synth.squiggle_batch(6, 40000, 555)
+    lens = np.array([40000, 8192, 8193, 16385, 20001, 36977], dtype=np.int32)
+    segs, nsegs = api.segment_batch(sig, lens)
+    osegs, onsegs = ora.segment_batch_i16(sig, lens, max_segs=segs.shape[1])
+    assert np.array_equal(nsegs, onsegs)
+    for r in range(6):
+        assert np.array_equal(segs[r, :nsegs[r]], osegs[r, :nsegs[r]])
+
+
+def test_invalid_params_are_loud(gpu):
+    from squigglekit_amd import api
+    from squigglekit_amd._lib import SquiggleKitError
+    with pytest.raises(SquiggleKitError):
+        api.segment_batch(np.full((1, 64), 500, dtype=np.int16), None, _params(dict(corrector=-1)))
