@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- whole-job throughput of the SquiggleKit hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload motifseq|segmenter]
+
+Headline (BASELINE.json `metric`): reads/s of the MotifSeq path -- scale_outliers ->
+medmad -> subsequence DTW -- for 4 000-sample int16 reads against a 200-point motif
+(config C4: 1 000 000 reads per GPU, seed 20260929 + rank, synthetic squiggles generated
+on the device).  One "step" = one pass of the hot path (prep kernel + DTW kernel) over the
+whole HBM-resident batch; inputs are already in HBM when the timed region starts.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): reads are sharded, no data-path
+collective; torch.distributed (backend nccl == RCCL) provides the barrier, the MAX over
+ranks of the elapsed time and the final all-gather of the 24-byte hit records.  torch is
+plumbing only -- the kernels, memory and stream are the library's own (ctypes C ABI).
+
+Rank 0 prints ONE JSON line with the driver's contract plus `roofline` (HIP-event kernel
+time vs algorithmic bytes; the VALU view is inside it because this kernel is FP64-VALU bound,
+see DESIGN.md) and `cpu_baseline` (the oracle's mlpy-style C restatement timed on one host
+core over a bounded sample of the same reads -- the only place the oracle is timed).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_F64_LANEOPS = 256 * 4 * 16 * 2.4e9   # 3.93e13 f64 add/min/cmp lane-ops per second
+HIT_BYTES = 24
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="motifseq", choices=["motifseq", "segmenter"])
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
+    ap.add_argument("--samples", type=int, default=4000)
+    ap.add_argument("--motif", type=int, default=200, help="motif points")
+    ap.add_argument("--scale", default="medmad", choices=["medmad", "zscale"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (a.gpus, a.gpus))
+        a.gpus = world
+
+    from squigglekit_amd import _lib, synth
+    from squigglekit_amd._lib import SegParams, check, ptr, HIT_DTYPE
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    L = _lib.load()
+    _lib.init(local)
+
+    R, M, N = a.reads, a.samples, a.motif
+    stride = (M + 7) // 8 * 8
+    motif = synth.synthetic_motif(N)
+    seed = (synth.SEED_C4 if a.workload == "motifseq" else synth.SEED_C2) + rank
+
+    # ---- device-resident inputs -------------------------------------------------------
+    d_sig = L.sk_dev_alloc(R * stride * 2)
+    d_len = L.sk_dev_alloc(R * 4)
+    if not d_sig or not d_len:
+        check(-4)
+    lens = np.full(R, M if a.workload == "motifseq" else M - 1, dtype=np.int32)   # segmenter: Num=-1
+    check(L.sk_dev_upload(d_len, ptr(lens), lens.nbytes))
+    check(L.sk_synth_squiggles_dev(d_sig, stride, R, M, seed, ptr(motif), N))
+
+    max_segs = 16
+    if a.workload == "motifseq":
+        if world > 1:
+            out_t = torch.empty(R * HIT_BYTES, dtype=torch.uint8, device="cuda")
+            gath_t = torch.empty(world * R * HIT_BYTES, dtype=torch.uint8, device="cuda")
+            d_out = C.c_void_p(out_t.data_ptr())
+        else:
+            d_out = L.sk_dev_alloc(R * HIT_BYTES)
+        mode = _lib.SK_SCALE[a.scale]
+
+        def step():
+            check(L.sk_motifseq_dev_i16(d_sig, stride, d_len, R, ptr(motif), N, mode, 0, 1200, d_out))
+            check(L.sk_sync())
+            if world > 1:                      # the one exchange: gather of the hit records (RCCL)
+                dist.all_gather_into_tensor(gath_t, out_t)
+    else:
+        d_segs = L.sk_dev_alloc(R * max_segs * 2 * 4)
+        d_nsegs = L.sk_dev_alloc(R * 4)
+        sp = SegParams()
+
+        def step():
+            check(L.sk_segment_dev_i16(d_sig, stride, d_len, R, C.byref(sp), d_segs, d_nsegs, max_segs))
+            check(L.sk_sync())
+
+    def fence():
+        check(L.sk_sync())
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    prep_ms = main_ms = 0.0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        p_, m_ = C.c_float(), C.c_float()
+        check(L.sk_last_kernel_ms(C.byref(p_), C.byref(m_)))   # HIP events on the library's stream
+        prep_ms += p_.value
+        main_ms += m_.value
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prep_ms /= max(1, a.steps)
+    main_ms /= max(1, a.steps)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / a.steps * 1e3
+    value = world * R * a.steps / elapsed
+    alg_bytes = R * (2 * M + HIT_BYTES)                       # 2*M in + 24 out per read
+
+    # ---- parity + CPU baseline on a bounded sample of rank 0's reads -------------------
+    from oracle import oracle as ora
+    S = min(R, 8192)
+    sample = np.empty((S, stride), dtype=np.int16)
+    check(L.sk_dev_download(ptr(sample), d_sig, sample.nbytes))
+    parity, cpu = {}, None
+    if a.workload == "motifseq":
+        hits = np.empty(S, dtype=HIT_DTYPE)
+        check(L.sk_dev_download(ptr(hits), d_out, hits.nbytes))
+        n0 = min(S, 128)
+        t0 = time.perf_counter()
+        want = [ora.motifseq_batch_i16(sample[:n0], lens[:n0], motif, scale_mode=mode)]
+        dt = time.perf_counter() - t0
+        done = n0
+        if a.cpu_seconds > 0 and done < S:
+            more = int(min(S - done, max(0, (a.cpu_seconds - dt) / (dt / n0))))
+            if more > 0:
+                t1 = time.perf_counter()
+                want.append(ora.motifseq_batch_i16(sample[done:done + more], lens[done:done + more], motif,
+                                                   scale_mode=mode))
+                dt += time.perf_counter() - t1
+                done += more
+        want = np.concatenate(want)
+        got = hits[:done]
+        parity = {"reads_checked": int(done),
+                  "start_end_exact": bool(np.array_equal(got["start"], want["start"])
+                                          and np.array_equal(got["end"], want["end"])),
+                  "max_abs_ddist": float(np.nanmax(np.abs(got["dist"] - want["dist"]))),
+                  "dist_bit_identical": bool(np.array_equal(got["dist"], want["dist"]))}
+        cpu = {"value": done / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+               "sample": "%d of rank 0's reads (%d x %d-pt motif): oracle C restatement of "
+                         "filter+medmad+mlpy dtw_subsequence (full matrix malloc per call), gcc -O2, 1 thread, %.1f s"
+                         % (done, M, N, dt),
+               "host_cores_total": os.cpu_count()}
+        cells = float(N) * float(np.mean(got["n"]))
+        valu = {"bound": "valu_f64", "achieved": R * cells * 4 / (main_ms * 1e-3) / 1e12,
+                "peak": VALU_F64_LANEOPS / 1e12, "unit": "Tlane-op/s (4 canonical f64 ops per cell)"}
+        valu["frac"] = valu["achieved"] / valu["peak"]
+        dominant, dom_ms = "k_sdtw", main_ms
+    else:
+        segs = np.empty((S, max_segs, 2), dtype=np.int32)
+        nsegs = np.empty(S, dtype=np.int32)
+        check(L.sk_dev_download(ptr(segs), d_segs, segs.nbytes))
+        check(L.sk_dev_download(ptr(nsegs), d_nsegs, nsegs.nbytes))
+        t0 = time.perf_counter()
+        osegs, onsegs = ora.segment_batch_i16(sample, lens[:S], max_segs=max_segs)
+        dt = time.perf_counter() - t0
+        same = bool(np.array_equal(nsegs, onsegs)) and all(
+            np.array_equal(segs[r, :nsegs[r]], osegs[r, :nsegs[r]]) for r in range(S))
+        parity = {"reads_checked": int(S), "segments_bit_exact": same}
+        cpu = {"value": S / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+               "sample": "%d of rank 0's reads: oracle C restatement of filter+get_segs, gcc -O2, 1 thread, %.2f s"
+                         % (S, dt), "host_cores_total": os.cpu_count()}
+        alg_bytes = R * (2 * M + 4 + 8 * 2)
+        valu = None
+        dominant, dom_ms = ("k_prep_i16", prep_ms) if prep_ms >= main_ms else ("k_segment_walk", main_ms)
+
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel_ms": {"prep": prep_ms, "main": main_ms},
+                "algorithmic_bytes_per_launch": alg_bytes}
+    if valu:
+        roofline["binding"] = "valu_f64 (min-plus recurrence; HBM is not the limiter, DESIGN.md)"
+        roofline["valu"] = valu
+
+    name = ("reads/sec MotifSeq DTW (4k-sample read x 200-sample motif)" if a.workload == "motifseq"
+            else "reads/sec segmenter (4k-sample read)")
+    line = {"metric": name, "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64" if a.workload == "motifseq" else "int16/f64",
+            "data": "synthetic",
+            "config": {"workload": ("MotifSeq C4" if a.workload == "motifseq" else "segmenter C2-1M")
+                       + ": %d reads x %d int16 samples per GPU" % (R, M)
+                       + (", %d-pt motif, %s" % (N, a.scale) if a.workload == "motifseq" else ", default flags"),
+                       "reads_per_gpu": R, "samples": M, "motif_points": N if a.workload == "motifseq" else None,
+                       "seed": seed, "sharding": "reads block-sharded, %d rank(s), result all-gather over RCCL" % world},
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity}
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
