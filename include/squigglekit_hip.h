@@ -139,6 +139,8 @@ int sk_dtw_subsequence(const double *x, int32_t nx, const double *y, int32_t ny,
  * out must hold len doubles; *n_out receives the filtered length. */
 int sk_normalise_i16(const int16_t *sig, int32_t len, int32_t scale_mode,
                      int32_t scale_low, int32_t scale_hi, double *out, int32_t *n_out);
+int sk_normalise_f64(const double *sig, int32_t len, int32_t scale_mode,
+                     int32_t scale_low, int32_t scale_hi, double *out, int32_t *n_out);
 
 /* ---- instrumentation -------------------------------------------------- */
 /* HIP-event durations (ms) of the kernels of the most recent *_dev / batch

@@ -79,6 +79,7 @@ ABI = {
     "sk_dtw_subsequence_batch": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, _vp]),
     "sk_dtw_subsequence": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _dp, _i32p, _i32p, _vp]),
     "sk_normalise_i16": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _i32p]),
+    "sk_normalise_f64": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _i32p]),
     "sk_last_kernel_ms": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sk_synth_squiggles_dev": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, _vp, C.c_int32]),
 }

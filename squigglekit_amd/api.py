@@ -80,6 +80,50 @@ def segment_reads(reads, params=None):
     return [segs[i, :nsegs[i]].tolist() if nsegs[i] else False for i in range(len(reads))]
 
 
+def pack_f64(reads):
+    """list of 1-D float arrays -> (flat float64, int64 offsets[R+1])."""
+    off = np.zeros(len(reads) + 1, dtype=np.int64)
+    for i, r in enumerate(reads):
+        off[i + 1] = off[i] + len(r)
+    flat = (np.concatenate([np.asarray(r, dtype=np.float64) for r in reads])
+            if len(reads) else np.zeros(0))
+    return np.ascontiguousarray(flat, dtype=np.float64), off
+
+
+def segment_reads_f64(reads, params=None, max_segs=64):
+    """Fused scale_outliers + get_segs on float64 (pA) reads (segmenter.py:198-199)."""
+    if not len(reads):
+        return []
+    L = _lib.ensure_init()
+    flat, off = pack_f64(reads)
+    params = params or SegParams()
+    R = len(reads)
+    while True:
+        segs = np.zeros((R, max_segs, 2), dtype=np.int32)
+        nsegs = np.zeros(R, dtype=np.int32)
+        rc = L.sk_segment_batch_f64(ptr(flat), ptr(off), R, C.byref(params), ptr(segs), ptr(nsegs), max_segs)
+        if rc == _lib.SK_ERR_OVERFLOW:
+            max_segs = int(nsegs.max()) + 8
+            continue
+        check(rc)
+        return [segs[i, :nsegs[i]].tolist() if nsegs[i] else False for i in range(R)]
+
+
+def segment_any(reads, params=None):
+    """Route each read to the int16 kernels when it is integer valued and fits,
+    else to the float64 kernels; results come back in input order."""
+    ints = [i for i, r in enumerate(reads) if is_int16_exact(r)]
+    flts = [i for i in range(len(reads)) if i not in set(ints)]
+    out = [None] * len(reads)
+    if ints:
+        for i, res in zip(ints, segment_reads([np.asarray(reads[i]).astype(np.int16) for i in ints], params)):
+            out[i] = res
+    if flts:
+        for i, res in zip(flts, segment_reads_f64([reads[i] for i in flts], params)):
+            out[i] = res
+    return out
+
+
 def get_segs(sig, args):
     """Drop-in for segmenter.get_segs(sig, args): `sig` is already filtered
     (segmenter.py:209), args carries error/corrector/window/seg_dist/std_scale/
@@ -87,12 +131,12 @@ def get_segs(sig, args):
     sig = np.asarray(sig)
     if sig.size == 0:
         return False
-    if not is_int16_exact(sig):
-        raise SquiggleKitError(-5, "float64 (pA) signals need sk_segment_batch_f64 (not built yet)")
-    s = sig.astype(np.int16)
+    # limits that keep every sample: the caller has already run scale_outliers
+    lo = int(np.floor(float(sig.min()))) - 1
+    hi = int(np.ceil(float(sig.max()))) + 1
     p = SegParams(args.error, args.corrector, args.window, args.seg_dist, args.std_scale,
-                  args.stall_len, int(s.min()) - 1, int(s.max()) + 1)     # filter keeps everything
-    return segment_reads([s], p)[0]
+                  args.stall_len, lo, hi)
+    return segment_any([sig], p)[0]
 
 
 def test_segs(segs, args, err=None):
@@ -135,15 +179,47 @@ def motifseq_batch(sig, lens, motif, scale="medmad", scale_low=0, scale_hi=1200)
     return out
 
 
+def motifseq_reads_f64(reads, motif, scale="medmad", scale_low=0, scale_hi=1200):
+    """Same as motifseq_batch for float64 (pA) reads given as a list (MotifSeq.py:270)."""
+    L = _lib.ensure_init()
+    flat, off = pack_f64(reads)
+    motif = np.ascontiguousarray(motif, dtype=np.float64)
+    out = np.zeros(len(reads), dtype=HIT_DTYPE)
+    check(L.sk_motifseq_batch_f64(ptr(flat), ptr(off), len(reads), ptr(motif), motif.size,
+                                  _lib.SK_SCALE[scale], int(scale_low), int(scale_hi), ptr(out)))
+    return out
+
+
+def motifseq_any(reads, motif, scale="medmad", scale_low=0, scale_hi=1200):
+    """Integer-valued reads go through the int16 kernels, the rest through the
+    float64 kernels (bit-identical results either way); input order is kept."""
+    out = np.zeros(len(reads), dtype=HIT_DTYPE)
+    ints = [i for i, r in enumerate(reads) if is_int16_exact(r)]
+    iset = set(ints)
+    flts = [i for i in range(len(reads)) if i not in iset]
+    if ints:
+        buf, lens = pack_i16([np.asarray(reads[i]).astype(np.int16) for i in ints])
+        out[ints] = motifseq_batch(buf, lens, motif, scale, scale_low, scale_hi)
+    if flts:
+        out[flts] = motifseq_reads_f64([reads[i] for i in flts], motif, scale, scale_low, scale_hi)
+    return out
+
+
 def normalise(sig, scale="medmad", scale_low=0, scale_hi=1200):
-    """Filtered + normalised signal of one integer read, as MotifSeq hands it to
+    """Filtered + normalised signal of one read, as MotifSeq hands it to
     dtw_subsequence (MotifSeq.py:274-289)."""
     L = _lib.ensure_init()
-    s = np.ascontiguousarray(sig, dtype=np.int16)
-    out = np.empty(max(1, s.size), dtype=np.float64)
     n = C.c_int32(0)
-    check(L.sk_normalise_i16(ptr(s), s.size, _lib.SK_SCALE[scale], int(scale_low), int(scale_hi),
-                             ptr(out), C.byref(n)))
+    if is_int16_exact(sig):
+        s = np.ascontiguousarray(np.asarray(sig).astype(np.int16))
+        out = np.empty(max(1, s.size), dtype=np.float64)
+        check(L.sk_normalise_i16(ptr(s), s.size, _lib.SK_SCALE[scale], int(scale_low), int(scale_hi),
+                                 ptr(out), C.byref(n)))
+    else:
+        s = np.ascontiguousarray(sig, dtype=np.float64)
+        out = np.empty(max(1, s.size), dtype=np.float64)
+        check(L.sk_normalise_f64(ptr(s), s.size, _lib.SK_SCALE[scale], int(scale_low), int(scale_hi),
+                                 ptr(out), C.byref(n)))
     return out[:n.value].copy()
 
 

@@ -39,6 +39,14 @@ __global__ void k_normalise_i16(const int16_t *__restrict__ comp, const sk_prep 
         out[i] = ((double)comp[i] - pr.center) / pr.scale;     // MotifSeq.py:199 / sklearn.scale
 }
 
+__global__ void k_normalise_f64(const double *__restrict__ comp, const sk_prep *__restrict__ prep,
+                                double *__restrict__ out)
+{
+    const sk_prep pr = prep[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pr.n; i += gridDim.x * blockDim.x)
+        out[i] = (comp[i] - pr.center) / pr.scale;
+}
+
 } // namespace
 
 extern "C" {
@@ -103,11 +111,64 @@ int sk_motifseq_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len
     return SK_OK;
 }
 
-int sk_motifseq_batch_f64(const double *, const int64_t *, int32_t, const double *, int32_t, int32_t,
-                          int32_t, int32_t, sk_hit *)
+// Stage a ragged float64 batch: samples -> c->sig, zero-based offsets -> c->off.
+// Returns the total sample count in *total and the longest read in *maxlen.
+static int stage_ragged_f64(sk_ctx *c, const double *sig, const int64_t *off, int32_t nreads,
+                            int64_t *total, int64_t *maxlen)
 {
-    if (!sk_cur()) return SK_ERR_NO_DEVICE;
-    return sk_fail(SK_ERR_UNSUPPORTED, "float64 sample path not built yet");
+    if (!sig || !off) return sk_fail(SK_ERR_INVALID, "NULL sig/off");
+    std::vector<int64_t> rel((size_t)nreads + 1);
+    int64_t mx = 0;
+    for (int32_t r = 0; r <= nreads; r++) rel[r] = off[r] - off[0];
+    for (int32_t r = 0; r < nreads; r++) {
+        const int64_t n = rel[r + 1] - rel[r];
+        if (n < 0 || n > 0x7fffff00) return sk_fail(SK_ERR_INVALID, "bad length for read %d", r);
+        if (n > mx) mx = n;
+    }
+    *total = rel[nreads];
+    *maxlen = mx;
+    int rc;
+    if ((rc = sk_reserve(c, &c->sig, (size_t)(*total > 0 ? *total : 1) * sizeof(double)))) return rc;
+    if ((rc = sk_reserve(c, &c->off, rel.size() * sizeof(int64_t)))) return rc;
+    SK_HIP(hipMemcpyAsync(c->sig.p, sig + off[0], (size_t)*total * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipMemcpyAsync(c->off.p, rel.data(), rel.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));        // rel goes out of scope
+    return SK_OK;
+}
+
+int sk_motifseq_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
+                          const double *motif, int32_t nmotif, int32_t scale_mode,
+                          int32_t scale_low, int32_t scale_hi, sk_hit *out)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (nreads < 0) return sk_fail(SK_ERR_INVALID, "nreads < 0");
+    if (!motif || nmotif <= 0) return sk_fail(SK_ERR_INVALID, "empty motif");
+    if (scale_mode != SK_SCALE_MEDMAD && scale_mode != SK_SCALE_ZSCALE)
+        return sk_fail(SK_ERR_INVALID, "unknown scale mode %d", scale_mode);
+    if (nreads == 0) return SK_OK;
+    if (!out) return sk_fail(SK_ERR_INVALID, "NULL out");
+    int64_t total, maxlen;
+    int rc = stage_ragged_f64(c, sig, off, nreads, &total, &maxlen);
+    if (rc) return rc;
+    if ((rc = sk_reserve(c, &c->comp, (size_t)(total > 0 ? total : 1) * sizeof(double)))) return rc;
+    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
+    if ((rc = sk_reserve(c, &c->out, (size_t)nreads * sizeof(sk_hit)))) return rc;
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    rc = sk_launch_prep_f64(c, (const double *)c->sig.p, (const int64_t *)c->off.p, nreads, (double)scale_low,
+                            (double)scale_hi, scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE,
+                            0.0, (double *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
+    if (rc) return rc;
+    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+    sk_sdtw_args a;
+    a.feed = SK_FEED_F64_NORM; a.samples = c->comp.p; a.stride = 0; a.off = (const int64_t *)c->off.p;
+    a.prep = (const sk_prep *)c->prep.p; a.nreads = nreads; a.motif = motif; a.nmotif = nmotif;
+    a.out = (sk_hit *)c->out.p; a.last_row = nullptr;
+    if ((rc = sk_launch_sdtw(c, &a))) return rc;
+    c->ev_valid = true;
+    SK_HIP(hipMemcpyAsync(out, c->out.p, (size_t)nreads * sizeof(sk_hit), hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    return SK_OK;
 }
 
 // ------------------------------------------------------------------ mlpy boundary (pre-normalised f64)
@@ -214,6 +275,38 @@ int sk_normalise_i16(const int16_t *sig, int32_t len, int32_t scale_mode,
     return SK_OK;
 }
 
+int sk_normalise_f64(const double *sig, int32_t len, int32_t scale_mode,
+                     int32_t scale_low, int32_t scale_hi, double *out, int32_t *n_out)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (len < 0 || (len && (!sig || !out))) return sk_fail(SK_ERR_INVALID, "bad arguments");
+    if (scale_mode != SK_SCALE_MEDMAD && scale_mode != SK_SCALE_ZSCALE)
+        return sk_fail(SK_ERR_INVALID, "unknown scale mode %d", scale_mode);
+    if (len == 0) { if (n_out) *n_out = 0; return SK_OK; }
+    const int64_t off[2] = {0, len};
+    int64_t total, maxlen;
+    int rc = stage_ragged_f64(c, sig, off, 1, &total, &maxlen);
+    if (rc) return rc;
+    if ((rc = sk_reserve(c, &c->comp, (size_t)len * sizeof(double)))) return rc;
+    if ((rc = sk_reserve(c, &c->prep, sizeof(sk_prep)))) return rc;
+    if ((rc = sk_reserve(c, &c->misc, (size_t)len * sizeof(double)))) return rc;
+    rc = sk_launch_prep_f64(c, (const double *)c->sig.p, (const int64_t *)c->off.p, 1, (double)scale_low,
+                            (double)scale_hi, scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE,
+                            0.0, (double *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_normalise_f64, dim3(64), dim3(256), 0, c->stream, (const double *)c->comp.p,
+                       (const sk_prep *)c->prep.p, (double *)c->misc.p);
+    SK_HIP(hipGetLastError());
+    sk_prep pr;
+    SK_HIP(hipMemcpyAsync(&pr, c->prep.p, sizeof pr, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    if (pr.n > 0)
+        SK_HIP(hipMemcpy(out, c->misc.p, (size_t)pr.n * sizeof(double), hipMemcpyDeviceToHost));
+    if (n_out) *n_out = pr.n;
+    return SK_OK;
+}
+
 // ------------------------------------------------------------------ segmenter
 int sk_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
                        const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs)
@@ -275,11 +368,43 @@ int sk_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len,
     return SK_OK;
 }
 
-int sk_segment_batch_f64(const double *, const int64_t *, int32_t, const sk_seg_params *, int32_t *,
-                         int32_t *, int32_t)
+int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads, const sk_seg_params *p,
+                         int32_t *segs, int32_t *nsegs, int32_t max_segs)
 {
-    if (!sk_cur()) return SK_ERR_NO_DEVICE;
-    return sk_fail(SK_ERR_UNSUPPORTED, "float64 sample path not built yet");
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (nreads < 0) return sk_fail(SK_ERR_INVALID, "nreads < 0");
+    int rc = check_seg_params(p);
+    if (rc) return rc;
+    if (max_segs <= 0) return sk_fail(SK_ERR_INVALID, "max_segs must be positive");
+    if (nreads == 0) return SK_OK;
+    if (!segs || !nsegs) return sk_fail(SK_ERR_INVALID, "NULL segs/nsegs");
+    int64_t total, maxlen;
+    if ((rc = stage_ragged_f64(c, sig, off, nreads, &total, &maxlen))) return rc;
+    const int64_t words = (maxlen + 63) / 64 > 0 ? (maxlen + 63) / 64 : 1;
+    const size_t gb = (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t);
+    if ((rc = sk_reserve(c, &c->comp, (size_t)(total > 0 ? total : 1) * sizeof(double)))) return rc;
+    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
+    if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * sizeof(uint64_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->out, gb))) return rc;
+    if ((rc = sk_reserve(c, &c->out2, (size_t)nreads * sizeof(int32_t)))) return rc;
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    rc = sk_launch_prep_f64(c, (const double *)c->sig.p, (const int64_t *)c->off.p, nreads, (double)p->lim_low,
+                            (double)p->lim_hi, SK_PREP_SEGMENT, p->std_scale, (double *)c->comp.p,
+                            (sk_prep *)c->prep.p, (uint64_t *)c->mask.p, nreads);
+    if (rc) return rc;
+    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+    rc = sk_launch_segment_walk(c, (const uint64_t *)c->mask.p, nreads, nullptr, (const sk_prep *)c->prep.p,
+                                nreads, p, (int32_t *)c->out.p, (int32_t *)c->out2.p, max_segs);
+    if (rc) return rc;
+    c->ev_valid = true;
+    SK_HIP(hipMemcpyAsync(segs, c->out.p, gb, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipMemcpyAsync(nsegs, c->out2.p, (size_t)nreads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    for (int32_t r = 0; r < nreads; r++)
+        if (nsegs[r] > max_segs)
+            return sk_fail(SK_ERR_OVERFLOW, "read %d has %d segments, max_segs is %d", r, nsegs[r], max_segs);
+    return SK_OK;
 }
 
 // ------------------------------------------------------------------ bench input

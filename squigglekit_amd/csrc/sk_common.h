@@ -73,7 +73,7 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
 // f64 ragged: read r is sig[off[r]..off[r+1]); comp uses the same offsets.
 int sk_launch_prep_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads,
                        double lo, double hi, int mode, double std_scale,
-                       double *d_comp, sk_prep *d_prep, uint64_t *d_mask, const int64_t *d_mask_off);
+                       double *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_rows);
 
 // ---- DTW (sk_sdtw.hip) ----
 // Input kinds for the sample feed.

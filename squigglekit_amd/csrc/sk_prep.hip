@@ -326,6 +326,209 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// float64 reads (pA TSVs, segmenter.py:198-199 / MotifSeq.py:270; fast5 input converted to pA)
+// ------------------------------------------------------------------------------------------
+// Values are arbitrary doubles, so the median is found by an MSD radix select over the
+// order-preserving 64-bit image of each double: 8-bit digits, one 256-bin LDS histogram per
+// pass (one bin per thread), starting below the bits that min and max have in common.
+
+__device__ __forceinline__ unsigned long long f64_key(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+__device__ void block_minmax_u64(unsigned long long &mn, unsigned long long &mx, unsigned long long *tmp /*[2*NWAVE]*/)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long a = __shfl_xor(mn, d), b = __shfl_xor(mx, d);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if (lane == 0) { tmp[w] = mn; tmp[NWAVE + w] = mx; }
+    __syncthreads();
+    mn = tmp[0]; mx = tmp[NWAVE];
+#pragma unroll
+    for (int i = 1; i < NWAVE; i++) {
+        mn = tmp[i] < mn ? tmp[i] : mn;
+        mx = tmp[NWAVE + i] > mx ? tmp[NWAVE + i] : mx;
+    }
+    __syncthreads();
+}
+
+// Key of rank k (0-based) among key(0..n-1).  kmin/kmax: block-uniform extremes of the keys.
+template <typename KeyFn>
+__device__ unsigned long long radix_select(int n, int k, Scratch *sc, unsigned *hist256, KeyFn key,
+                                           unsigned long long kmin, unsigned long long kmax)
+{
+    if (kmin == kmax) return kmin;
+    const int tid = threadIdx.x;
+    const int top = 63 - __clzll((long long)(kmin ^ kmax));
+    int shift = (top / 8) * 8;
+    unsigned long long pmask = (shift + 8 >= 64) ? 0ull : ~((1ull << (shift + 8)) - 1ull);
+    unsigned long long prefix = kmin & pmask;
+    for (; shift >= 0; shift -= 8) {
+        hist256[tid] = 0u;
+        __syncthreads();
+        for (int i = tid; i < n; i += TPB) {
+            const unsigned long long kk = key(i);
+            if ((kk & pmask) == prefix) atomicAdd(&hist256[(unsigned)(kk >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        const int c = (int)hist256[tid];
+        int total;
+        const int excl = block_excl_scan(c, sc->wsum[0], &total);
+        if (c > 0 && k >= excl && k < excl + c) { sc->sel[0] = tid; sc->sel[1] = k - excl; }
+        __syncthreads();
+        prefix |= (unsigned long long)(unsigned)sc->sel[0] << shift;
+        pmask |= 0xffull << shift;
+        k = sc->sel[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// Median of n values val(i) given as keys; returns (a+b)/2 for even n like np.median.
+template <typename KeyFn>
+__device__ double median_select(int n, Scratch *sc, unsigned *hist256, KeyFn key,
+                                unsigned long long kmin, unsigned long long kmax)
+{
+    const int k1 = (n - 1) / 2, k2 = n / 2;
+    const double a = key_f64(radix_select(n, k1, sc, hist256, key, kmin, kmax));
+    if (k2 == k1) return a;
+    const double b = key_f64(radix_select(n, k2, sc, hist256, key, kmin, kmax));
+    return (a + b) / 2.0;
+}
+
+__global__ __launch_bounds__(TPB)
+void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off, int nreads,
+                double lo, double hi, int mode, double std_scale,
+                double *__restrict__ comp, sk_prep *__restrict__ prep,
+                uint64_t *__restrict__ maskT, int64_t mask_rows)
+{
+    __shared__ Scratch sc_;
+    __shared__ unsigned hist256[256];
+    __shared__ unsigned long long mm[2 * NWAVE];
+    Scratch *sc = &sc_;
+
+    const int r = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t o0 = off[r];
+    const int M = (int)(off[r + 1] - o0);
+    const double *row = sig + o0;
+    double *crow = comp + o0;
+    if (tid < 4) sc->sel[tid] = 0;
+
+    // ---- pass A: filter + order-preserving compaction + key extremes --------------------
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    int run = 0, parity = 0;
+    for (int base = 0; base < M; base += TPB * 4, parity ^= 1) {
+        const int i0 = base + tid * 4;
+        double v[4];
+        unsigned keep = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[k] = (i0 + k < M) ? row[i0 + k] : 0.0;
+            if (i0 + k < M && v[k] > lo && v[k] < hi) keep |= 1u << k;
+        }
+        const int cnt = __popc(keep);
+        const int inc = wave_incl_scan(cnt, lane);
+        if (lane == 63) sc->wsum[parity][w] = inc;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < NWAVE; i++) {
+            const int s = sc->wsum[parity][i];
+            if (i < w) wbase += s;
+            tot += s;
+        }
+        int o = run + wbase + inc - cnt;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (keep & (1u << k)) {
+                crow[o++] = v[k];
+                const unsigned long long kk = f64_key(v[k]);
+                kmin = kk < kmin ? kk : kmin;
+                kmax = kk > kmax ? kk : kmax;
+            }
+        }
+        run += tot;
+    }
+    const int n = run;
+    __syncthreads();
+
+    sk_prep pr;
+    pr.n = n; pr.flags = 0; pr.center = 0.0; pr.scale = 1.0; pr.top = 0.0; pr.bot = 0.0;
+    if (n == 0) {
+        pr.flags = SK_FLAG_EMPTY;
+        const double qnan = __builtin_nan("");
+        pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
+        if (tid == 0) prep[r] = pr;
+        return;
+    }
+    block_minmax_u64(kmin, kmax, mm);
+
+    double median = 0.0;
+    if (mode != SK_PREP_ZSCALE)
+        median = median_select(n, sc, hist256, [&](int i) { return f64_key(crow[i]); }, kmin, kmax);
+
+    if (mode == SK_PREP_MEDMAD) {
+        // MAD = median(|x - med|)   MotifSeq.py:195
+        unsigned long long dmin = ~0ull, dmax = 0ull;
+        for (int i = tid; i < n; i += TPB) {
+            const unsigned long long kk = f64_key(fabs(crow[i] - median));
+            dmin = kk < dmin ? kk : dmin;
+            dmax = kk > dmax ? kk : dmax;
+        }
+        block_minmax_u64(dmin, dmax, mm);
+        const double mad = median_select(n, sc, hist256,
+                                         [&](int i) { return f64_key(fabs(crow[i] - median)); }, dmin, dmax);
+        pr.center = median;
+        pr.scale = mad * 1.4826;
+        if (mad == 0.0) pr.flags |= SK_FLAG_DEGENERATE;
+        if (tid == 0) prep[r] = pr;
+        return;
+    }
+
+    // ---- numpy-order mean and std ---------------------------------------------------------
+    const double mean = numpy_sum(n, sc, [&](int i) { return crow[i]; }) / (double)n;
+    const double ssq = numpy_sum(n, sc, [&](int i) {
+        const double d = crow[i] - mean;
+        return d * d;
+    });
+    const double sd = sqrt(ssq / (double)n);
+    if (mode == SK_PREP_ZSCALE) {
+        pr.center = mean;
+        pr.scale = (sd == 0.0) ? 1.0 : sd;
+        if (tid == 0) prep[r] = pr;
+        return;
+    }
+    const double spread = sd * std_scale;
+    const double top = median + spread;
+    const double bot = median - spread;
+    pr.center = median; pr.scale = sd; pr.top = top; pr.bot = bot;
+    if (tid == 0) prep[r] = pr;
+    for (int base = 0; base < n; base += TPB) {
+        const int i = base + tid;
+        bool in = false;
+        if (i < n) {
+            const double a = crow[i];
+            in = (a < top) && (a > bot);
+        }
+        const unsigned long long bits = __ballot(in);
+        if (lane == 0) maskT[(int64_t)(i >> 6) * mask_rows + r] = bits;
+    }
+}
+
 } // namespace
 
 int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len,
@@ -350,8 +553,13 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
     return SK_OK;
 }
 
-int sk_launch_prep_f64(sk_ctx *, const double *, const int64_t *, int32_t, double, double, int, double,
-                       double *, sk_prep *, uint64_t *, const int64_t *)
+int sk_launch_prep_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads,
+                       double lo, double hi, int mode, double std_scale,
+                       double *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_rows)
 {
-    return sk_fail(SK_ERR_UNSUPPORTED, "float64 sample path not built yet");
+    if (nreads <= 0) return SK_OK;
+    hipLaunchKernelGGL(k_prep_f64, dim3(nreads), dim3(TPB), 0, c->stream, d_sig, d_off, nreads, lo, hi, mode,
+                       std_scale, d_comp, d_prep, d_mask, mask_rows);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
 }

@@ -1,0 +1,209 @@
+"""Drop-in for /root/reference/MotifSeq.py's command line (MotifSeq.py:80-311, 431-449).
+
+Same flags, the same stderr banner, the same 12/13-column TSV on stdout.  Per read,
+scale_outliers + medmad/zscale + dtw_subsequence run on the GPU (batched, C ABI);
+the scoring of MotifSeq.py:441-445 stays in Python so the printed floats are the
+reference's digit for digit.  Additive flags: --device, --batch, --strict-compat.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+from . import api, tsvio
+
+VERSION = "1.3.0"          # the reference's MotifSeq version string (MotifSeq.py:84)
+HEADER = ["fast5", "readID", "model", "start", "end", "length", "distance_score", "model_mean",
+          "model_stdev", "Z-score", "p-value", "hit_Probability"]
+BANNER = ("\n\n**********************************************************\n"
+          "*  z-score, p-value, probability, etc. are based on      *\n"
+          "*     preliminary experimental modeling only             *\n"
+          "*                Use at own risk                         *\n"
+          "**********************************************************\n\n\n")
+
+
+class _Parser(argparse.ArgumentParser):
+    def error(self, message):                      # MotifSeq.py:73-77
+        sys.stderr.write("error: %s\n" % message)
+        self.print_help()
+        sys.exit(2)
+
+
+def build_parser():
+    p = _Parser(description="MotifSeq (MI355X) - find a sequence motif's signal inside raw nanopore reads")
+    src = p.add_mutually_exclusive_group()
+    mod = p.add_mutually_exclusive_group()
+    src.add_argument("-f", "--f5f", help="text file listing fast5 paths (needs h5py)")
+    src.add_argument("-p", "--f5_path", help="directory searched recursively for fast5 files (needs h5py)")
+    src.add_argument("-s", "--signal", help="signal TSV written by SquigglePull (.gz accepted)")
+    p.add_argument("-l", "--scale", default="medmad", choices=["zscale", "medmad"],
+                   help="per-read normalisation applied before the search")
+    mod.add_argument("-i", "--fasta_input", help="fasta of motifs, turned into squiggles with scrappy")
+    p.add_argument("--scrappie_model", default="squiggle_r94",
+                   choices=["squiggle_r94", "squiggle_r94_rna", "squiggle_r10"],
+                   help="scrappie squiggle model used for -i")
+    mod.add_argument("-m", "--model", help="pre-computed motif signal: scrappie squiggle text or name/len/x/values TSV")
+    p.add_argument("-x", "--sig_extract", action="store_true", help="append the matched normalised signal")
+    p.add_argument("--slope", type=float, default=2.90, help="[experimental] distance model slope")
+    p.add_argument("--intercept", type=float, default=-9.6, help="[experimental] distance model intercept")
+    p.add_argument("--std_const", type=float, default=0.08468, help="[experimental] distance model stdev factor")
+    p.add_argument("-v", "--view", action="store_true", help="plot each hit (not available in this build)")
+    p.add_argument("--save", help="directory for hit images (not available in this build)")
+    p.add_argument("--img", default="png", help="image type for --save")
+    p.add_argument("-scale_hi", "--scale_hi", type=int, default=1200, help="samples >= this are dropped")
+    p.add_argument("-scale_low", "--scale_low", type=int, default=0, help="samples <= this are dropped")
+    p.add_argument("-V", "--version", action="store_true", help="print the version and exit")
+    p.add_argument("--verbose", action="store_true", help="dump the parsed arguments to stderr")
+    p.add_argument("--device", type=int, default=None, help="[extension] GPU index (default $SK_DEVICE or 0)")
+    p.add_argument("--batch", type=int, default=2048, help="[extension] reads per GPU call")
+    p.add_argument("--strict-compat", action="store_true",
+                   help="[extension] keep the reference's -m defect (empty model order: header only)")
+    return p
+
+
+def norm_cdf(z):
+    """scipy.stats.norm.cdf == scipy.special.ndtr (MotifSeq.py:444)."""
+    try:
+        from scipy.special import ndtr
+        return ndtr(z)
+    except ImportError:                              # pragma: no cover
+        import math
+        return np.float64(0.5 * math.erfc(-z / math.sqrt(2.0)))
+
+
+def load_models(args):
+    if args.model:
+        models, order, lens = tsvio.read_model_auto(args.model)
+        if args.strict_compat:
+            order, lens = [], []                     # MotifSeq.py:413-428 never fills them
+        return models, order, lens
+    if args.fasta_input:
+        try:
+            return tsvio.fasta_to_models(args.fasta_input, args.scrappie_model)
+        except ImportError:
+            side = os.path.splitext(args.fasta_input)[0] + ".model"
+            if os.path.exists(side):
+                sys.stderr.write("MotifSeq: scrappy is not installed; using the pre-computed scrappie "
+                                 "squiggle {}\n".format(side))
+                return tsvio.read_scrappie_model(side)
+            sys.stderr.write("MotifSeq: -i needs the scrappy package (not installed) or a scrappie squiggle "
+                             "file next to the fasta; use -m <file.model>\n")
+            sys.exit(1)
+    return {}, [], []
+
+
+class _Batcher:
+    def __init__(self, args, models, order, lens):
+        self.args, self.models, self.order, self.lens = args, models, order, lens
+        self.meta, self.sigs = [], []
+
+    def add(self, fast5, read_id, sig):
+        self.meta.append((fast5, read_id))
+        self.sigs.append(sig)
+        if len(self.sigs) >= self.args.batch:
+            self.flush()
+
+    def note(self, message):
+        """A stderr message that must keep its place between the reads around it."""
+        self.meta.append((None, message))
+        self.sigs.append(None)
+
+    def flush(self):
+        if not self.sigs:
+            return
+        a = self.args
+        live = [i for i, s in enumerate(self.sigs) if s is not None]
+        sigs = [self.sigs[i] for i in live]
+        hits = [api.motifseq_any(sigs, np.asarray(self.models[name], dtype=np.float64), a.scale,
+                                 a.scale_low, a.scale_hi) if sigs else [] for name in self.order]
+        slot = {i: k for k, i in enumerate(live)}
+        for i, (fast5, read_id) in enumerate(self.meta):
+            if self.sigs[i] is None:
+                sys.stderr.write(read_id)
+                continue
+            r = slot[i]
+            norm = None
+            for c, name in enumerate(self.order):                       # MotifSeq.py:436-449
+                h = hits[c][r]
+                if h["flags"] & 1:
+                    sys.stderr.write("MotifSeq: no sample of {} survived the outlier limits; skipped\n".format(read_id))
+                    break
+                dist, start, end = float(h["dist"]), int(h["start"]), int(h["end"])
+                mod_mean = (a.slope * self.lens[c]) + a.intercept
+                mod_stdev = mod_mean * a.std_const
+                z = (dist - mod_mean) / mod_stdev
+                p_value = norm_cdf(z)
+                hit_p = (1 - p_value) * 100
+                row = [fast5, read_id, name, start, end, end - start, dist, mod_mean, mod_stdev, z, p_value, hit_p]
+                if a.sig_extract:
+                    if norm is None:
+                        norm = api.normalise(self.sigs[i], a.scale, a.scale_low, a.scale_hi)
+                    row.append("\t".join(str(v) for v in norm[start:end]))
+                print("\t".join("{}".format(v) for v in row))
+        self.meta, self.sigs = [], []
+
+
+def main(argv=None):
+    parser = build_parser()
+    argv = sys.argv[1:] if argv is None else argv
+    args = parser.parse_args(argv)
+    if len(argv) == 0:                               # MotifSeq.py:129-131
+        parser.print_help(sys.stderr)
+        sys.exit(1)
+    if args.version:                                 # MotifSeq.py:134-136
+        sys.stderr.write("SquiggleKit MotifSeq: {}\n".format(VERSION))
+        sys.exit(1)
+    if args.verbose:
+        sys.stderr.write("Verbose mode active - dumping info to stderr\n")
+        sys.stderr.write("SquiggleKit MotifSeq: {}\n".format(VERSION))
+        sys.stderr.write("args: {}\n".format(args))
+    sys.stderr.write(BANNER)                         # MotifSeq.py:147-151
+    if args.view or args.save:
+        sys.stderr.write("MotifSeq: -v/--save plotting is not part of this build; ignoring\n")
+
+    models, order, lens = load_models(args)
+    print("\t".join(HEADER + (["normalised_signal"] if args.sig_extract else [])))    # MotifSeq.py:160-163
+
+    if not (args.f5f or args.f5_path or args.signal):
+        sys.stderr.write("Unknown file or path input")
+        parser.print_help(sys.stderr)
+        sys.exit(1)
+    if (args.f5f or args.f5_path) and not tsvio.have_h5py():
+        sys.stderr.write("MotifSeq: fast5 input needs h5py, which is not installed; use -s <SquigglePull TSV>\n")
+        sys.exit(1)
+    if not order:                                    # nothing to search for: header only
+        return
+
+    from . import _lib
+    _lib.init(args.device)
+    out = _Batcher(args, models, order, lens)
+    if args.signal:
+        with tsvio.open_text(args.signal) as fh:
+            for line in fh:
+                fast5, read_id, sig = tsvio.parse_motifseq_line(line)
+                if not sig.any():                    # MotifSeq.py:271-273
+                    out.note("No Signal found - please check signal format\n")
+                    continue
+                out.add(fast5, read_id, sig)
+    else:
+        if args.f5f:                                 # MotifSeq.py:165-184: first column = path
+            with tsvio.open_text(args.f5f) as fh:
+                files = [ln.strip("\n").split("\t")[0] for ln in fh]
+        else:
+            files = [os.path.join(d, f) for d, _, fs in os.walk(args.f5_path) for f in fs if f.endswith(".fast5")]
+        for path in files:
+            fast5 = path.split("/")[-1]
+            try:
+                sig, read_id = tsvio.read_single_fast5(path, raw_signal=True)     # MotifSeq.py:326-345: raw ints
+            except Exception:
+                sig, read_id = [], ""
+            if not len(sig):
+                out.note("Failed to extract signal: {} {}\n".format(path, fast5))
+                continue
+            out.add(fast5, read_id, np.array(sig, dtype=int))
+    out.flush()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,161 @@
+"""Drop-in for /root/reference/segmenter.py's command line (segmenter.py:49-297).
+
+Same flags, same stdout (`name<TAB>s0,e0,s1,e1,...`), same stderr strings, same exit
+codes; the per-read work (scale_outliers + get_segs) runs on the GPU in batches
+through the C ABI.  Reads are buffered `--batch` at a time and printed in input
+order.  Additive flags: --device, --batch, --blow5.  There is no CPU path.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+from . import api, tsvio
+from ._lib import SegParams
+
+
+class _Parser(argparse.ArgumentParser):
+    def error(self, message):                      # segmenter.py:40-44
+        sys.stderr.write("error: %s\n" % message)
+        self.print_help()
+        sys.exit(2)
+
+
+def build_parser():
+    p = _Parser(description="segmenter (MI355X) - find stall / homopolymer stretches in squiggle data")
+    src = p.add_mutually_exclusive_group()
+    src.add_argument("-i", "--ind", nargs="+", help="one or more fast5 files (needs h5py)")
+    src.add_argument("-p", "--f5_path", help="directory searched recursively for fast5 files (needs h5py)")
+    src.add_argument("-s", "--signal", help="signal TSV written by SquigglePull (.gz accepted)")
+    src.add_argument("--blow5", help="[extension] BLOW5 file (uncompressed or zlib records)")
+    p.add_argument("--single", action="store_true", help="fast5 files hold one read each")
+    p.add_argument("-n", "--Num", type=int, default=0, help="use only the first Num samples; 0 = whole read")
+    p.add_argument("-e", "--error", type=int, default=5, help="out-of-band samples tolerated inside a segment")
+    p.add_argument("-c", "--corrector", type=int, default=50,
+                   help="window that lets the error budget recover on long segments")
+    p.add_argument("-w", "--window", type=int, default=150, help="shortest segment reported")
+    p.add_argument("-d", "--seg_dist", type=int, default=50, help="segments closer than this are merged")
+    p.add_argument("-t", "--std_scale", type=float, default=0.75,
+                   help="band half-width in standard deviations around the median")
+    p.add_argument("-v", "--view", action="store_true", help="plot each result (not available in this build)")
+    p.add_argument("-g", "--gap", action="store_true", help="with -u: enforce stall-to-polyT gap distance")
+    p.add_argument("-b", "--gap_dist", type=int, default=3000, help="largest stall-to-polyT gap accepted")
+    p.add_argument("-k", "--stall", action="store_true", help="with -u: require a stall near the read start")
+    p.add_argument("-u", "--test", action="store_true", help="filter reads with the -k / -g checks")
+    p.add_argument("-l", "--stall_len", type=float, default=0.25,
+                   help="fraction of --window the first (stall) segment may be")
+    p.add_argument("-j", "--stall_start", type=int, default=300, help="latest start accepted for the stall")
+    p.add_argument("-lim_hi", "--lim_hi", type=int, default=900, help="samples >= this are dropped")
+    p.add_argument("-lim_low", "--lim_low", type=int, default=0, help="samples <= this are dropped")
+    p.add_argument("--raw_signal", action="store_true", help="fast5 input: keep raw ADC values (no pA conversion)")
+    p.add_argument("--device", type=int, default=None, help="[extension] GPU index (default $SK_DEVICE or 0)")
+    p.add_argument("--batch", type=int, default=4096, help="[extension] reads per GPU call")
+    return p
+
+
+class _Batcher:
+    """Buffers (name, signal) pairs, runs them through the GPU, emits in order."""
+
+    def __init__(self, args):
+        self.args = args
+        self.params = SegParams.from_args(args)
+        self.names, self.sigs = [], []
+
+    def add(self, name, sig, miss_name=None):
+        self.names.append((name, miss_name if miss_name is not None else name))
+        self.sigs.append(sig)
+        if len(self.sigs) >= self.args.batch:
+            self.flush()
+
+    def note(self, message):
+        """A stderr message that must keep its place between the reads around it."""
+        self.names.append((None, message))
+        self.sigs.append(None)
+
+    def flush(self):
+        if not self.sigs:
+            return
+        live = [s for s in self.sigs if s is not None]
+        results = iter(api.segment_any(live, self.params) if live else [])
+        for (name, miss), sig in zip(self.names, self.sigs):
+            if sig is None:
+                sys.stderr.write(miss)
+                continue
+            segs = next(results)
+            if not segs:
+                sys.stderr.write("no segments found: {}".format(miss))        # segmenter.py:213
+                continue
+            if self.args.test:
+                segs = api.test_segs(segs, self.args)
+                if not segs:
+                    if self.args.signal:
+                        sys.stderr.write("no segs for testing: {}".format(miss))   # :219 (TSV branch only)
+                    continue
+            print("\t".join([name, ",".join(str(v) for pair in segs for v in pair)]))
+        self.names, self.sigs = [], []
+
+
+def main(argv=None):
+    parser = build_parser()
+    argv = sys.argv[1:] if argv is None else argv
+    args = parser.parse_args(argv)
+    if len(argv) == 0:                              # segmenter.py:100-102
+        parser.print_help(sys.stderr)
+        sys.exit(1)
+    if not args.Num:                                # segmenter.py:104-105 (drops the last sample)
+        args.Num = -1
+    if args.view:
+        sys.stderr.write("segmenter: -v/--view plotting is not part of this build; ignoring\n")
+
+    fast5_mode = bool(args.f5_path or args.ind)
+    if fast5_mode and not tsvio.have_h5py():
+        sys.stderr.write("segmenter: fast5 input needs h5py, which is not installed; "
+                         "use -s <SquigglePull TSV> or --blow5\n")
+        sys.exit(1)
+    if not (args.f5_path or args.ind or args.signal or args.blow5):
+        sys.stderr.write("Unknown file or path input")
+        parser.print_help(sys.stderr)
+        sys.exit(1)
+
+    from . import _lib
+    _lib.init(args.device)
+    out = _Batcher(args)
+
+    if args.signal:
+        with tsvio.open_text(args.signal) as fh:
+            for line in fh:
+                name, sig = tsvio.parse_segmenter_line(line)
+                if not sig.any():                   # segmenter.py:203-205
+                    out.note("No signal found in file: {} {}".format(args.signal, name))
+                    continue
+                out.add(name, sig[:args.Num])
+    elif args.blow5:
+        from .blow5 import read_blow5, to_pA
+        for rec in read_blow5(args.blow5):
+            sig = rec["signal"].astype(int)
+            if not args.raw_signal:
+                sig = to_pA(sig, rec["digitisation"], rec["offset"], rec["range"])
+            out.add(rec["read_id"], sig[:args.Num])
+    else:
+        if args.f5_path:
+            files = [os.path.join(d, f) for d, _, fs in os.walk(args.f5_path) for f in fs if f.endswith(".fast5")]
+        else:
+            files = list(args.ind)
+        for path in files:
+            label = os.path.basename(path) if args.f5_path else path
+            if args.single:
+                sig, _ = tsvio.read_single_fast5(path, args.raw_signal)
+                if not np.asarray(sig).any():
+                    out.note("main():data not extracted. Moving to next file: {}".format(label))
+                    continue
+                out.add(label, np.array(sig[:args.Num], dtype=float))
+            else:
+                for read, sig in tsvio.read_multi_fast5(path, args.raw_signal).items():
+                    out.add(read, np.array(sig[:args.Num], dtype=float), miss_name=label)
+    out.flush()
+    sys.stderr.write("Done")                        # segmenter.py:297
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+"""Input side of the two command-line tools: SquigglePull TSV lines, model files,
+and (when h5py is importable) fast5 files.
+
+TSV wire format (SquigglePull.py:243-253): one read per line,
+    fast5 <tab> readID [<tab> digitisation <tab> offset <tab> range <tab> sampling_rate] <tab> s0 <tab> s1 ...
+The consumers disagree about where the samples start -- segmenter reads from
+column 4 (segmenter.py:198-201), MotifSeq from column 8 (MotifSeq.py:270) -- and
+this module keeps each tool's convention (the `start_col` argument).
+"""
+import gzip
+import math
+
+import numpy as np
+
+
+def open_text(path):
+    """Plain or gzip text (the reference's dicSwitch, segmenter.py:300-308; its
+    segmenter is broken on .gz under Python 3 -- here .gz simply works)."""
+    if path.endswith(".gz"):
+        return gzip.open(path, "rt")
+    return open(path, "rt")
+
+
+def parse_segmenter_line(line):
+    """segmenter.py:192-201: name = col 0; data = cols 4..; float if col 4 has a '.', else int."""
+    cols = line.strip("\n").split("\t")
+    name = cols[0]
+    if "." in cols[4]:
+        sig = np.array([float(v) for v in cols[4:]], dtype=float)
+    else:
+        sig = np.array([int(v) for v in cols[4:]], dtype=int)
+    return name, sig
+
+
+def parse_motifseq_line(line):
+    """MotifSeq.py:265-270: fast5 = col 0, readID = col 1, data = float(cols 8..)."""
+    cols = line.strip("\n").split("\t")
+    return cols[0], cols[1], np.array([float(v) for v in cols[8:]])
+
+
+# ----------------------------------------------------------------------------
+# motif models
+# ----------------------------------------------------------------------------
+def read_scrappie_model(path):
+    """scrappie CLI squiggle text ("#name", "pos base current sd dwell" rows):
+    each k-mer's current repeated round(dwell) times -- the expansion of
+    MotifSeq.read_synth_model (MotifSeq.py:354-379).  Returns (models, order, L)."""
+    models, order, lens = {}, [], []
+    count, name = 0, None
+    with open_text(path) as fh:
+        for line in fh:
+            line = line.strip("\n")
+            if not line:
+                continue
+            if line[0] == "#":
+                if name is not None:
+                    lens.append(count)
+                count = 0
+                name = line[1:]
+                models[name] = []
+                order.append(name)
+            elif line[:3] == "pos":
+                continue
+            else:
+                f = line.split()
+                count += 1
+                models[name] = models[name] + [float(f[2])] * int(round(float(f[4])))
+    if name is not None:
+        lens.append(count)
+    return models, order, lens
+
+
+def read_bait_model(path):
+    """Custom TSV model: name <tab> kmer_length <tab> (ignored) <tab> v0 <tab> v1 ...
+    (layout documented at MotifSeq.py:408-428; the reference forgets to fill
+    m_order / L_list there, which makes `-m` print only the header -- here the
+    order and lengths are filled so `-m` works)."""
+    models, order, lens = {}, [], []
+    with open_text(path) as fh:
+        for line in fh:
+            cols = line.strip("\n").split("\t")
+            if len(cols) < 4:
+                continue
+            models[cols[0]] = np.array([float(v) for v in cols[3:]], dtype=float)
+            order.append(cols[0])
+            lens.append(int(cols[1]))
+    return models, order, lens
+
+
+def read_model_auto(path):
+    """'#'-headed files are scrappie text, anything else the bait TSV."""
+    with open_text(path) as fh:
+        first = fh.readline()
+    if first.startswith("#"):
+        return read_scrappie_model(path)
+    return read_bait_model(path)
+
+
+def fasta_to_models(path, scrappie_model):
+    """MotifSeq.convert_fasta (MotifSeq.py:382-405): scrappy squiggle per record,
+    current repeated round(exp(-log_dwell)) times.  Needs the `scrappy` package."""
+    import scrappy            # absent here: the caller reports that and exits
+    models, order, lens = {}, [], []
+    name = None
+    with open(path, "r") as fh:
+        for line in fh:
+            line = line.strip("\n")
+            if not line:
+                continue
+            if line[0] == ">":
+                name = line[1:]
+                models[name] = []
+                order.append(name)
+                continue
+            lens.append(len(line))
+            squiggle = scrappy.sequence_to_squiggle(line, model=scrappie_model).data(as_numpy=True, sloika=False)
+            for row in squiggle:
+                models[name] = models[name] + [row[0]] * int(round(math.exp(-row[2])))
+    return models, order, lens
+
+
+# ----------------------------------------------------------------------------
+# fast5 (only when h5py exists; HDF5 is out of this build's scope otherwise)
+# ----------------------------------------------------------------------------
+def _h5py():
+    try:
+        import h5py
+        return h5py
+    except ImportError:
+        return None
+
+
+def have_h5py():
+    return _h5py() is not None
+
+
+def pA(raw, digitisation, range_, offset):
+    """convert_to_pA_numpy + round (segmenter.py:515-517,347-349)."""
+    return np.round((np.asarray(raw, dtype=int) + offset) * (range_ / digitisation), 2)
+
+
+def read_single_fast5(path, raw_signal):
+    """segmenter.process_fast5 (segmenter.py:321-356): (signal, read_id)."""
+    h5py = _h5py()
+    with h5py.File(path, "r") as hdf:
+        key = list(hdf["Raw/Reads"].keys())[0]
+        read = hdf["Raw/Reads/"][key]
+        sig = np.array(read["Signal"][()], dtype=int)
+        rid = read.attrs["read_id"]
+        rid = rid.decode() if isinstance(rid, bytes) else rid
+        if not raw_signal:
+            ch = hdf["UniqueGlobalKey/channel_id"].attrs
+            sig = pA(sig, ch["digitisation"], float("{0:.2f}".format(ch["range"])), ch["offset"])
+    return sig, rid
+
+
+def read_multi_fast5(path, raw_signal):
+    """segmenter.get_multi_fast5_signal (segmenter.py:358-396): {read_name: signal}."""
+    h5py = _h5py()
+    out = {}
+    with h5py.File(path, "r") as hdf:
+        for read in list(hdf.keys()):
+            sig = np.array(hdf[read]["Raw/Signal"][()], dtype=int)
+            if not raw_signal:
+                ch = hdf[read]["channel_id"].attrs
+                sig = pA(sig, ch["digitisation"], float("{0:.2f}".format(ch["range"])), ch["offset"])
+            out[read] = sig
+    return out

@@ -1,0 +1,66 @@
+"""CPU: the C-ABI library builds, loads, exports every symbol include/*.h declares, and
+refuses to compute without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(sk_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_header_symbols_all_exported():
+    from squigglekit_amd import _lib
+    _lib.build()
+    lib = ctypes.CDLL(_lib.SO_PATH)
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    missing = [n for n in sorted(decl) if not hasattr(lib, n)]
+    assert not missing, "declared in include/ but not exported: %s" % missing
+    # and the ctypes table binds exactly the declared set
+    assert set(_lib.ABI) == decl, (set(_lib.ABI) ^ decl)
+    L = _lib.load()
+    assert b"gfx950" in L.sk_version()
+
+
+def test_struct_layouts_match_header():
+    from squigglekit_amd import _lib
+    assert ctypes.sizeof(_lib.Hit) == 24 and _lib.HIT_DTYPE.itemsize == 24
+    assert ctypes.sizeof(_lib.SegParams) == 40
+    p = _lib.SegParams()
+    assert (p.error, p.corrector, p.window, p.seg_dist, p.std_scale, p.stall_len, p.lim_low, p.lim_hi) == \
+           (5, 50, 150, 50, 0.75, 0.25, 0, 900)          # segmenter.py:65-96 defaults
+
+
+def test_product_never_imports_oracle_or_torch():
+    """The product package must not route through the oracle or torch."""
+    pkg = os.path.join(ROOT, "squigglekit_amd")
+    for path in glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True):
+        src = open(path).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path
+        assert not re.search(r"^\s*(from|import)\s+torch\b", src, flags=re.M), path
+    for path in glob.glob(os.path.join(pkg, "csrc", "*")):
+        if path.endswith((".hip", ".h", ".cpp")):
+            assert "oracle" not in open(path).read(), path
+
+
+def test_fails_loudly_without_gpu():
+    from squigglekit_amd import _lib, api
+    L = _lib.load()
+    if L.sk_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(_lib.SquiggleKitError) as ei:
+        api.motifseq_batch(np.full((1, 64), 500, dtype=np.int16), None, np.zeros(10))
+    assert "no CPU fallback" in str(ei.value) or "no HIP device" in str(ei.value)
+    with pytest.raises(_lib.SquiggleKitError):
+        api.segment_batch(np.full((1, 64), 500, dtype=np.int16))

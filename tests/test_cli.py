@@ -1,0 +1,215 @@
+"""The two command-line harness rows: stdout, stderr and exit code of
+the drop-in tools vs what the reference printed (goldens from tools/gen_golden.py).
+
+CPU variant: the GPU entry points of squigglekit_amd.api are replaced by oracle-backed
+stand-ins so that the HARNESS (parsing, batching, ordering, formatting, messages) is pinned
+without a GPU.  GPU variant (marked gpu): the same comparisons through the real HIP path."""
+import contextlib
+import hashlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, load_golden
+
+
+# ------------------------------------------------------------------ inputs, rebuilt like gen_golden
+def tsv_line(name, read_id, values, extra=None):
+    cols = [name, read_id] + ([str(v) for v in extra] if extra is not None else [])
+    return "\t".join(cols + [str(v) for v in values]) + "\n"
+
+
+@pytest.fixture(scope="module")
+def tsv_files(tmp_path_factory, example_read):
+    from squigglekit_amd import synth
+    from squigglekit_amd.blow5 import to_pA
+    d = tmp_path_factory.mktemp("tsv")
+    rec = example_read
+    raw = rec["signal"]
+    pa = to_pA(raw, rec["digitisation"], rec["offset"], rec["range"])
+    extra = [rec["digitisation"], rec["offset"], float("{0:.2f}".format(rec["range"])), rec["sampling_rate"]]
+    texts = {"pA_noinfo": tsv_line("test.fast5", rec["read_id"], pa),
+             "raw_noinfo": tsv_line("test.fast5", rec["read_id"], raw),
+             "pA_info": tsv_line("test.fast5", rec["read_id"], pa, extra),
+             "raw_info": tsv_line("test.fast5", rec["read_id"], raw, extra)}
+    syn = synth.squiggle_batch(256, 4000, synth.SEED_C2)
+    assert hashlib.sha256(syn[:8].tobytes()).hexdigest() == load_golden("segmenter_cli.json.gz")["synthetic8_sha256"]
+    lines = []
+    for r in range(8):
+        vals = syn[r]
+        if r == 3:
+            vals = np.zeros(50, dtype=np.int16)
+        if r == 5:
+            vals = np.full(800, 500, dtype=np.int16)
+        lines.append("\t".join(["read%d.fast5" % r, "id%d" % r, "x", "y"] + [str(int(v)) for v in vals]) + "\n")
+    texts["synthetic8"] = "".join(lines)
+
+    def mline(name, rid, vals):
+        return "\t".join([name, rid] + ["c%d" % i for i in range(6)] + [str(v) for v in vals]) + "\n"
+    model = np.array(load_golden("motifseq_cli.json.gz")["model_expanded"]["values"])
+    msyn = synth.squiggle_batch(6, 4000, synth.SEED_C3, motif=model)
+    texts["m_real_raw"] = mline("test.fast5", rec["read_id"], raw)
+    texts["m_real_pA"] = mline("test.fast5", rec["read_id"], pa)
+    texts["m_synthetic6"] = "".join(mline("r%d.fast5" % r, "id%d" % r, [int(v) for v in msyn[r]]) for r in range(6))
+    paths = {}
+    for k, t in texts.items():
+        p = d / (k + ".tsv")
+        p.write_text(t)
+        paths[k] = str(p)
+    return paths
+
+
+@pytest.fixture
+def scrappy_stub(monkeypatch):
+    """Same stand-in tools/gen_golden.py gave the reference: float32 currents from the example model."""
+    rows = []
+    with open(os.path.join(GOLD, "CATCTATCCAGGGTTAAATT.model")) as fh:
+        for line in fh:
+            if line[0] == "#" or line.startswith("pos"):
+                continue
+            f = line.split()
+            rows.append((np.float32(f[2]), np.float32(f[3]), -np.log(float(f[4]))))
+    mod = types.ModuleType("scrappy")
+    mod.sequence_to_squiggle = lambda seq, model=None: types.SimpleNamespace(
+        data=lambda as_numpy=True, sloika=False: rows)
+    monkeypatch.setitem(sys.modules, "scrappy", mod)
+
+
+def run_cli(main, argv):
+    out, err = io.StringIO(), io.StringIO()
+    code = 0
+    with contextlib.redirect_stdout(out), contextlib.redirect_stderr(err):
+        try:
+            main(argv)
+        except SystemExit as e:
+            code = e.code if isinstance(e.code, int) else 1
+    return out.getvalue(), err.getvalue(), code
+
+
+@pytest.fixture
+def oracle_backend(monkeypatch, ora):
+    """CPU only: api's GPU calls answered by the oracle (tests may use the oracle as a checker/fake)."""
+    from squigglekit_amd import _lib, api
+
+    def seg_any(reads, params=None):
+        params = params or _lib.SegParams()
+        op = ora.SegParams(params.error, params.corrector, params.window, params.seg_dist,
+                           params.std_scale, params.stall_len)
+        return [ora.get_segs(ora.scale_outliers(np.asarray(r, float), params.lim_low, params.lim_hi), op)
+                for r in reads]
+
+    def norm(sig, scale="medmad", lo=0, hi=1200):
+        f = ora.scale_outliers(np.asarray(sig, float), lo, hi)
+        return ora.medmad(f)[0] if scale == "medmad" else ora.zscale(f)[0]
+
+    def mot_any(reads, motif, scale="medmad", lo=0, hi=1200):
+        out = np.zeros(len(reads), dtype=_lib.HIT_DTYPE)
+        for i, r in enumerate(reads):
+            y = norm(r, scale, lo, hi)
+            out[i]["n"] = y.size
+            if y.size:
+                out[i]["dist"], out[i]["start"], out[i]["end"] = ora.dtw_subsequence(motif, y)
+            else:
+                out[i]["flags"] = 1
+        return out
+
+    monkeypatch.setattr(api, "segment_any", seg_any)
+    monkeypatch.setattr(api, "motifseq_any", mot_any)
+    monkeypatch.setattr(api, "normalise", norm)
+    monkeypatch.setattr(_lib, "init", lambda device=None: 0)
+
+
+# ------------------------------------------------------------------ the comparisons
+def check_segmenter(tsv_files):
+    from squigglekit_amd.segmenter_cli import main
+    gold = load_golden("segmenter_cli.json.gz")
+    n = 0
+    for run in gold["runs"]:
+        if run["tsv"] is None:
+            so, se, code = run_cli(main, [])
+            assert (so, code) == (run["stdout"], run["exit"]) and se.startswith("usage:")
+            continue
+        so, se, code = run_cli(main, ["-s", tsv_files[run["tsv"]]] + run["flags"])
+        assert so == run["stdout"], (run["tsv"], run["flags"])
+        assert code == run["exit"]
+        assert _strip_path(se) == _strip_path(run["stderr"]), (run["tsv"], run["flags"], se, run["stderr"])
+        n += 1
+    assert n >= 20
+
+
+def _strip_path(s):
+    """The reference's 'No signal found in file: <path> <name>' embeds the temp path it was given,
+    and tracebacks name the file/line of whoever raised: both are normalised before comparing."""
+    import re
+    s = re.sub(r"No signal found in file: \S+ ", "No signal found in file: <tsv> ", s)
+    return re.sub(r'  File "[^"]+", line \d+, in ', "  File <f>, in ", s)
+
+
+def check_motifseq(tsv_files):
+    from squigglekit_amd.motifseq_cli import main
+    gold = load_golden("motifseq_cli.json.gz")
+    fa = os.path.join(GOLD, "CATCTATCCAGGGTTAAATT.fa")
+    n = 0
+    for run in gold["runs"]:
+        if run["tsv"] is None:
+            so, se, code = run_cli(main, run["flags"])
+            assert (so, se, code) == (run["stdout"], run["stderr"], run["exit"])
+            continue
+        so, se, code = run_cli(main, ["-s", tsv_files["m_" + run["tsv"]], "-i", fa] + run["flags"])
+        assert so == run["stdout"], (run["tsv"], run["flags"], so[-300:], run["stdout"][-300:])
+        assert (se, code) == (run["stderr"], run["exit"])
+        n += 1
+    assert n >= 9
+
+
+def test_segmenter_cli_harness_cpu(oracle_backend, tsv_files):
+    check_segmenter(tsv_files)
+
+
+def test_motifseq_cli_harness_cpu(oracle_backend, scrappy_stub, tsv_files):
+    check_motifseq(tsv_files)
+
+
+@pytest.mark.gpu
+def test_segmenter_cli_gpu(gpu, tsv_files):
+    check_segmenter(tsv_files)
+
+
+@pytest.mark.gpu
+def test_motifseq_cli_gpu(gpu, scrappy_stub, tsv_files):
+    check_motifseq(tsv_files)
+
+
+def test_motifseq_model_file_variants(oracle_backend, tsv_files, tmp_path):
+    """-m with the shipped scrappie text works (the reference crashes there); a bait TSV works;
+    --strict-compat reproduces the reference's header-only behaviour."""
+    from squigglekit_amd.motifseq_cli import main, HEADER
+    model = os.path.join(GOLD, "CATCTATCCAGGGTTAAATT.model")
+    so, se, code = run_cli(main, ["-s", tsv_files["m_synthetic6"], "-m", model])
+    rows = so.strip().split("\n")
+    assert rows[0].split("\t") == HEADER and len(rows) == 7 and code == 0
+    assert rows[1].split("\t")[2] == "3_prime_end" and rows[1].split("\t")[7] == "48.4"
+    vals = load_golden("motifseq_cli.json.gz")["model_expanded"]["values"]
+    bait = tmp_path / "bait.tsv"
+    bait.write_text("3_prime_end\t20\t.\t" + "\t".join(repr(v) for v in vals) + "\n")
+    so2, _, _ = run_cli(main, ["-s", tsv_files["m_synthetic6"], "-m", str(bait)])
+    assert so2 == so
+    so3, _, _ = run_cli(main, ["-s", tsv_files["m_synthetic6"], "-m", model, "--strict-compat"])
+    assert so3.strip().split("\n") == ["\t".join(HEADER)]
+
+
+def test_gz_and_error_paths(oracle_backend, tsv_files, tmp_path):
+    import gzip
+    from squigglekit_amd.segmenter_cli import main
+    gz = tmp_path / "x.tsv.gz"
+    with gzip.open(gz, "wt") as fh:
+        fh.write(open(tsv_files["synthetic8"]).read())
+    so, se, code = run_cli(main, ["-s", str(gz)])
+    so0, _, _ = run_cli(main, ["-s", tsv_files["synthetic8"]])
+    assert so == so0 and so.count("\n") >= 5
+    so, se, code = run_cli(main, ["--bogus"])
+    assert code == 2 and se.startswith("error: ")

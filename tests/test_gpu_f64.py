@@ -1,0 +1,90 @@
+"""GPU parity: the float64 sample path (pA TSVs, segmenter.py:198-199 / MotifSeq.py:270):
+radix-select median / MAD, numpy-order mean/std on doubles, same state machine and DTW."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _pa_reads(n, m, seed):
+    """pA-like signals: two decimals, ~N(96, 15), a stall plateau, a few spikes."""
+    from squigglekit_amd import synth
+    raw = synth.squiggle_batch(n, m, seed).astype(np.int64)
+    return [np.round((raw[r] + 16.0) * (1493.94 / 8192.0), 2) for r in range(n)]
+
+
+def test_segmenter_f64_real_read_golden(gpu, example_read):
+    from squigglekit_amd import api
+    from squigglekit_amd.blow5 import to_pA
+    rec = example_read
+    pa = to_pA(rec["signal"], rec["digitisation"], rec["offset"], rec["range"])
+    want = [g for g in load_golden("segmenter_get_segs.json.gz")["real_read"] if g["kind"] == "pA"][0]
+    assert api.segment_reads_f64([pa[:-1]])[0] == want["segs"]
+
+
+def test_segmenter_f64_vs_oracle(gpu, ora):
+    from squigglekit_amd import api
+    from squigglekit_amd._lib import SegParams
+    rng = np.random.default_rng(1)
+    reads = _pa_reads(48, 5000, 2024)
+    reads = [r[:int(rng.integers(1, 5001))] for r in reads]
+    reads[3] = np.zeros(100)                   # nothing survives
+    reads[4] = np.full(300, 95.5)              # std == 0
+    reads[5] = reads[5][:1]
+    reads.append(np.round(rng.normal(96, 15, 20001), 2))     # > 2 numpy chunks
+    for kw in (dict(lim_low=0, lim_hi=900), dict(lim_low=60, lim_hi=130, error=9, corrector=2, window=40)):
+        p = SegParams(**kw)
+        got = api.segment_reads_f64(reads, p)
+        op = ora.SegParams(p.error, p.corrector, p.window, p.seg_dist, p.std_scale, p.stall_len)
+        for r, sig in enumerate(reads):
+            f = ora.scale_outliers(sig, p.lim_low, p.lim_hi)
+            assert got[r] == ora.get_segs(f, op), (kw, r)
+
+
+@pytest.mark.parametrize("scale", ["medmad", "zscale"])
+def test_motifseq_f64_vs_oracle(gpu, ora, example_model, scale):
+    from squigglekit_amd import api
+    reads = _pa_reads(40, 3000, 7)
+    reads[0] = reads[0][:1]
+    reads[1] = reads[1][:2]
+    reads[2] = reads[2][:777]
+    got = api.motifseq_reads_f64(reads, example_model, scale=scale, scale_low=0, scale_hi=1200)
+    for r, sig in enumerate(reads):
+        f = ora.scale_outliers(sig, 0, 1200)
+        y = ora.medmad(f)[0] if scale == "medmad" else ora.zscale(f)[0]
+        if not np.all(np.isfinite(y)):
+            assert got["flags"][r] & 2
+            continue
+        d, s, e = ora.dtw_subsequence(example_model, y)
+        assert (got["dist"][r], got["start"][r], got["end"][r], got["n"][r]) == (d, s, e, f.size), (scale, r)
+
+
+def test_f64_and_i16_paths_agree(gpu, example_model):
+    """Integer-valued data must give identical results through either kernel family."""
+    from squigglekit_amd import api, synth
+    sig = synth.squiggle_batch(24, 2500, 99, motif=example_model)
+    a = api.motifseq_batch(sig, None, example_model)
+    b = api.motifseq_reads_f64([sig[r].astype(float) for r in range(24)], example_model)
+    assert np.array_equal(a, b)
+    sa = api.segment_reads([sig[r] for r in range(24)])
+    sb = api.segment_reads_f64([sig[r].astype(float) for r in range(24)])
+    assert sa == sb
+
+
+def test_normalise_f64_matches_reference_pA_row(gpu, ora, example_read):
+    """The real read in pA: normalised signal equals the numpy/sklearn result the reference fed to DTW."""
+    from squigglekit_amd import api
+    from squigglekit_amd.blow5 import to_pA
+    rec = example_read
+    pa = to_pA(rec["signal"], rec["digitisation"], rec["offset"], rec["range"])
+    gold = load_golden("motifseq_cli.json.gz")
+    import hashlib
+    for run in gold["runs"]:
+        if run["tsv"] != "real_pA" or run["flags"][:1] != ["-l"]:
+            continue
+        y = api.normalise(pa, scale=run["flags"][1])
+        g = run["dtw_inputs"][0]
+        assert y.size == g["n"]
+        assert hashlib.sha256(y.tobytes()).hexdigest() == g["sha256"], run["flags"]
