@@ -66,7 +66,8 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("SK_BENCH_FORCE_DIST") == "1"   # force: exercise the RCCL path on 1 GPU
+    if use_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -91,7 +92,7 @@ def main():
 
     max_segs = 16
     if a.workload == "motifseq":
-        if world > 1:
+        if use_dist:
             out_t = torch.empty(R * HIT_BYTES, dtype=torch.uint8, device="cuda")
             gath_t = torch.empty(world * R * HIT_BYTES, dtype=torch.uint8, device="cuda")
             d_out = C.c_void_p(out_t.data_ptr())
@@ -102,8 +103,9 @@ def main():
         def step():
             check(L.sk_motifseq_dev_i16(d_sig, stride, d_len, R, ptr(motif), N, mode, 0, 1200, d_out))
             check(L.sk_sync())
-            if world > 1:                      # the one exchange: gather of the hit records (RCCL)
+            if use_dist:                       # the one exchange: gather of the hit records (RCCL)
                 dist.all_gather_into_tensor(gath_t, out_t)
+                torch.cuda.current_stream().synchronize()   # out_t is rewritten by the next step
     else:
         d_segs = L.sk_dev_alloc(R * max_segs * 2 * 4)
         d_nsegs = L.sk_dev_alloc(R * 4)
@@ -115,7 +117,7 @@ def main():
 
     def fence():
         check(L.sk_sync())
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -133,7 +135,7 @@ def main():
         main_ms += m_.value
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -141,7 +143,7 @@ def main():
     main_ms /= max(1, a.steps)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -228,7 +230,7 @@ def main():
                        "seed": seed, "sharding": "reads block-sharded, %d rank(s), result all-gather over RCCL" % world},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity}
     print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
