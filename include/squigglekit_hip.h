@@ -146,6 +146,9 @@ int sk_normalise_f64(const double *sig, int32_t len, int32_t scale_mode,
 /* HIP-event durations (ms) of the kernels of the most recent *_dev / batch
  * call on this thread's device: prep (filter+stats), main (DTW or segment walk). */
 int sk_last_kernel_ms(float *prep_ms, float *main_ms);
+/* Reads of the most recent DTW call whose optimal path was longer than the two-pass
+ * look-back window and were therefore recomputed by the exact single pass (diagnostic). */
+int sk_last_dtw_retries(void);
 /* Synthetic squiggle generator on the device (bench input; not a reference
  * function): fills d_sig[nreads][nsamples] int16 deterministically from seed. */
 int sk_synth_squiggles_dev(int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,

@@ -79,7 +79,7 @@ int sk_motifseq_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_l
     sk_sdtw_args a;
     a.feed = SK_FEED_I16; a.samples = c->comp.p; a.stride = stride; a.off = nullptr;
     a.prep = (const sk_prep *)c->prep.p; a.nreads = nreads; a.motif = motif; a.nmotif = nmotif;
-    a.out = d_out; a.last_row = nullptr;
+    a.out = d_out; a.last_row = nullptr; a.max_len = stride; a.force_single = 0;
     rc = sk_launch_sdtw(c, &a);
     if (rc) return rc;
     c->ev_valid = true;
@@ -163,7 +163,7 @@ int sk_motifseq_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
     sk_sdtw_args a;
     a.feed = SK_FEED_F64_NORM; a.samples = c->comp.p; a.stride = 0; a.off = (const int64_t *)c->off.p;
     a.prep = (const sk_prep *)c->prep.p; a.nreads = nreads; a.motif = motif; a.nmotif = nmotif;
-    a.out = (sk_hit *)c->out.p; a.last_row = nullptr;
+    a.out = (sk_hit *)c->out.p; a.last_row = nullptr; a.max_len = maxlen; a.force_single = 0;
     if ((rc = sk_launch_sdtw(c, &a))) return rc;
     c->ev_valid = true;
     SK_HIP(hipMemcpyAsync(out, c->out.p, (size_t)nreads * sizeof(sk_hit), hipMemcpyDeviceToHost, c->stream));
@@ -182,9 +182,11 @@ int sk_dtw_subsequence_batch(const double *x, int32_t nx, const double *y, const
     if (!y || !off || !out) return sk_fail(SK_ERR_INVALID, "NULL y/off/out");
     const int64_t total = off[nreads] - off[0];
     if (total < 0) return sk_fail(SK_ERR_INVALID, "offsets not increasing");
+    int64_t maxlen = 0;
     for (int32_t r = 0; r < nreads; r++) {
         const int64_t n = off[r + 1] - off[r];
         if (n < 0 || n > 0x7fffff00) return sk_fail(SK_ERR_INVALID, "bad length for read %d", r);
+        if (n > maxlen) maxlen = n;
     }
     int rc;
     if ((rc = sk_reserve(c, &c->sig, (size_t)(total > 0 ? total : 1) * sizeof(double)))) return rc;
@@ -198,7 +200,7 @@ int sk_dtw_subsequence_batch(const double *x, int32_t nx, const double *y, const
     sk_sdtw_args a;
     a.feed = SK_FEED_F64_RAW; a.samples = c->sig.p; a.stride = 0; a.off = (const int64_t *)c->off.p;
     a.prep = nullptr; a.nreads = nreads; a.motif = x; a.nmotif = nx; a.out = (sk_hit *)c->out.p;
-    a.last_row = nullptr;
+    a.last_row = nullptr; a.max_len = maxlen; a.force_single = 0;
     SK_HIP(hipEventRecord(c->ev[0], c->stream));
     SK_HIP(hipEventRecord(c->ev[1], c->stream));
     if ((rc = sk_launch_sdtw(c, &a))) return rc;
@@ -227,6 +229,7 @@ int sk_dtw_subsequence(const double *x, int32_t nx, const double *y, int32_t ny,
     a.feed = SK_FEED_F64_RAW; a.samples = c->sig.p; a.stride = 0; a.off = (const int64_t *)c->off.p;
     a.prep = nullptr; a.nreads = 1; a.motif = x; a.nmotif = nx; a.out = (sk_hit *)c->out.p;
     a.last_row = cost_last_row ? (double *)c->misc.p : nullptr;
+    a.max_len = ny; a.force_single = 1;
     if ((rc = sk_launch_sdtw(c, &a))) return rc;
     sk_hit h;
     SK_HIP(hipMemcpyAsync(&h, c->out.p, sizeof h, hipMemcpyDeviceToHost, c->stream));

@@ -48,6 +48,9 @@ struct sk_ctx {
     sk_buf out;       // sk_hit / segs staging
     sk_buf out2;      // nsegs staging
     sk_buf misc;
+    sk_buf ckpt;      // DTW pass-A checkpoints (systolic state dumps)
+    sk_buf retry;     // DTW pass-B retry counter + read list
+    int    last_retry = 0;   // reads that needed the exact single-pass retry in the last DTW call
     std::vector<double> motif_host;   // last laid-out motif (kept alive for async H2D)
     std::vector<double> motif_src;    // the motif it was built from (upload cache key)
 };
@@ -91,6 +94,8 @@ struct sk_sdtw_args {
     int32_t       nmotif;
     sk_hit       *out;         // device, nreads records
     double       *last_row;    // device, optional: cost[-1,:] of read 0 (single-pair call)
+    int64_t       max_len;     // upper bound of any read's filtered length (chooses 1 vs 2 passes)
+    int           force_single;// 1: always the single FULL pass
 };
 int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a);
 

@@ -101,7 +101,7 @@ int sk_shutdown(void)
         (void)hipSetDevice(d);
         (void)hipStreamSynchronize(c->stream);
         sk_buf *bufs[] = {&c->sig, &c->len, &c->off, &c->comp, &c->prep, &c->mask,
-                          &c->motif, &c->out, &c->out2, &c->misc};
+                          &c->motif, &c->out, &c->out2, &c->misc, &c->ckpt, &c->retry};
         for (sk_buf *b : bufs) free_buf(b);
         for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev[i]);
         (void)hipStreamDestroy(c->stream);
@@ -183,6 +183,13 @@ int sk_last_kernel_ms(float *prep_ms, float *main_ms)
     if (prep_ms) *prep_ms = a;
     if (main_ms) *main_ms = b;
     return SK_OK;
+}
+
+int sk_last_dtw_retries(void)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    return c->last_retry;
 }
 
 } // extern "C"

@@ -21,10 +21,20 @@
 //     slot of the last lane: the first P = L*R - N lanes own R-1 rows ("short" lanes, their
 //     last slot is a dead pad cell) -- so neither end needs a run-time slot select.
 //   * boundaries come for free: D starts at +inf (column -1), lane 0's incoming "up" is the
-//     virtual row -1 (D = 0, S = j + 1), samples past the end are +inf so they never win
-//     the running argmin kept by the last lane.
+//     virtual row -1 (D = 0, S = j + 1), samples outside [0, n) are +inf so those columns stay
+//     at +inf and never win the running argmin kept by the last lane.
 //   * the normalisation (x - center) / scale of MotifSeq.py:192-200 / :186-191 is fused into
 //     the sample feed: every L steps each lane normalises one sample of the next block.
+//
+// Three modes of the one kernel template:
+//   FULL   one pass carrying D and S (12 of its 28 VALU cycles per cell are the S tracking).
+//   DIST   pass A of the two-pass scheme: D only (16 cycles per cell) -> dist and end; every
+//          CK steps each lane dumps its systolic state (R D's, y, bottom, diag) to HBM.
+//   START  pass B: for each read restart from the last checkpoint at least `span` columns
+//          before `end`, run with S tracking up to `end` only and read S there.  Cells of the
+//          restart front carry S = -1; if the optimal path crosses the front the read's start
+//          stays -1 and the read is appended to a retry list (FULL pass on those reads only).
+//          The restart reproduces the state bit for bit, so the result is exact either way.
 #include "sk_common.h"
 #include <math.h>
 #include <string.h>
@@ -36,6 +46,8 @@ constexpr int DPP_ROW_SHR1  = 0x111;   // lane i <- lane i-1 inside a row of 16;
 constexpr int DPP_ROW_ROL1  = 0x12F;   // row_ror:15 == rotate left by one inside a row of 16
 constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i <- lane i-1 across the wave; lane 0 keeps `old`
 constexpr int DPP_WAVE_ROL1 = 0x134;   // lane i <- lane i+1 across the wave (rotate)
+
+enum { MODE_FULL = 0, MODE_DIST = 1, MODE_START = 2 };
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int old, int src)
@@ -51,24 +63,53 @@ __device__ __forceinline__ double dpp_f64(double old, double src)
     return __hiloint2double(hi, lo);
 }
 
-template <int L, int R, int FEED>
+// min of two non-NaN doubles as ONE v_min_f64 (fmin() would add canonicalising ops in IEEE mode)
+__device__ __forceinline__ double vmin(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+struct sdtw_kargs {
+    const void    *samples;     // int16 or double samples (filtered)
+    int64_t        stride;      // row stride for FEED_I16
+    const int64_t *off;         // ragged offsets for the f64 feeds
+    const sk_prep *prep;        // n / center / scale per read (not for F64_RAW)
+    int            nreads;      // reads (or entries of ridx) covered by this launch
+    int            read0;       // first read of this launch (chunking); checkpoint slot = r - read0
+    const int32_t *ridx;        // optional indirection: launch slot -> read (retry pass)
+    const double  *xlay;        // motif laid out per lane [L][R]
+    int            P;           // number of short lanes
+    sk_hit        *out;
+    double        *last_row;    // FULL only: cost[-1, :] of read 0
+    double        *ckpt;        // [slot][nck][L][R+3]
+    int            nck;         // checkpoints per read
+    int            ck;          // steps between checkpoints (multiple of L)
+    int            span;        // START: look-back in columns
+    int32_t       *retry;       // START: reads whose path crossed the restart front
+    int32_t       *retry_cnt;
+};
+
+template <int L, int R, int FEED, int MODE>
 __global__ __launch_bounds__(256)
-void k_sdtw(const void *__restrict__ samples, int64_t stride, const int64_t *__restrict__ off,
-            const sk_prep *__restrict__ prep, int nreads, const double *__restrict__ xlay, int P,
-            sk_hit *__restrict__ out, double *__restrict__ last_row)
+void k_sdtw(const sdtw_kargs a)
 {
     static_assert(L == 16 || L == 64, "lanes per read");
     constexpr int G = 64 / L;
     constexpr int SHR = (L == 16) ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
     constexpr int ROL = (L == 16) ? DPP_ROW_ROL1 : DPP_WAVE_ROL1;
+    constexpr bool TRACK = (MODE != MODE_DIST);
+    constexpr int CKW = R + 3;                      // doubles per lane per checkpoint
     const double INF = __builtin_huge_val();
 
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int g = lane / L, l = lane % L;
-    int r = wave * G + g;
-    const bool live = r < nreads;
-    if (!live) r = nreads - 1;
+    int slot = wave * G + g;
+    const bool live = slot < a.nreads;
+    if (!live) slot = a.nreads - 1;
+    const int r = a.ridx ? a.ridx[slot] : a.read0 + slot;
 
     // ---- per-read parameters -------------------------------------------------
     int n, flags = 0;
@@ -76,44 +117,70 @@ void k_sdtw(const void *__restrict__ samples, int64_t stride, const int64_t *__r
     const int16_t *s16 = nullptr;
     const double  *s64 = nullptr;
     if constexpr (FEED == SK_FEED_I16) {
-        const sk_prep pr = prep[r];
+        const sk_prep pr = a.prep[r];
         n = pr.n; flags = pr.flags; center = pr.center; scale = pr.scale;
-        s16 = (const int16_t *)samples + (int64_t)r * stride;
+        s16 = (const int16_t *)a.samples + (int64_t)r * a.stride;
     } else if constexpr (FEED == SK_FEED_F64_NORM) {
-        const sk_prep pr = prep[r];
+        const sk_prep pr = a.prep[r];
         n = pr.n; flags = pr.flags; center = pr.center; scale = pr.scale;
-        s64 = (const double *)samples + off[r];
+        s64 = (const double *)a.samples + a.off[r];
     } else {
-        n = (int)(off[r + 1] - off[r]);
+        n = (int)(a.off[r + 1] - a.off[r]);
         if (n == 0) flags = SK_FLAG_EMPTY;
-        s64 = (const double *)samples + off[r];
+        s64 = (const double *)a.samples + a.off[r];
     }
     if (!live) n = 0;
 
-    int nmax = n;                                   // wave-uniform step count
+    // ---- step range of this group: [tbase, tlast] ---------------------------------
+    int tbase = 0, tlast = n - 1 + L - 1, end = -1, c0 = 0;
+    if (n <= 0) tlast = -1;
+    if constexpr (MODE == MODE_START) {
+        end = a.out[r].end;
+        if (n > 0 && end >= 0) {
+            c0 = max(0, end - a.span) / a.ck;       // last checkpoint at least `span` columns back
+            if (c0 > a.nck) c0 = a.nck;
+            tbase = c0 * a.ck;
+            tlast = end + L - 1;                    // lane L-1 reaches column `end`
+        } else {
+            tlast = -1;
+        }
+    }
+    int nsteps = tlast - tbase + 1;                 // wave-uniform step count
+    if (nsteps < 0) nsteps = 0;
 #pragma unroll
-    for (int d = L; d < 64; d <<= 1) nmax = max(nmax, __shfl_xor(nmax, d));
-    nmax = __builtin_amdgcn_readfirstlane(nmax);
-    const int nblk = (nmax + L - 1 + L - 1) / L;    // steps 0 .. nmax-1 + L-1
+    for (int d = L; d < 64; d <<= 1) nsteps = max(nsteps, __shfl_xor(nsteps, d));
+    nsteps = __builtin_amdgcn_readfirstlane(nsteps);
+    const int nblk = (nsteps + L - 1) / L;
 
     // ---- this lane's motif rows ------------------------------------------------
     double x[R];
 #pragma unroll
-    for (int k = 0; k < R; k++) x[k] = xlay[l * R + k];
-    const bool shortlane = l < P;
+    for (int k = 0; k < R; k++) x[k] = a.xlay[l * R + k];
+    const bool shortlane = l < a.P;
 
     double D[R];
     int    S[R];
 #pragma unroll
-    for (int k = 0; k < R; k++) { D[k] = INF; S[k] = 0; }
+    for (int k = 0; k < R; k++) { D[k] = INF; S[k] = -1; }
     // my bottom row at my current column.  A lane 0 that owns no rows (R == 1, N < L) forwards
     // the virtual row -1, whose value at column -1 is (D = 0, S = 0).
-    double botD = (R == 1 && l == 0 && shortlane) ? 0.0 : INF;  int botS = 0;
-    double diagD = (l == 0) ? 0.0 : INF;  int diagS = 0;   // lane l-1's bottom one column back
+    double botD = (R == 1 && l == 0 && shortlane) ? 0.0 : INF;
+    int    botS = (R == 1 && l == 0 && shortlane) ? 0 : -1;
+    double diagD = (l == 0) ? 0.0 : INF;            // lane l-1's bottom one column back
+    int    diagS = (l == 0) ? tbase : -1;           // virtual row -1 at column tbase-1: S = column + 1
     double y = INF;                                 // columns < 0: cost +inf keeps D at +inf
     double best = INF;  int bestS = -1, bestJ = -1;
 
-    auto fetch = [&](int idx) -> double {           // normalised sample idx of my read, +inf past the end
+    if constexpr (MODE == MODE_START) {
+        if (c0 > 0) {                               // restart from the saved systolic state
+            const double *cp = a.ckpt + (((int64_t)(r - a.read0) * a.nck + (c0 - 1)) * L + l) * CKW;
+#pragma unroll
+            for (int k = 0; k < R; k++) D[k] = cp[k];
+            y = cp[R]; botD = cp[R + 1]; diagD = cp[R + 2];
+        }
+    }
+
+    auto fetch = [&](int idx) -> double {           // normalised sample idx of my read, +inf outside
         if constexpr (FEED == SK_FEED_I16) {
             int16_t raw = (idx < n) ? s16[idx] : (int16_t)0;
             double v = ((double)raw - center) / scale;
@@ -127,71 +194,104 @@ void k_sdtw(const void *__restrict__ samples, int64_t stride, const int64_t *__r
         }
     };
 
-    double F = fetch(l);
+    double F = fetch(tbase + l);
     for (int blk = 0; blk < nblk; blk++) {
-        const double Fnext = fetch((blk + 1) * L + l);     // in flight during the L steps below
+        const double Fnext = fetch(tbase + (blk + 1) * L + l);   // in flight during the L steps below
+        if constexpr (MODE == MODE_DIST) {
+            // checkpoint c (>= 1) = state at the beginning of step c*ck (ck is a multiple of L)
+            const int t0 = blk * L;
+            if (t0 > 0 && (t0 % a.ck) == 0 && t0 / a.ck <= a.nck && live) {
+                double *cp = a.ckpt + (((int64_t)(r - a.read0) * a.nck + (t0 / a.ck - 1)) * L + l) * CKW;
+#pragma unroll
+                for (int k = 0; k < R; k++) cp[k] = D[k];
+                cp[R] = y; cp[R + 1] = botD; cp[R + 2] = diagD;
+            }
+        }
 #pragma unroll 2
         for (int q = 0; q < L; q++) {
-            const int t = blk * L + q;
+            const int t = tbase + blk * L + q;
             // ---- systolic shift: sample and lane l-1's bottom row arrive -------
             y = dpp_f64<SHR>(F, y);                         // lane 0 takes sample t from the feed
             F = dpp_f64<ROL>(F, F);
             const double upD = dpp_f64<SHR>(0.0, botD);     // lane 0: virtual row -1 (D = 0)
-            const int    upS = dpp_i32<SHR>(t + 1, botS);   //         whose S is column + 1
+            int upS = 0;
+            if constexpr (TRACK) upS = dpp_i32<SHR>(t + 1, botS);   //   whose S is column + 1
             // ---- R cells of column j = t - l ---------------------------------
             double dgD = diagD;  int dgS = diagS;           // (i-1, j-1)
             double uD = upD;     int uS = upS;              // (i-1, j)
 #pragma unroll
             for (int k = 0; k < R; k++) {
-                const double lfD = D[k];  const int lfS = S[k];     // (i, j-1)
+                const double lfD = D[k];                    // (i, j-1)
                 const double c = fabs(x[k] - y);
-                const bool lt1 = lfD < dgD;                 // diag wins ties over left
-                const double m1 = lt1 ? lfD : dgD;
-                const int    s1 = lt1 ? lfS : dgS;
-                const bool lt2 = uD < m1;                   // up only if strictly smaller
-                const double m = lt2 ? uD : m1;
-                const int    s = lt2 ? uS : s1;
-                const double nd = c + m;
-                dgD = lfD;  dgS = lfS;
-                D[k] = nd;  S[k] = s;
-                uD = nd;    uS = s;
+                double nd;
+                if constexpr (TRACK) {
+                    const int lfS = S[k];
+                    const bool lt1 = lfD < dgD;             // diag wins ties over left
+                    const double m1 = lt1 ? lfD : dgD;
+                    const int    s1 = lt1 ? lfS : dgS;
+                    const bool lt2 = uD < m1;               // up only if strictly smaller
+                    const double m = lt2 ? uD : m1;
+                    const int    s = lt2 ? uS : s1;
+                    nd = c + m;
+                    dgS = lfS;  S[k] = s;  uS = s;
+                } else {
+                    nd = c + vmin(vmin(dgD, lfD), uD);
+                }
+                dgD = lfD;
+                D[k] = nd;
+                uD = nd;
             }
             diagD = upD;  diagS = upS;
             if constexpr (R >= 2) {
                 botD = shortlane ? D[R - 2] : D[R - 1];
-                botS = shortlane ? S[R - 2] : S[R - 1];
+                if constexpr (TRACK) botS = shortlane ? S[R - 2] : S[R - 1];
             } else {
                 botD = shortlane ? upD : D[0];              // a lane with no rows just forwards
-                botS = shortlane ? upS : S[0];
+                if constexpr (TRACK) botS = shortlane ? upS : S[0];
             }
-            // ---- running first-argmin of the last row (meaningful in lane L-1) --
             const int j = t - l;
-            if (D[R - 1] < best) { best = D[R - 1]; bestS = S[R - 1]; bestJ = j; }
-            if (last_row != nullptr) {
-                if (l == L - 1 && r == 0 && j >= 0 && j < n) last_row[j] = D[R - 1];
+            if constexpr (MODE == MODE_START) {
+                if (j == end) bestS = S[R - 1];             // S of cell (N-1, end), lane L-1
+            } else {
+                // ---- running first-argmin of the last row (meaningful in lane L-1) --
+                if (D[R - 1] < best) {
+                    best = D[R - 1]; bestJ = j;
+                    if constexpr (TRACK) bestS = S[R - 1];
+                }
+                if constexpr (MODE == MODE_FULL) {
+                    if (a.last_row != nullptr) {
+                        if (l == L - 1 && slot == 0 && j >= 0 && j < n) a.last_row[j] = D[R - 1];
+                    }
+                }
             }
         }
         F = Fnext;
     }
 
     if (live && l == L - 1) {
-        sk_hit h;
-        if (n > 0) { h.dist = best; h.start = bestS; h.end = bestJ; }
-        else       { h.dist = __builtin_nan(""); h.start = -1; h.end = -1; }
-        h.n = n;
-        h.flags = flags;
-        out[r] = h;
+        if constexpr (MODE == MODE_START) {
+            if (n > 0 && end >= 0) {
+                if (bestS >= 0) a.out[r].start = bestS;
+                else a.retry[atomicAdd(a.retry_cnt, 1)] = r;
+            }
+        } else {
+            sk_hit h;
+            if (n > 0) { h.dist = best; h.start = bestS; h.end = bestJ; }
+            else       { h.dist = __builtin_nan(""); h.start = -1; h.end = -1; }
+            h.n = n;
+            h.flags = flags;
+            a.out[r] = h;
+        }
     }
 }
 
-typedef void (*sdtw_fn)(const void *, int64_t, const int64_t *, const sk_prep *, int, const double *, int,
-                        sk_hit *, double *);
+typedef void (*sdtw_fn)(const sdtw_kargs);
 
-template <int L, int FEED>
+template <int L, int FEED, int MODE>
 sdtw_fn pick_r(int R)
 {
     switch (R) {
-#define SK_CASE(RR) case RR: return k_sdtw<L, RR, FEED>;
+#define SK_CASE(RR) case RR: return k_sdtw<L, RR, FEED, MODE>;
         SK_CASE(1) SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5) SK_CASE(6) SK_CASE(7) SK_CASE(8)
         SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16)
 #undef SK_CASE
@@ -200,14 +300,41 @@ sdtw_fn pick_r(int R)
 }
 
 template <int FEED>
-sdtw_fn pick(int L, int R)
+sdtw_fn pick(int L, int R, int mode)
 {
-    return (L == 16) ? pick_r<16, FEED>(R) : pick_r<64, FEED>(R);
+    if (L == 16) {
+        if (mode == MODE_FULL) return pick_r<16, FEED, MODE_FULL>(R);
+        if (mode == MODE_DIST) return pick_r<16, FEED, MODE_DIST>(R);
+        return pick_r<16, FEED, MODE_START>(R);
+    }
+    if (mode == MODE_FULL) return pick_r<64, FEED, MODE_FULL>(R);
+    if (mode == MODE_DIST) return pick_r<64, FEED, MODE_DIST>(R);
+    return pick_r<64, FEED, MODE_START>(R);
+}
+
+sdtw_fn pick_any(int feed, int L, int R, int mode)
+{
+    switch (feed) {
+        case SK_FEED_I16:      return pick<SK_FEED_I16>(L, R, mode);
+        case SK_FEED_F64_NORM: return pick<SK_FEED_F64_NORM>(L, R, mode);
+        case SK_FEED_F64_RAW:  return pick<SK_FEED_F64_RAW>(L, R, mode);
+    }
+    return nullptr;
+}
+
+int launch(sk_ctx *c, sdtw_fn fn, const sdtw_kargs &k, int L)
+{
+    if (k.nreads <= 0) return SK_OK;
+    const int reads_per_block = 4 * (64 / L);
+    const int grid = (k.nreads + reads_per_block - 1) / reads_per_block;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, c->stream, k);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
 }
 
 } // namespace
 
-// Host side: lay the motif out per lane, pick (L, R), launch.
+// Host side: lay the motif out per lane, pick (L, R), choose one or two passes, launch.
 int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
 {
     const int N = a->nmotif;
@@ -240,20 +367,63 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
         c->motif_src.assign(a->motif, a->motif + N);
     }
 
-    sdtw_fn fn = nullptr;
-    switch (a->feed) {
-        case SK_FEED_I16:      fn = pick<SK_FEED_I16>(L, R); break;
-        case SK_FEED_F64_NORM: fn = pick<SK_FEED_F64_NORM>(L, R); break;
-        case SK_FEED_F64_RAW:  fn = pick<SK_FEED_F64_RAW>(L, R); break;
-    }
-    if (!fn) return sk_fail(SK_ERR_UNSUPPORTED, "no kernel for L=%d R=%d", L, R);
+    sdtw_kargs k;
+    memset(&k, 0, sizeof k);
+    k.samples = a->samples; k.stride = a->stride; k.off = a->off; k.prep = a->prep;
+    k.nreads = a->nreads; k.read0 = 0; k.ridx = nullptr; k.xlay = (const double *)c->motif.p; k.P = P;
+    k.out = a->out; k.last_row = a->last_row;
 
-    const int reads_per_block = 4 * (64 / L);
-    const int grid = (a->nreads + reads_per_block - 1) / reads_per_block;
+    // ---- one pass or two? ---------------------------------------------------------------
+    // Two passes pay when reads are much longer than the look-back window; the caller's
+    // max_len bounds every read's filtered length.
+    const int ck = 256;                                    // multiple of both L
+    const int span = N + N / 2 + 64;                       // look-back in columns (typical paths span ~N)
+    const int64_t maxlen = a->max_len;
+    const bool two_pass = !a->last_row && !a->force_single && maxlen >= 4 * (int64_t)(span + ck) &&
+                          a->nreads >= 256;
     SK_HIP(hipEventRecord(c->ev[2], c->stream));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, c->stream, a->samples, a->stride, a->off, a->prep,
-                       a->nreads, (const double *)c->motif.p, P, a->out, a->last_row);
-    SK_HIP(hipGetLastError());
+    if (!two_pass) {
+        c->last_retry = 0;
+        sdtw_fn fn = pick_any(a->feed, L, R, MODE_FULL);
+        if (!fn) return sk_fail(SK_ERR_UNSUPPORTED, "no kernel for L=%d R=%d", L, R);
+        int rc = launch(c, fn, k, L);
+        if (rc) return rc;
+        SK_HIP(hipEventRecord(c->ev[3], c->stream));
+        return SK_OK;
+    }
+
+    sdtw_fn fa = pick_any(a->feed, L, R, MODE_DIST);
+    sdtw_fn fb = pick_any(a->feed, L, R, MODE_START);
+    sdtw_fn ff = pick_any(a->feed, L, R, MODE_FULL);
+    if (!fa || !fb || !ff) return sk_fail(SK_ERR_UNSUPPORTED, "no kernel for L=%d R=%d", L, R);
+    const int nck = (int)((maxlen + L - 1) / ck);          // checkpoints at steps ck, 2ck, ... <= last step
+    const size_t per_read = (size_t)(nck > 0 ? nck : 1) * L * (R + 3) * sizeof(double);
+    size_t budget = (size_t)12 << 30;                      // checkpoint scratch per chunk
+    int64_t chunk = (int64_t)(budget / per_read);
+    if (chunk > a->nreads) chunk = a->nreads;
+    if (chunk < 1024) chunk = 1024 < a->nreads ? 1024 : a->nreads;
+    int rc;
+    if ((rc = sk_reserve(c, &c->ckpt, (size_t)chunk * per_read))) return rc;
+    if ((rc = sk_reserve(c, &c->retry, ((size_t)a->nreads + 1) * sizeof(int32_t)))) return rc;
+    int32_t *cnt = (int32_t *)c->retry.p;                  // [0] = counter, [1..] = read indices
+    SK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), c->stream));
+    k.ckpt = (double *)c->ckpt.p; k.nck = nck; k.ck = ck; k.span = span;
+    k.retry = cnt + 1; k.retry_cnt = cnt;
+    for (int64_t r0 = 0; r0 < a->nreads; r0 += chunk) {
+        k.read0 = (int)r0;
+        k.nreads = (int)((a->nreads - r0 < chunk) ? a->nreads - r0 : chunk);
+        if ((rc = launch(c, fa, k, L))) return rc;         // pass A: dist, end, checkpoints
+        if ((rc = launch(c, fb, k, L))) return rc;         // pass B: start from the nearest checkpoint
+    }
+    // reads whose path crossed the restart front: exact single pass on just those
+    int32_t nretry = 0;
+    SK_HIP(hipMemcpyAsync(&nretry, cnt, sizeof nretry, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    c->last_retry = nretry;
+    if (nretry > 0) {
+        k.read0 = 0; k.nreads = nretry; k.ridx = cnt + 1; k.ckpt = nullptr;
+        if ((rc = launch(c, ff, k, L))) return rc;
+    }
     SK_HIP(hipEventRecord(c->ev[3], c->stream));
     return SK_OK;
 }

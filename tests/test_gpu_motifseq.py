@@ -145,3 +145,42 @@ def test_unsupported_and_invalid_are_loud(gpu):
         api.motifseq_batch(sig, None, np.zeros(2000))          # motif too long for this build
     with pytest.raises(SquiggleKitError):
         api.motifseq_batch(sig, None, np.zeros(0))
+
+
+def test_two_pass_with_forced_retries(gpu, ora):
+    """Batches big enough for the two-pass scheme (distance pass + windowed start pass), with
+    reads whose optimal path is far longer than the look-back window (an exact, 4x time-stretched
+    copy of the motif: cost 0 over ~800 columns), so the exact single-pass retry is exercised
+    too.  Everything must stay bit-exact."""
+    from squigglekit_amd import api, synth
+    L = gpu.load()
+    rng = np.random.default_rng(99)
+    motif = synth.synthetic_motif(200, seed=3)
+    stretched = np.repeat(motif, 4)
+    ys = []
+    for r in range(300):
+        n = 3000 if r % 11 else 2600
+        y = rng.normal(0.0, 1.2, n)
+        if r % 3 == 0:
+            off = 100 + (r * 37) % (n - 1000)
+            y[off:off + stretched.size] = stretched
+        ys.append(y)
+    got = api.dtw_subsequence_batch(motif, ys)
+    retries = L.sk_last_dtw_retries()
+    for r, y in enumerate(ys):
+        d, s, e = ora.dtw_subsequence(motif, y)
+        assert (got["dist"][r], got["start"][r], got["end"][r]) == (d, s, e), r
+    assert retries >= 90, "stretched reads should have crossed the restart front (got %d retries)" % retries
+    assert (got["end"] - got["start"]).max() > 700
+
+
+def test_two_pass_l64_long_motif(gpu, ora):
+    """Two-pass on the L=64 kernel family (motif > 256 points) with ragged lengths."""
+    from squigglekit_amd import api, synth
+    motif = synth.synthetic_motif(300, seed=5)
+    sig = synth.squiggle_batch(272, 6000, 1212, motif=motif)
+    lens = np.full(272, 6000, dtype=np.int32)
+    lens[::5] = 4500
+    got = api.motifseq_batch(sig, lens, motif)
+    want = ora.motifseq_batch_i16(sig, lens, motif)
+    _assert_hits(got, want, "two-pass L64")
