@@ -37,6 +37,7 @@
 //          The restart reproduces the state bit for bit, so the result is exact either way.
 #include "sk_common.h"
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -376,8 +377,12 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     // ---- one pass or two? ---------------------------------------------------------------
     // Two passes pay when reads are much longer than the look-back window; the caller's
     // max_len bounds every read's filtered length.
-    const int ck = 256;                                    // multiple of both L
-    const int span = N + N / 2 + 64;                       // look-back in columns (typical paths span ~N)
+    // steps between checkpoints (multiple of both L) and look-back in columns; env overrides are
+    // for tuning runs only.  Typical optimal paths span about N columns (140 for N=163).
+    int ck = 128;
+    int span = N + N / 4 + 32;
+    if (const char *e = getenv("SK_DTW_CK")) { int v = atoi(e); if (v >= 64 && v % 64 == 0) ck = v; }
+    if (const char *e = getenv("SK_DTW_SPAN")) { int v = atoi(e); if (v > 0) span = v; }
     const int64_t maxlen = a->max_len;
     const bool two_pass = !a->last_row && !a->force_single && maxlen >= 4 * (int64_t)(span + ck) &&
                           a->nreads >= 256;
