@@ -17,6 +17,7 @@
 // segment kernels), 48 B of statistics, n/8 B of mask (segmenter only).
 #include "sk_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -31,13 +32,17 @@ struct Scratch {
     int       wsum[2][NWAVE];         // per-wave counts (double buffered by iteration parity)
     long long wred[NWAVE];
     int       sel[4];                 // rank-select results
-    int       nleaf;
-    int       node_start[MAX_NODES];
-    int       node_len[MAX_NODES];
-    int       leaf_id[MAX_NODES];
-    double    node_sum[MAX_NODES];
+    double    node_sum[MAX_NODES];    // pairwise-tree partial sums, heap order (node 1 = chunk)
     double    bcast[2];
 };
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would
+// serialise the global loads we keep in flight across the statistics phase.  Use it wherever the
+// barrier protects LDS data; keep __syncthreads() where global writes must become visible.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 {
@@ -55,7 +60,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wsum /*[NWAVE]*/, int
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int inc = wave_incl_scan(v, lane);
     if (lane == 63) wsum[w] = inc;
-    __syncthreads();
+    lds_barrier();
     int base = 0, tot = 0;
 #pragma unroll
     for (int i = 0; i < NWAVE; i++) {
@@ -88,11 +93,38 @@ __device__ void rank_select2(const unsigned *hist, int nbins, int k1, int k2, Sc
             for (int b = b0; b < b1; b++) { acc += (int)hist[b]; if (k2 < acc) { sc->sel[1] = b; break; } }
         }
     }
-    __syncthreads();
+    lds_barrier();
+}
+
+// numpy's pairwise split tree of a chunk of m elements, addressed without storing it: walk
+// from the root along `bits` (MSB first, nbits of them); a node longer than PW_BLOCK splits at
+// n2 = (len/2) rounded down to a multiple of 8.  With stop_at_leaf the walk ends at the first
+// leaf and succeeds only for the canonical path (remaining bits zero) -- that enumerates every
+// leaf exactly once over the 2^7 possible paths; without it the walk fails if the node does
+// not exist.  id is the heap index (root 1, children 2id, 2id+1).
+__device__ __forceinline__ bool tree_node(int m, unsigned bits, int nbits, bool stop_at_leaf,
+                                          int &start, int &len, int &id)
+{
+    start = 0; len = m; id = 1;
+    for (int b = nbits - 1; b >= 0; b--) {
+        if (len <= PW_BLOCK) {
+            if (!stop_at_leaf) return false;
+            return (bits & ((2u << b) - 1u)) == 0u;
+        }
+        int n2 = len / 2;
+        n2 -= n2 % 8;
+        const unsigned bit = (bits >> b) & 1u;
+        if (bit) { start += n2; len -= n2; } else { len = n2; }
+        id = 2 * id + (int)bit;
+    }
+    return true;
 }
 
 // Sum of term(i), i in [0, m), in the order numpy's pairwise_sum uses (m <= 8192).
 // term(i) must be a pure function.  All 256 threads call; result returned to every thread.
+// Leaves (<= 128 elements) are summed by 8-lane groups -- lane j owns numpy's accumulator
+// r[j], the butterfly shfl_xor 1,2,4 reproduces ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) -- then
+// wave 0 folds the partial sums bottom-up (parent = left + right), wave-synchronously.
 template <typename Term>
 __device__ double pairwise_chunk(int m, Scratch *sc, Term term)
 {
@@ -103,43 +135,20 @@ __device__ double pairwise_chunk(int m, Scratch *sc, Term term)
             for (int i = 0; i < m; i++) res += term(i);
             sc->bcast[0] = res;
         }
-        __syncthreads();
+        lds_barrier();
         double r = sc->bcast[0];
-        __syncthreads();
+        lds_barrier();
         return r;
     }
-    // ---- build the split tree top-down (heap order: node 1 = whole chunk) ------------
-    if (tid == 1) { sc->node_start[1] = 0; sc->node_len[1] = m; }
-    if (tid != 1 && tid < MAX_NODES) { sc->node_start[tid] = 0; sc->node_len[tid] = 0; }
-    __syncthreads();
-    for (int lvl = 1; lvl < 8; lvl++) {            // nodes [2^lvl, 2^(lvl+1))
-        const int lo = 1 << lvl;
-        if (tid >= lo && tid < 2 * lo) {
-            const int par = tid >> 1;
-            const int plen = sc->node_len[par];
-            if (plen > PW_BLOCK) {
-                int n2 = plen / 2;
-                n2 -= n2 % 8;
-                if (tid & 1) { sc->node_start[tid] = sc->node_start[par] + n2; sc->node_len[tid] = plen - n2; }
-                else         { sc->node_start[tid] = sc->node_start[par];      sc->node_len[tid] = n2; }
-            }
-        }
-        __syncthreads();
-    }
-    // ---- leaf list -------------------------------------------------------------------
-    const int mylen = (tid < MAX_NODES && tid >= 1) ? sc->node_len[tid] : 0;
-    const int isleaf = (mylen > 0 && mylen <= PW_BLOCK) ? 1 : 0;
-    int nleaf;
-    const int slot = block_excl_scan(isleaf, sc->wsum[0], &nleaf);
-    if (isleaf) sc->leaf_id[slot] = tid;
-    __syncthreads();
-    // ---- leaf sums: 8 threads per leaf, lane j owns accumulator r[j] ------------------
+    // deepest leaf level: follow the larger (right) child
+    int depth = 0;
+    for (int len = m; len > PW_BLOCK; depth++) { int n2 = len / 2; n2 -= n2 % 8; len -= n2; }
+    const int npaths = 1 << depth;                 // bit-reversed path order packs the leaves first
     const int grp = tid >> 3, j = tid & 7;
-    for (int li = grp; li < ((nleaf + 31) & ~31); li += TPB / 8) {
-        const bool act = li < nleaf;
-        const int node = act ? sc->leaf_id[li] : 0;
-        const int s = act ? sc->node_start[node] : 0;
-        const int len = act ? sc->node_len[node] : 0;
+    for (int idx = grp; idx < ((npaths + 31) & ~31); idx += TPB / 8) {
+        const unsigned path = __brev((unsigned)idx) >> 25;     // 7-bit reversal
+        int s, len, id;
+        const bool act = (idx < 128) && tree_node(m, path, 7, true, s, len, id);
         double r = 0.0;
         if (act) {
             r = term(s + j);
@@ -151,19 +160,24 @@ __device__ double pairwise_chunk(int m, Scratch *sc, Term term)
         r += __shfl_xor(r, 4);
         if (act && j == 0) {
             for (int i = len - (len % 8); i < len; i++) r += term(s + i);
-            sc->node_sum[node] = r;
+            sc->node_sum[id] = r;
         }
     }
-    __syncthreads();
-    // ---- combine bottom-up: parent = left + right ------------------------------------
-    for (int lvl = 6; lvl >= 0; lvl--) {
-        const int lo = 1 << lvl;
-        if (tid >= lo && tid < 2 * lo && sc->node_len[tid] > PW_BLOCK)
-            sc->node_sum[tid] = sc->node_sum[2 * tid] + sc->node_sum[2 * tid + 1];
-        __syncthreads();
+    lds_barrier();
+    if (tid < 64) {
+        volatile double *ns = sc->node_sum;
+        for (int lvl = depth - 1; lvl >= 0; lvl--) {
+            if (tid < (1 << lvl)) {
+                int s, len, id;
+                if (tree_node(m, (unsigned)tid, lvl, false, s, len, id) && len > PW_BLOCK)
+                    ns[id] = ns[2 * id] + ns[2 * id + 1];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
+    lds_barrier();
     double res = sc->node_sum[1];
-    __syncthreads();
+    lds_barrier();
     return res;
 }
 
@@ -182,7 +196,11 @@ __device__ double numpy_sum(int n, Scratch *sc, Term term)
 // ------------------------------------------------------------------------------------------
 // int16 reads
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB)
+// LDSCOMP: the compacted samples also live in LDS (reads up to lds_cap samples), so the std
+// leaf sums and the in-band classification never go back to global memory; the segmenter
+// variant then writes no compacted samples to HBM at all (the walk kernel only needs the mask).
+template <bool LDSCOMP>
+__global__ __launch_bounds__(TPB, 8) __attribute__((amdgpu_num_sgpr(80)))
 void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *__restrict__ len, int nreads,
                 int lo, int hi, int mode, double std_scale, int vec_ok,
                 int16_t *__restrict__ comp, sk_prep *__restrict__ prep,
@@ -194,24 +212,14 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     const int nbins = max(0, hi - lo - 1);                 // values lo+1 .. hi-1
     unsigned *dev = hist + nbins;                          // medmad: 2*nbins+1 bins of |2x - 2med|
     const int ndev = (mode == SK_PREP_MEDMAD) ? 2 * nbins + 1 : 0;
+    int16_t *lcomp = (int16_t *)(hist + nbins + ndev + ((nbins + ndev) & 1));   // 8-byte aligned
 
-    const int r = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int M = len[r];
-    const int16_t *row = sig + (int64_t)r * stride;
-    int16_t *crow = comp + (int64_t)r * stride;
+    const bool to_global = !(LDSCOMP && mode == SK_PREP_SEGMENT);
 
-    for (int b = tid; b < nbins + ndev; b += TPB) hist[b] = 0u;
-    if (tid < 4) sc->sel[tid] = 0;
-    __syncthreads();
-
-    // ---- pass A: filter, compact (order preserving), histogram, exact integer sum ----
-    long long isum = 0;
-    int run = 0;                                           // survivors so far (block uniform)
-    int parity = 0;
-    for (int base = 0; base < M; base += TPB * 8, parity ^= 1) {
-        const int i0 = base + tid * 8;
-        int16_t v[8];
+    // Persistent workgroups: each walks reads r, r + grid, ... and has the first tile of its
+    // next read in flight while it does the statistics of the current one.
+    auto load8 = [&](const int16_t *row, int M, int i0, int16_t (&v)[8]) {
         if (vec_ok && i0 + 8 <= M) {
             const int4 q = *(const int4 *)(row + i0);
             v[0] = (int16_t)(q.x & 0xffff); v[1] = (int16_t)(q.x >> 16);
@@ -222,6 +230,26 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
 #pragma unroll
             for (int k = 0; k < 8; k++) v[k] = (i0 + k < M) ? row[i0 + k] : (int16_t)lo;   // lo is filtered out
         }
+    };
+
+    int16_t v[8], vn[8];
+    int Mnext = (blockIdx.x < nreads) ? len[blockIdx.x] : 0;
+    if (blockIdx.x < nreads) load8(sig + (int64_t)blockIdx.x * stride, Mnext, tid * 8, v);
+    for (int r = blockIdx.x; r < nreads; r += gridDim.x) {
+    const int M = Mnext;
+    const int16_t *row = sig + (int64_t)r * stride;
+    int16_t *crow = comp + (int64_t)r * stride;
+    for (int b = tid; b < nbins + ndev; b += TPB) hist[b] = 0u;
+    if (tid < 4) sc->sel[tid] = 0;
+    lds_barrier();
+
+    // ---- pass A: filter, compact (order preserving), histogram, exact integer sum ----
+    long long isum = 0;
+    int run = 0;                                           // survivors so far (block uniform)
+    int parity = 0;
+    for (int base = 0; base < M; base += TPB * 8, parity ^= 1) {
+        const int i0 = base + tid * 8;
+        if (base + TPB * 8 < M) load8(row, M, i0 + TPB * 8, vn);   // prefetch the next tile
         unsigned keep = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -231,7 +259,7 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
         const int cnt = __popc(keep);
         const int inc = wave_incl_scan(cnt, lane);
         if (lane == 63) sc->wsum[parity][w] = inc;
-        __syncthreads();
+        lds_barrier();
         int wbase = 0, tot = 0;
 #pragma unroll
         for (int i = 0; i < NWAVE; i++) {
@@ -244,14 +272,23 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
         for (int k = 0; k < 8; k++) {
             if (keep & (1u << k)) {
                 const int x = v[k];
-                crow[o++] = (int16_t)x;
+                if (LDSCOMP) lcomp[o] = (int16_t)x;
+                if (to_global) crow[o] = (int16_t)x;
+                o++;
                 atomicAdd(&hist[x - lo - 1], 1u);
                 isum += x;
             }
         }
         run += tot;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = vn[k];
     }
     const int n = run;
+    {                                                      // first tile of my next read
+        const int rn = r + gridDim.x;
+        Mnext = (rn < nreads) ? len[rn] : 0;
+        if (rn < nreads) load8(sig + (int64_t)rn * stride, Mnext, tid * 8, v);
+    }
     __syncthreads();                                       // histogram + compacted samples complete
 
     sk_prep pr;
@@ -261,14 +298,15 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
         const double qnan = __builtin_nan("");
         pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
         if (tid == 0) prep[r] = pr;
-        return;
+        lds_barrier();
+        continue;
     }
 
     // ---- median: ranks (n-1)/2 and n/2 of the value histogram -------------------------
     rank_select2(hist, nbins, (n - 1) / 2, n / 2, sc, 0);
     const int med2 = (sc->sel[0] + lo + 1) + (sc->sel[1] + lo + 1);    // 2 * median, exact
     const double median = (double)med2 * 0.5;
-    __syncthreads();
+    lds_barrier();
 
     if (mode == SK_PREP_MEDMAD) {
         // MAD from the value histogram: |x - med| = |2x - med2| / 2
@@ -276,27 +314,29 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
             const unsigned cb = hist[b];
             if (cb) atomicAdd(&dev[abs(2 * (b + lo + 1) - med2)], cb);
         }
-        __syncthreads();
+        lds_barrier();
         rank_select2(dev, ndev, (n - 1) / 2, n / 2, sc, 1);
         const double mad = (double)(sc->sel[0] + sc->sel[1]) * 0.25;   // (d1/2 + d2/2) / 2, exact
         pr.center = median;
         pr.scale = mad * 1.4826;                                       // MotifSeq.py:196
         if (mad == 0.0) pr.flags |= SK_FLAG_DEGENERATE;
         if (tid == 0) prep[r] = pr;
-        return;
+        lds_barrier();
+        continue;
     }
 
     // ---- mean (exact integer sum) and numpy-order std ----------------------------------
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) isum += __shfl_xor(isum, d);
     if (lane == 0) sc->wred[w] = isum;
-    __syncthreads();
+    lds_barrier();
     long long S = 0;
 #pragma unroll
     for (int i = 0; i < NWAVE; i++) S += sc->wred[i];
     const double mean = (double)S / (double)n;
+    const int16_t *src = LDSCOMP ? (const int16_t *)lcomp : (const int16_t *)crow;
     const double ssq = numpy_sum(n, sc, [&](int i) {
-        const double d = (double)crow[i] - mean;
+        const double d = (double)src[i] - mean;
         return d * d;
     });
     const double sd = sqrt(ssq / (double)n);
@@ -305,7 +345,8 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
         pr.center = mean;
         pr.scale = (sd == 0.0) ? 1.0 : sd;                 // sklearn _handle_zeros_in_scale
         if (tid == 0) prep[r] = pr;
-        return;
+        lds_barrier();
+        continue;
     }
 
     // ---- segmenter thresholds + in-band mask (segmenter.py:413-414,431) -----------------
@@ -318,11 +359,13 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
         const int i = base + tid;
         bool in = false;
         if (i < n) {
-            const double a = (double)crow[i];
+            const double a = (double)src[i];
             in = (a < top) && (a > bot);
         }
         const unsigned long long bits = __ballot(in);
         if (lane == 0) maskT[(int64_t)(i >> 6) * mask_rows + r] = bits;
+    }
+    lds_barrier();                                       // LDS is reused by the next read
     }
 }
 
@@ -355,14 +398,14 @@ __device__ void block_minmax_u64(unsigned long long &mn, unsigned long long &mx,
         mx = b > mx ? b : mx;
     }
     if (lane == 0) { tmp[w] = mn; tmp[NWAVE + w] = mx; }
-    __syncthreads();
+    lds_barrier();
     mn = tmp[0]; mx = tmp[NWAVE];
 #pragma unroll
     for (int i = 1; i < NWAVE; i++) {
         mn = tmp[i] < mn ? tmp[i] : mn;
         mx = tmp[NWAVE + i] > mx ? tmp[NWAVE + i] : mx;
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // Key of rank k (0-based) among key(0..n-1).  kmin/kmax: block-uniform extremes of the keys.
@@ -378,21 +421,21 @@ __device__ unsigned long long radix_select(int n, int k, Scratch *sc, unsigned *
     unsigned long long prefix = kmin & pmask;
     for (; shift >= 0; shift -= 8) {
         hist256[tid] = 0u;
-        __syncthreads();
+        lds_barrier();
         for (int i = tid; i < n; i += TPB) {
             const unsigned long long kk = key(i);
             if ((kk & pmask) == prefix) atomicAdd(&hist256[(unsigned)(kk >> shift) & 255u], 1u);
         }
-        __syncthreads();
+        lds_barrier();
         const int c = (int)hist256[tid];
         int total;
         const int excl = block_excl_scan(c, sc->wsum[0], &total);
         if (c > 0 && k >= excl && k < excl + c) { sc->sel[0] = tid; sc->sel[1] = k - excl; }
-        __syncthreads();
+        lds_barrier();
         prefix |= (unsigned long long)(unsigned)sc->sel[0] << shift;
         pmask |= 0xffull << shift;
         k = sc->sel[1];
-        __syncthreads();
+        lds_barrier();
     }
     return prefix;
 }
@@ -443,7 +486,7 @@ void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off,
         const int cnt = __popc(keep);
         const int inc = wave_incl_scan(cnt, lane);
         if (lane == 63) sc->wsum[parity][w] = inc;
-        __syncthreads();
+        lds_barrier();
         int wbase = 0, tot = 0;
 #pragma unroll
         for (int i = 0; i < NWAVE; i++) {
@@ -538,16 +581,32 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
     if (nreads <= 0) return SK_OK;
     const int64_t nbins = (int64_t)hi - (int64_t)lo - 1 > 0 ? (int64_t)hi - lo - 1 : 0;
     const int64_t words = (mode == SK_PREP_MEDMAD) ? 3 * nbins + 1 : nbins;
-    const size_t lds = sizeof(Scratch) + (size_t)words * 4;
+    size_t lds = sizeof(Scratch) + (size_t)(words + (words & 1)) * 4;
     if (lds > 160 * 1024)
         return sk_fail(SK_ERR_UNSUPPORTED,
                        "outlier limits (%d, %d) span %lld integer values: the LDS histogram holds %d (%s)",
                        lo, hi, (long long)nbins, (mode == SK_PREP_MEDMAD) ? 12900 : 38900,
                        "narrow -scale_low/-scale_hi / -lim_low/-lim_hi");
     const int vec_ok = (((uintptr_t)d_sig & 15) == 0 && (stride % 8) == 0) ? 1 : 0;
+    // keep the compacted samples in LDS when the whole read fits next to the histograms without
+    // dropping below ~4 workgroups per CU (mean/std modes only; medmad never re-reads samples)
+    const size_t lds_comp = (size_t)stride * sizeof(int16_t);
+    const bool ldscomp = mode != SK_PREP_MEDMAD && lds + lds_comp <= 40 * 1024;
+    if (ldscomp) lds += lds_comp;
+    auto fn = ldscomp ? k_prep_i16<true> : k_prep_i16<false>;
     if (lds > 64 * 1024)
-        SK_HIP(hipFuncSetAttribute((const void *)k_prep_i16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_prep_i16, dim3(nreads), dim3(TPB), lds, c->stream, d_sig, stride, d_len, nreads,
+        SK_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // persistent grid: as many workgroups as the chip holds (8 x 256 threads per CU, LDS permitting)
+    int per_cu = (int)((160 * 1024) / (lds + 512));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    // several grid "rounds" so that the resident count (fewer than per_cu when SGPRs bind) does
+    // not have to divide the grid; SK_PREP_ROUNDS is a tuning override
+    int rounds = 6;
+    if (const char *e = getenv("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
+    long long g = (long long)c->num_cu * per_cu * rounds;
+    int grid = g > nreads ? nreads : (int)g;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(TPB), lds, c->stream, d_sig, stride, d_len, nreads,
                        lo, hi, mode, std_scale, vec_ok, d_comp, d_prep, d_mask, mask_stride);
     SK_HIP(hipGetLastError());
     return SK_OK;
