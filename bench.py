@@ -125,6 +125,7 @@ def main():
     for _ in range(a.warmup):
         step()
     prep_ms = main_ms = 0.0
+    dtw_prof = {"dist_ms": 0.0, "start_ms": 0.0, "launches": 0, "retries": 0}
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -133,6 +134,14 @@ def main():
         check(L.sk_last_kernel_ms(C.byref(p_), C.byref(m_)))   # HIP events on the library's stream
         prep_ms += p_.value
         main_ms += m_.value
+        if a.workload == "motifseq":           # per-launch times of the two DTW passes
+            da, sb = C.c_float(), C.c_float()
+            la, lb, rpl = C.c_int32(), C.c_int32(), C.c_int32()
+            check(L.sk_last_dtw_profile(C.byref(da), C.byref(la), C.byref(sb), C.byref(lb), C.byref(rpl)))
+            dtw_prof["dist_ms"] += da.value
+            dtw_prof["start_ms"] += sb.value
+            dtw_prof["launches"] += la.value
+            dtw_prof["retries"] += L.sk_last_dtw_retries()
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -189,7 +198,17 @@ def main():
         valu = {"bound": "valu_f64", "achieved": R * cells * 4 / (main_ms * 1e-3) / 1e12,
                 "peak": VALU_F64_LANEOPS / 1e12, "unit": "Tlane-op/s (4 canonical f64 ops per cell)"}
         valu["frac"] = valu["achieved"] / valu["peak"]
-        dominant, dom_ms = "k_sdtw", main_ms
+        dominant, dom_ms = "k_sdtw (all launches of one call)", main_ms
+        if dtw_prof["launches"] > 0:
+            # dominant kernel = the distance pass k_sdtw<L,R,feed,DIST>; one launch covers one chunk
+            per_step = dtw_prof["launches"] / a.steps
+            dominant = "k_sdtw<16,%d,0,1> (distance pass, %d launches per call)" % ((N + 15) // 16, per_step) \
+                if N <= 256 else "k_sdtw<64,%d,0,1> (distance pass)" % ((N + 63) // 64)
+            dom_ms = dtw_prof["dist_ms"] / dtw_prof["launches"]
+            alg_bytes = alg_bytes / per_step                   # algorithmic bytes one launch covers
+            valu["passes_ms_per_call"] = {"dist": dtw_prof["dist_ms"] / a.steps,
+                                          "start": dtw_prof["start_ms"] / a.steps,
+                                          "retried_reads": dtw_prof["retries"] / a.steps}
     else:
         segs = np.empty((S, max_segs, 2), dtype=np.int32)
         nsegs = np.empty(S, dtype=np.int32)
@@ -209,9 +228,26 @@ def main():
         dominant, dom_ms = ("k_prep_i16", prep_ms) if prep_ms >= main_ms else ("k_segment_walk", main_ms)
 
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    # HBM bytes from the PMC passes (FETCH_SIZE, WRITE_SIZE; collected separately with rocprofv3 --pmc
+    # and committed under profiles/ -- a bench run cannot read hardware counters itself)
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = [k for k in tj["kernels"] if ("1>" in k if a.workload == "motifseq" else "k_prep_i16" in k)]
+            if key and tj.get("reads_per_call"):
+                kk = tj["kernels"][key[0]]
+                per_read = (kk["fetch_bytes_total"] + kk["write_bytes_total"]) / (
+                    tj["reads_per_call"] * max(1, tj.get("calls", 1)))
+                traffic = per_read * (alg_bytes / (2 * M + HIT_BYTES) if a.workload == "motifseq" else R)
+                traffic_src = "profiles/traffic_%s.json: %s, %.0f B/read measured" % (a.workload, key[0], per_read)
+        except Exception:
+            traffic = None
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel_ms": {"prep": prep_ms, "main": main_ms},
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src,
+                "kernel_ms": {"prep": prep_ms, "main": main_ms, "dominant_avg_launch": dom_ms},
                 "algorithmic_bytes_per_launch": alg_bytes}
     if valu:
         roofline["binding"] = "valu_f64 (min-plus recurrence; HBM is not the limiter, DESIGN.md)"

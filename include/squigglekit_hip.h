@@ -149,6 +149,11 @@ int sk_last_kernel_ms(float *prep_ms, float *main_ms);
 /* Reads of the most recent DTW call whose optimal path was longer than the two-pass
  * look-back window and were therefore recomputed by the exact single pass (diagnostic). */
 int sk_last_dtw_retries(void);
+/* Per-launch view of the most recent two-pass DTW call: summed HIP-event time and launch count
+ * of the distance pass (k_sdtw<..,DIST>) and of the start pass (k_sdtw<..,START>), and the reads
+ * covered by the largest launch.  *dist_launches == 0 means the call used the single pass. */
+int sk_last_dtw_profile(float *dist_ms, int *dist_launches, float *start_ms, int *start_launches,
+                        int *reads_per_launch);
 /* Synthetic squiggle generator on the device (bench input; not a reference
  * function): fills d_sig[nreads][nsamples] int16 deterministically from seed. */
 int sk_synth_squiggles_dev(int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,

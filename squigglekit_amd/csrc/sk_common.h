@@ -51,6 +51,9 @@ struct sk_ctx {
     sk_buf ckpt;      // DTW pass-A checkpoints (systolic state dumps)
     sk_buf retry;     // DTW pass-B retry counter + read list
     int    last_retry = 0;   // reads that needed the exact single-pass retry in the last DTW call
+    std::vector<hipEvent_t> evpool;   // per-launch events of the two-pass DTW (3 per chunk)
+    int    prof_chunks = 0;  // chunks of the last two-pass DTW call (0: single pass)
+    int    prof_reads[64] = {0};
     std::vector<double> motif_host;   // last laid-out motif (kept alive for async H2D)
     std::vector<double> motif_src;    // the motif it was built from (upload cache key)
 };

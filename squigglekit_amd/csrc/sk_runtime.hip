@@ -104,6 +104,7 @@ int sk_shutdown(void)
                           &c->motif, &c->out, &c->out2, &c->misc, &c->ckpt, &c->retry};
         for (sk_buf *b : bufs) free_buf(b);
         for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev[i]);
+        for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(c->stream);
         *c = sk_ctx();
     }
@@ -182,6 +183,30 @@ int sk_last_kernel_ms(float *prep_ms, float *main_ms)
     SK_HIP(hipEventElapsedTime(&b, c->ev[2], c->ev[3]));
     if (prep_ms) *prep_ms = a;
     if (main_ms) *main_ms = b;
+    return SK_OK;
+}
+
+int sk_last_dtw_profile(float *dist_ms, int *dist_launches, float *start_ms, int *start_launches,
+                        int *reads_per_launch)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    float a = 0.f, b = 0.f;
+    int mx = 0;
+    for (int i = 0; i < c->prof_chunks; i++) {
+        hipEvent_t *ev = &c->evpool[3 * (size_t)i];
+        SK_HIP(hipEventSynchronize(ev[2]));
+        float t = 0.f;
+        SK_HIP(hipEventElapsedTime(&t, ev[0], ev[1])); a += t;
+        SK_HIP(hipEventElapsedTime(&t, ev[1], ev[2])); b += t;
+        const int rr = c->prof_reads[i < 64 ? i : 63];
+        if (rr > mx) mx = rr;
+    }
+    if (dist_ms) *dist_ms = a;
+    if (start_ms) *start_ms = b;
+    if (dist_launches) *dist_launches = c->prof_chunks;
+    if (start_launches) *start_launches = c->prof_chunks;
+    if (reads_per_launch) *reads_per_launch = mx;
     return SK_OK;
 }
 

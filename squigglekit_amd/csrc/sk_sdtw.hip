@@ -389,6 +389,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     SK_HIP(hipEventRecord(c->ev[2], c->stream));
     if (!two_pass) {
         c->last_retry = 0;
+        c->prof_chunks = 0;
         sdtw_fn fn = pick_any(a->feed, L, R, MODE_FULL);
         if (!fn) return sk_fail(SK_ERR_UNSUPPORTED, "no kernel for L=%d R=%d", L, R);
         int rc = launch(c, fn, k, L);
@@ -414,11 +415,25 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     SK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), c->stream));
     k.ckpt = (double *)c->ckpt.p; k.nck = nck; k.ck = ck; k.span = span;
     k.retry = cnt + 1; k.retry_cnt = cnt;
+    // per-launch HIP events (pool grows on demand) so a profile can name each pass's duration
+    const size_t nchunks = (size_t)((a->nreads + chunk - 1) / chunk);
+    while (c->evpool.size() < 3 * nchunks) {
+        hipEvent_t e;
+        SK_HIP(hipEventCreate(&e));
+        c->evpool.push_back(e);
+    }
+    c->prof_chunks = 0;
     for (int64_t r0 = 0; r0 < a->nreads; r0 += chunk) {
         k.read0 = (int)r0;
         k.nreads = (int)((a->nreads - r0 < chunk) ? a->nreads - r0 : chunk);
+        hipEvent_t *ev = &c->evpool[3 * (size_t)c->prof_chunks];
+        SK_HIP(hipEventRecord(ev[0], c->stream));
         if ((rc = launch(c, fa, k, L))) return rc;         // pass A: dist, end, checkpoints
+        SK_HIP(hipEventRecord(ev[1], c->stream));
         if ((rc = launch(c, fb, k, L))) return rc;         // pass B: start from the nearest checkpoint
+        SK_HIP(hipEventRecord(ev[2], c->stream));
+        c->prof_reads[c->prof_chunks < 64 ? c->prof_chunks : 63] = k.nreads;
+        c->prof_chunks++;
     }
     // reads whose path crossed the restart front: exact single pass on just those
     int32_t nretry = 0;

@@ -17,51 +17,69 @@ struct WalkParams {
     int error, corrector, window, seg_dist, first_len;   // first_len = ceil(window * stall_len)
 };
 
+// Per-sample update written as straight-line selects: the 64 lanes of a wave are 64 different
+// reads in 64 different states, so `if` ladders would execute every arm at every step.  Only the
+// two rare events leave the straight line: closing a segment that is long enough to be reported
+// (a handful per read) and the corrector test (dead unless error >= corrector).
 __global__ __launch_bounds__(64)
 void k_segment_walk(const uint64_t *__restrict__ maskT, int64_t mask_rows,
                     const sk_prep *__restrict__ prep, int nreads, WalkParams p,
                     int32_t *__restrict__ segs, int32_t *__restrict__ nsegs, int max_segs)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nreads) return;
-    const int n = prep[r].n;
-    int32_t *my = segs + (int64_t)r * 2 * max_segs;
+    const bool live = r < nreads;
+    const int n = live ? prep[r].n : 0;
+    int32_t *my = segs + (int64_t)(live ? r : 0) * 2 * max_segs;
 
-    bool prev = false;
+    int prev = 0;                                 // inside a candidate segment
     int err = 0, prev_err = 0, c = 0;
     int w = p.corrector;                          // segmenter.py:424 -- never reset inside a read
     int start = 0, nseg = 0, last_end = 0;
 
-    for (int wi = 0; wi * 64 < n; wi++) {
-        const uint64_t word = maskT[(int64_t)wi * mask_rows + r];
-        const int lim = min(64, n - wi * 64);
-        for (int b = 0; b < lim; b++) {
-            const int i = wi * 64 + b;
-            if ((word >> b) & 1) {                                         // :431 in band
-                if (!prev) { start = i; prev = true; }
-                c++; w++; prev_err = 0;
-                if (c >= p.window && c >= w && (c % w) == 0) err--;        // :439
-            } else if (prev) {
-                if (err < p.error) {                                       // :442 tolerated
-                    c++; err++; prev_err++;
-                    if (c >= p.window && c >= w && (c % w) == 0) err--;    // :446
-                } else {
-                    if (c >= p.window || (nseg == 0 && c >= p.first_len)) {    // :448 close
-                        const int end = i - prev_err;                      // :449
-                        if (nseg > 0 && start - last_end < p.seg_dist) {   // :451 merge
-                            if (nseg <= max_segs) my[2 * (nseg - 1) + 1] = end;
-                        } else {
-                            if (nseg < max_segs) { my[2 * nseg] = start; my[2 * nseg + 1] = end; }
-                            nseg++;
-                        }
-                        last_end = end;
+    int nmax = n;                                 // wave-uniform trip count (lanes past their n idle)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+    const int nwords = (nmax + 63) >> 6;
+
+    uint64_t next = (n > 0) ? maskT[r] : 0ull;
+    for (int wi = 0; wi < nwords; wi++) {
+        const uint64_t word = next;
+        if ((wi + 1) * 64 < n) next = maskT[(int64_t)(wi + 1) * mask_rows + r];     // prefetch
+        const unsigned half[2] = {(unsigned)word, (unsigned)(word >> 32)};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned bits = half[h];
+#pragma unroll 4
+            for (int b = 0; b < 32; b++) {
+                const int i = wi * 64 + h * 32 + b;
+                const int valid = i < n;
+                const int inb = (int)((bits >> b) & 1u) & valid;                   // :431 in band
+                const int tol = (inb ^ 1) & prev & (int)(err < p.error) & valid;   // :442 tolerated
+                const int act = inb | tol;
+                const int closing = prev & (act ^ 1) & valid;                      // :448 / :458
+                if (closing && (c >= p.window || (nseg == 0 && c >= p.first_len))) {
+                    const int end = i - prev_err;                                  // :449
+                    if (nseg > 0 && start - last_end < p.seg_dist) {               // :451 merge
+                        if (nseg <= max_segs) my[2 * (nseg - 1) + 1] = end;
+                    } else {
+                        if (nseg < max_segs) { my[2 * nseg] = start; my[2 * nseg + 1] = end; }
+                        nseg++;
                     }
-                    prev = false; c = 0; err = 0; prev_err = 0;            // :455-462
+                    last_end = end;
+                }
+                start = (inb & (prev ^ 1)) ? i : start;
+                c = act ? c + 1 : (valid ? 0 : c);
+                w += inb;
+                err = tol ? err + 1 : (act ? err : (valid ? 0 : err));
+                prev_err = tol ? prev_err + 1 : (valid ? 0 : prev_err);
+                prev = valid ? act : prev;
+                if (act && c >= p.window && c >= w) {                              // :439 / :446
+                    if ((c % w) == 0) err--;
                 }
             }
         }
     }
-    nsegs[r] = nseg;                              // a segment still open at EOF is dropped (:466)
+    if (live) nsegs[r] = nseg;                    // a segment still open at EOF is dropped (:466)
 }
 
 } // namespace
