@@ -142,6 +142,27 @@ int sk_normalise_i16(const int16_t *sig, int32_t len, int32_t scale_mode,
 int sk_normalise_f64(const double *sig, int32_t len, int32_t scale_mode,
                      int32_t scale_low, int32_t scale_hi, double *out, int32_t *n_out);
 
+/* ---- TSV ingest (host code; no GPU needed) ------------------------------ */
+/* Native replacement of the per-line split + int()/float() loops that feed the hot path
+ * (segmenter.py:192-201 reads columns 4.., MotifSeq.py:265-270 columns 8..; layout written by
+ * SquigglePull.py:243-253).  Three calls: count lines, count data tokens per line (caller turns
+ * them into offsets), parse into one flat float64 array.  Conversion is exactly float()'s for
+ * plain decimal tokens; lines with any other token get SK_TSV_SLOW and should be parsed by the
+ * caller the slow way. */
+enum {
+    SK_TSV_ALLINT   = 1,   /* every data token is [+-]digits                                  */
+    SK_TSV_ANY      = 2,   /* some value is non-zero (the reference skips reads where none is) */
+    SK_TSV_FIRSTDOT = 4,   /* the first data token contains '.' (segmenter.py:198 picks float) */
+    SK_TSV_SLOW     = 8,   /* a token is outside the plain grammar: use the fallback parser    */
+    SK_TSV_SHORT    = 16   /* the line has no data column at all                               */
+};
+int64_t sk_tsv_count_lines(const char *buf, size_t len);
+int sk_tsv_count_tokens(const char *buf, size_t len, int32_t start_col, int64_t nlines, int64_t *ntok,
+                        int32_t nthreads);
+int sk_tsv_parse(const char *buf, size_t len, int32_t start_col, int64_t nlines, const int64_t *off,
+                 double *values, int64_t *name_off, int32_t *name_len, int64_t *id_off, int32_t *id_len,
+                 int32_t *flags, int32_t nthreads);
+
 /* ---- instrumentation -------------------------------------------------- */
 /* HIP-event durations (ms) of the kernels of the most recent *_dev / batch
  * call on this thread's device: prep (filter+stats), main (DTW or segment walk). */

@@ -80,6 +80,10 @@ ABI = {
     "sk_dtw_subsequence": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _dp, _i32p, _i32p, _vp]),
     "sk_normalise_i16": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _i32p]),
     "sk_normalise_f64": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _i32p]),
+    "sk_tsv_count_lines": (C.c_int64, [_vp, C.c_size_t]),
+    "sk_tsv_count_tokens": (C.c_int, [_vp, C.c_size_t, C.c_int32, C.c_int64, _vp, C.c_int32]),
+    "sk_tsv_parse": (C.c_int, [_vp, C.c_size_t, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               C.c_int32]),
     "sk_last_kernel_ms": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sk_last_dtw_retries": (C.c_int, []),
     "sk_last_dtw_profile": (C.c_int, [C.POINTER(C.c_float), _i32p, C.POINTER(C.c_float), _i32p, _i32p]),

@@ -179,13 +179,16 @@ def main(argv=None):
     _lib.init(args.device)
     out = _Batcher(args, models, order, lens)
     if args.signal:
-        with tsvio.open_text(args.signal) as fh:
-            for line in fh:
-                fast5, read_id, sig = tsvio.parse_motifseq_line(line)
-                if not sig.any():                    # MotifSeq.py:271-273
-                    out.note("No Signal found - please check signal format\n")
-                    continue
-                out.add(fast5, read_id, sig)
+        for fast5, read_id, vals, fl, raw in tsvio.iter_tsv_native(args.signal, 8):
+            if fl & 8 or (fl & 16 and raw is not None and raw.count(b"\t") < 1):
+                # odd tokens (or not even a readID column): the reference's own parse, exceptions included
+                fast5, read_id, sig = tsvio.parse_motifseq_line(raw.decode())
+            else:
+                sig = vals
+            if not sig.any():                        # MotifSeq.py:271-273
+                out.note("No Signal found - please check signal format\n")
+                continue
+            out.add(fast5, read_id, sig)
     else:
         if args.f5f:                                 # MotifSeq.py:165-184: first column = path
             with tsvio.open_text(args.f5f) as fh:

@@ -123,13 +123,17 @@ def main(argv=None):
     out = _Batcher(args)
 
     if args.signal:
-        with tsvio.open_text(args.signal) as fh:
-            for line in fh:
-                name, sig = tsvio.parse_segmenter_line(line)
-                if not sig.any():                   # segmenter.py:203-205
-                    out.note("No signal found in file: {} {}".format(args.signal, name))
-                    continue
-                out.add(name, sig[:args.Num])
+        # native tokenizer; a line it cannot take verbatim (odd tokens, too few columns, a
+        # non-integer token in an "integer" line) is re-parsed exactly the reference's way
+        for name, _rid, vals, fl, raw in tsvio.iter_tsv_native(args.signal, 4):
+            if (fl & 24) or not (fl & 5):           # SLOW | SHORT, or neither FIRSTDOT nor ALLINT
+                name, sig = tsvio.parse_segmenter_line(raw.decode())
+            else:
+                sig = vals
+            if not sig.any():                       # segmenter.py:203-205
+                out.note("No signal found in file: {} {}".format(args.signal, name))
+                continue
+            out.add(name, sig[:args.Num])
     elif args.blow5:
         from .blow5 import read_blow5, to_pA
         for rec in read_blow5(args.blow5):

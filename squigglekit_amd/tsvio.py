@@ -38,6 +38,64 @@ def parse_motifseq_line(line):
     return cols[0], cols[1], np.array([float(v) for v in cols[8:]])
 
 
+def iter_tsv_native(path, start_col, chunk_bytes=64 << 20, nthreads=None):
+    """Stream a SquigglePull TSV through the native tokenizer (csrc/sk_tsv.cpp).
+
+    Yields (name, read_id, values, flags, raw_line) per line, in file order:
+      values  float64 array of the columns from start_col on (integers are exact)
+      flags   SK_TSV_* bits (ALLINT=1, ANY=2, FIRSTDOT=4, SLOW=8, SHORT=16)
+      raw_line the undecoded line (bytes) -- only needed when flags & SLOW/SHORT tells the
+               caller to re-parse it the reference's way.
+    No GPU is involved; the library only has to be loadable."""
+    import ctypes as C
+    import os
+    from . import _lib
+    L = _lib.load()
+    nthreads = nthreads or min(32, os.cpu_count() or 1)
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rb") as fh:
+        tail = b""
+        while True:
+            block = fh.read(chunk_bytes)
+            if not block and not tail:
+                break
+            buf = tail + block
+            if block:
+                cut = buf.rfind(b"\n")
+                if cut < 0:
+                    tail = buf                      # no complete line yet
+                    continue
+                tail, buf = buf[cut + 1:], buf[:cut + 1]
+            else:
+                tail = b""
+            n = L.sk_tsv_count_lines(buf, len(buf))
+            if n <= 0:
+                continue
+            ntok = np.zeros(n, dtype=np.int64)
+            _lib.check(L.sk_tsv_count_tokens(buf, len(buf), start_col, n, _lib.ptr(ntok), nthreads))
+            off = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(ntok, out=off[1:])
+            values = np.empty(max(1, int(off[-1])), dtype=np.float64)
+            name_off = np.zeros(n, dtype=np.int64)
+            name_len = np.zeros(n, dtype=np.int32)
+            id_off = np.zeros(n, dtype=np.int64)
+            id_len = np.zeros(n, dtype=np.int32)
+            flags = np.zeros(n, dtype=np.int32)
+            _lib.check(L.sk_tsv_parse(buf, len(buf), start_col, n, _lib.ptr(off), _lib.ptr(values),
+                                      _lib.ptr(name_off), _lib.ptr(name_len), _lib.ptr(id_off),
+                                      _lib.ptr(id_len), _lib.ptr(flags), nthreads))
+            pos = 0
+            for i in range(n):
+                nl = buf.find(b"\n", pos)
+                end = nl if nl >= 0 else len(buf)
+                fl = int(flags[i])
+                raw = buf[pos:end] if (fl & 24) or not (fl & 5) else None
+                yield (buf[name_off[i]:name_off[i] + name_len[i]].decode(),
+                       buf[id_off[i]:id_off[i] + id_len[i]].decode(),
+                       values[off[i]:off[i + 1]], fl, raw)
+                pos = end + 1
+
+
 # ----------------------------------------------------------------------------
 # motif models
 # ----------------------------------------------------------------------------
