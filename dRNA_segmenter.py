@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""dRNA_segmenter.py -- MI355X drop-in for SquiggleKit's dRNA_segmenter.py (slow5 branch).
+Thin launcher; the tool lives in squigglekit_amd/drna_cli.py."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from squigglekit_amd.drna_cli import main  # noqa: E402
+
+if __name__ == "__main__":
+    main()

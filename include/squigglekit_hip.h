@@ -109,6 +109,25 @@ int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
 int sk_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
                        const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs);
 
+/* ---- dRNA adapter segmenter (dRNA_segmenter.py, slow5 branch :85-176) ---- */
+/* The script hard-codes these (dRNA_segmenter.py:80-104); they are parameters here. */
+typedef struct sk_drna_params {
+    int32_t error;          /* 5     tolerated out-of-band samples                         */
+    int32_t no_err_thresh;  /* 2500  errors only count from this sample index on           */
+    int32_t w;              /* 1200  constant corrector period                             */
+    int32_t window;         /* 100   shortest segment kept                                 */
+    int32_t seg_dist;       /* 1200  merge distance, and the "adapter found" stop distance */
+    int32_t t_start;        /* 1000  statistics come from filtered samples [t_start, t_end) */
+    int32_t t_end;          /* 5000                                                        */
+    double  std_scale;      /* 0.8   top = median + std * std_scale (one sided: a < top)   */
+    int32_t lim_low;        /* 0     scale_outliers limits (dRNA_segmenter.py:329-332)     */
+    int32_t lim_hi;         /* 1200                                                        */
+} sk_drna_params;
+/* Per read: scale_outliers, window statistics, the scan.  segs holds every segment collected
+ * before the scan stopped (the script prints the first one only). */
+int sk_drna_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
+                              const sk_drna_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs);
+
 /* ---- MotifSeq path ---------------------------------------------------- */
 /* Replaces, per read r: scale_outliers (MotifSeq.py:274,317-324), medmad
  * (:192-200) or zscale (:186-191), then mlpy.dtw_subsequence(motif, sig)

@@ -37,6 +37,17 @@ class SegParams(C.Structure):
         super().__init__(error, corrector, window, seg_dist, std_scale, stall_len)
 
 
+class DrnaParams(C.Structure):
+    """Mirror of ora_drna_params; defaults are dRNA_segmenter.py:80-104's constants."""
+    _fields_ = [("error", C.c_int32), ("no_err_thresh", C.c_int32), ("w", C.c_int32),
+                ("window", C.c_int32), ("seg_dist", C.c_int32), ("t_start", C.c_int32),
+                ("t_end", C.c_int32), ("std_scale", C.c_double)]
+
+    def __init__(self, error=5, no_err_thresh=2500, w=1200, window=100, seg_dist=1200,
+                 t_start=1000, t_end=5000, std_scale=0.8):
+        super().__init__(error, no_err_thresh, w, window, seg_dist, t_start, t_end, std_scale)
+
+
 class Hit(C.Structure):
     _fields_ = [("dist", C.c_double), ("start", C.c_int32), ("end", C.c_int32),
                 ("n", C.c_int32), ("flags", C.c_int32)]
@@ -65,6 +76,8 @@ def lib():
         L.ora_scale_outliers.argtypes = [dp, C.c_int64, C.c_double, C.c_double, dp]
         L.ora_get_segs.restype = C.c_int32
         L.ora_get_segs.argtypes = [dp, C.c_int64, C.POINTER(SegParams), ip, C.c_int32, dp, dp]
+        L.ora_drna_segs.restype = C.c_int32
+        L.ora_drna_segs.argtypes = [dp, C.c_int64, C.POINTER(DrnaParams), ip, C.c_int32, dp]
         L.ora_medmad.restype = None
         L.ora_medmad.argtypes = [dp, C.c_int64, dp, dp, dp]
         L.ora_zscale.restype = C.c_int
@@ -143,6 +156,18 @@ def get_segs(sig, params=None, max_segs=4096, return_thresholds=False):
     if return_thresholds:
         return out, top.value, bot.value
     return out
+
+
+def drna_segs(sig, params=None, max_segs=256):
+    """dRNA_segmenter's slow5-branch scan on an already filtered signal: list of [start, end]."""
+    a, p = _d(sig)
+    params = params or DrnaParams()
+    segs = np.zeros(2 * max_segs, dtype=np.int32)
+    top = C.c_double()
+    k = lib().ora_drna_segs(p, a.size, C.byref(params), _i(segs), max_segs, C.byref(top))
+    if k < 0:
+        raise ValueError("invalid dRNA parameters")
+    return segs[:2 * min(k, max_segs)].reshape(-1, 2).tolist(), top.value
 
 
 def medmad(x):

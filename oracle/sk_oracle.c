@@ -414,3 +414,58 @@ int ora_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------ */
+/* dRNA_segmenter.py, slow5 branch (dRNA_segmenter.py:85-176)           */
+/* ------------------------------------------------------------------ */
+/* sig: already filtered by its scale_outliers (0 < x < 1200, :329-332).  Thresholds come from
+ * the slice sig[t_start:t_end] (:109-111); the scan is one-sided (a < top), errors only count
+ * from sample no_err_thresh on, `w` is a constant, and the scan stops once the signal has left
+ * the last segment by more than seg_dist (:152-159).  Returns the number of segments collected
+ * before the scan stopped (the script prints only the first one, :173-176). */
+int32_t ora_drna_segs(const double *sig, int64_t n, const ora_drna_params *p,
+                      int32_t *segs, int32_t max_segs, double *top_out)
+{
+    if (!p || p->w <= 0) return -1;
+    int64_t a0 = p->t_start < n ? p->t_start : n, a1 = p->t_end < n ? p->t_end : n;
+    if (a0 < 0) a0 = 0;
+    if (a1 < a0) a1 = a0;
+    double median = ora_median(sig + a0, a1 - a0);      /* NaN on an empty slice, like numpy */
+    double stdev = ora_std(sig + a0, a1 - a0);
+    double top = median + (stdev * p->std_scale);
+    if (top_out) *top_out = top;
+
+    int prev = 0;
+    int64_t err = 0, prev_err = 0, c = 0, start = 0, last_end = 0;
+    int32_t nseg = 0;
+    for (int64_t i = 0; i < n; i++) {
+        double a = sig[i];
+        if (a < top) {
+            if (!prev) { start = i; prev = 1; err = 0; }
+            c += 1;
+            if (prev_err) prev_err = 0;
+            if (c >= p->window && c >= p->w && (c % p->w) == 0) err -= 1;
+        } else {
+            if (prev && err < p->error) {
+                c += 1;
+                if (i >= p->no_err_thresh) { err += 1; prev_err += 1; }
+                if (c >= p->window && c >= p->w && (c % p->w) == 0) err -= 1;
+            } else if (prev) {
+                if (c >= p->window) {
+                    int64_t end = i - prev_err;
+                    if (nseg > 0 && start - last_end < p->seg_dist) {
+                        if (nseg <= max_segs) segs[2 * (nseg - 1) + 1] = (int32_t)end;
+                    } else {
+                        if (nseg < max_segs) { segs[2 * nseg] = (int32_t)start; segs[2 * nseg + 1] = (int32_t)end; }
+                        nseg++;
+                    }
+                    last_end = end;
+                }
+                prev = 0; c = 0; err = 0; prev_err = 0;
+            } else if (nseg > 0 && i - last_end > p->seg_dist) {
+                break;                                   /* adapter found */
+            }
+        }
+    }
+    return nseg;
+}

@@ -75,6 +75,20 @@ int ora_dtw_subsequence_fwd(const double *x, int32_t nx, const double *y, int32_
 int32_t ora_dtw_subsequence_path(const double *x, int32_t nx, const double *y, int32_t ny,
                                  int32_t *px, int32_t *py, int32_t cap);
 
+/* dRNA_segmenter.py slow5 branch; defaults are its hard-coded values (dRNA_segmenter.py:80-104). */
+typedef struct {
+    int32_t error;          /* 5    */
+    int32_t no_err_thresh;  /* 2500 */
+    int32_t w;              /* 1200 (constant corrector) */
+    int32_t window;         /* 100  */
+    int32_t seg_dist;       /* 1200 */
+    int32_t t_start;        /* 1000 */
+    int32_t t_end;          /* 5000 */
+    double  std_scale;      /* 0.8  */
+} ora_drna_params;
+int32_t ora_drna_segs(const double *sig, int64_t n, const ora_drna_params *p,
+                      int32_t *segs, int32_t max_segs, double *top);
+
 /* 24-byte hit record shared with the product ABI. */
 typedef struct { double dist; int32_t start, end, n, flags; } ora_hit;
 

@@ -42,6 +42,19 @@ class SegParams(C.Structure):
                    args.stall_len, getattr(args, "lim_low", 0), getattr(args, "lim_hi", 900))
 
 
+class DrnaParams(C.Structure):
+    """sk_drna_params; defaults are the constants hard-coded at dRNA_segmenter.py:80-104."""
+    _fields_ = [("error", C.c_int32), ("no_err_thresh", C.c_int32), ("w", C.c_int32),
+                ("window", C.c_int32), ("seg_dist", C.c_int32), ("t_start", C.c_int32),
+                ("t_end", C.c_int32), ("std_scale", C.c_double), ("lim_low", C.c_int32),
+                ("lim_hi", C.c_int32)]
+
+    def __init__(self, error=5, no_err_thresh=2500, w=1200, window=100, seg_dist=1200, t_start=1000,
+                 t_end=5000, std_scale=0.8, lim_low=0, lim_hi=1200):
+        super().__init__(error, no_err_thresh, w, window, seg_dist, t_start, t_end, std_scale,
+                         lim_low, lim_hi)
+
+
 class Hit(C.Structure):
     _fields_ = [("dist", C.c_double), ("start", C.c_int32), ("end", C.c_int32),
                 ("n", C.c_int32), ("flags", C.c_int32)]
@@ -70,6 +83,7 @@ ABI = {
     "sk_segment_batch_f64": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(SegParams), _vp, _vp, C.c_int32]),
     "sk_segment_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, C.POINTER(SegParams),
                                      _vp, _vp, C.c_int32]),
+    "sk_drna_segment_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32]),
     "sk_motifseq_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, _vp]),
     "sk_motifseq_batch_f64": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,

@@ -109,6 +109,28 @@ def segment_reads_f64(reads, params=None, max_segs=64):
         return [segs[i, :nsegs[i]].tolist() if nsegs[i] else False for i in range(R)]
 
 
+def drna_segment_reads(reads, params=None, max_segs=32):
+    """dRNA_segmenter.py's slow5-branch per-read work (scale_outliers, window statistics, scan)
+    for a list of raw integer reads: per read the list of [start, end] collected before the scan
+    stopped (the script prints only the first, dRNA_segmenter.py:173-176)."""
+    if not len(reads):
+        return []
+    L = _lib.ensure_init()
+    buf, lens = pack_i16(reads)
+    params = params or _lib.DrnaParams()
+    R = len(reads)
+    while True:
+        segs = np.zeros((R, max_segs, 2), dtype=np.int32)
+        nsegs = np.zeros(R, dtype=np.int32)
+        rc = L.sk_drna_segment_batch_i16(ptr(buf), buf.shape[1], ptr(lens), R, C.byref(params),
+                                         ptr(segs), ptr(nsegs), max_segs)
+        if rc == _lib.SK_ERR_OVERFLOW:
+            max_segs = int(nsegs.max()) + 8
+            continue
+        check(rc)
+        return [segs[i, :nsegs[i]].tolist() for i in range(R)]
+
+
 def segment_any(reads, params=None):
     """Route each read to the int16 kernels when it is integer valued and fits,
     else to the float64 kernels; results come back in input order."""

@@ -58,3 +58,33 @@ def to_pA(raw, digitisation, offset, range_):
     range2 = float("{0:.2f}".format(range_))
     raw_unit = range2 / digitisation
     return np.round((np.asarray(raw, dtype=np.int64) + offset) * raw_unit, 2)
+
+
+def read_slow5_ascii(path):
+    """ASCII SLOW5: '#'/'@' header lines, a '#read_id<TAB>...' column line, then one read per
+    line with the raw signal as a comma separated list in the `raw_signal` column."""
+    cols = None
+    with open(path, "rt") as fh:
+        for line in fh:
+            line = line.rstrip("\n")
+            if not line:
+                continue
+            if line.startswith("#read_id"):
+                cols = line[1:].split("\t")
+                continue
+            if line[0] in "#@":
+                continue
+            if cols is None:
+                raise ValueError("SLOW5 column header missing: %s" % path)
+            f = dict(zip(cols, line.split("\t")))
+            sig = np.array(f["raw_signal"].split(","), dtype=np.int64).astype(np.int16)
+            yield {"read_id": f["read_id"], "read_group": int(f.get("read_group", 0)),
+                   "digitisation": float(f["digitisation"]), "offset": float(f["offset"]),
+                   "range": float(f["range"]), "sampling_rate": float(f["sampling_rate"]), "signal": sig}
+
+
+def read_slow5(path):
+    """BLOW5 (binary) or SLOW5 (ASCII), chosen by the file's magic."""
+    with open(path, "rb") as fh:
+        head = fh.read(6)
+    return read_blow5(path) if head == MAGIC else read_slow5_ascii(path)

@@ -410,6 +410,53 @@ int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads, 
     return SK_OK;
 }
 
+// ------------------------------------------------------------------ dRNA adapter segmenter
+int sk_drna_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
+                              const sk_drna_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    int rc = check_i16(sig, stride, len, nreads);
+    if (rc) return rc;
+    if (!p) return sk_fail(SK_ERR_INVALID, "NULL sk_drna_params");
+    if (p->w <= 0) return sk_fail(SK_ERR_INVALID, "w must be positive (the scan takes c %% w)");
+    if (p->t_start < 0 || p->t_end < p->t_start) return sk_fail(SK_ERR_INVALID, "bad statistics window");
+    if (max_segs <= 0) return sk_fail(SK_ERR_INVALID, "max_segs must be positive");
+    if (nreads == 0) return SK_OK;
+    if (!segs || !nsegs) return sk_fail(SK_ERR_INVALID, "NULL segs/nsegs");
+    int32_t lo = p->lim_low, hi = p->lim_hi;
+    clamp_limits(&lo, &hi);
+    const int64_t words = (stride + 63) / 64;
+    const size_t sb = (size_t)nreads * (size_t)stride * sizeof(int16_t);
+    const size_t gb = (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t);
+    if ((rc = sk_reserve(c, &c->sig, sb))) return rc;
+    if ((rc = sk_reserve(c, &c->len, (size_t)nreads * sizeof(int32_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->comp, sb))) return rc;
+    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
+    if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * sizeof(uint64_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->out, gb))) return rc;
+    if ((rc = sk_reserve(c, &c->out2, (size_t)nreads * sizeof(int32_t)))) return rc;
+    SK_HIP(hipMemcpyAsync(c->sig.p, sig, sb, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipMemcpyAsync(c->len.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    rc = sk_launch_prep_i16(c, (const int16_t *)c->sig.p, stride, (const int32_t *)c->len.p, nreads, lo, hi,
+                            SK_PREP_DRNA, p->std_scale, (int16_t *)c->comp.p, (sk_prep *)c->prep.p,
+                            (uint64_t *)c->mask.p, nreads, p->t_start, p->t_end);
+    if (rc) return rc;
+    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+    rc = sk_launch_drna_walk(c, (const uint64_t *)c->mask.p, nreads, (const sk_prep *)c->prep.p, nreads, p,
+                             (int32_t *)c->out.p, (int32_t *)c->out2.p, max_segs);
+    if (rc) return rc;
+    c->ev_valid = true;
+    SK_HIP(hipMemcpyAsync(segs, c->out.p, gb, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipMemcpyAsync(nsegs, c->out2.p, (size_t)nreads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    for (int32_t r = 0; r < nreads; r++)
+        if (nsegs[r] > max_segs)
+            return sk_fail(SK_ERR_OVERFLOW, "read %d has %d segments, max_segs is %d", r, nsegs[r], max_segs);
+    return SK_OK;
+}
+
 // ------------------------------------------------------------------ bench input
 int sk_synth_squiggles_dev(int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
                            uint64_t seed, const double *motif, int32_t nmotif)

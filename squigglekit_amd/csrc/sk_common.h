@@ -22,7 +22,7 @@ struct sk_prep {
     double  bot;      // segmenter: median - std*std_scale   (segmenter.py:414)
 };
 
-enum sk_prep_mode { SK_PREP_MEDMAD = 0, SK_PREP_ZSCALE = 1, SK_PREP_SEGMENT = 2 };
+enum sk_prep_mode { SK_PREP_MEDMAD = 0, SK_PREP_ZSCALE = 1, SK_PREP_SEGMENT = 2, SK_PREP_DRNA = 3 };
 
 // Growable device scratch buffer.
 struct sk_buf {
@@ -75,7 +75,8 @@ int  sk_reserve(sk_ctx *c, sk_buf *b, size_t bytes);
 // comp + r*stride.  mask (segmenter only) gets ceil(stride/64) words per read.
 int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len,
                        int32_t nreads, int32_t lo, int32_t hi, int mode, double std_scale,
-                       int16_t *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_stride);
+                       int16_t *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_stride,
+                       int32_t t0 = 0, int32_t t1 = 0x7fffffff);   // statistics window (filtered index)
 // f64 ragged: read r is sig[off[r]..off[r+1]); comp uses the same offsets.
 int sk_launch_prep_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads,
                        double lo, double hi, int mode, double std_scale,
@@ -103,6 +104,10 @@ struct sk_sdtw_args {
 int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a);
 
 // ---- segment walk (sk_segment.hip) ----
+struct sk_drna_params;
+int sk_launch_drna_walk(sk_ctx *c, const uint64_t *d_mask, int64_t mask_rows, const sk_prep *d_prep,
+                        int32_t nreads, const sk_drna_params *p, int32_t *d_segs, int32_t *d_nsegs,
+                        int32_t max_segs);
 int sk_launch_segment_walk(sk_ctx *c, const uint64_t *d_mask, int64_t mask_stride,
                            const int64_t *d_mask_off, const sk_prep *d_prep, int32_t nreads,
                            const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs,

@@ -202,7 +202,7 @@ __device__ double numpy_sum(int n, Scratch *sc, Term term)
 template <bool LDSCOMP>
 __global__ __launch_bounds__(TPB, 8) __attribute__((amdgpu_num_sgpr(80)))
 void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *__restrict__ len, int nreads,
-                int lo, int hi, int mode, double std_scale, int vec_ok,
+                int lo, int hi, int mode, double std_scale, int vec_ok, int t0, int t1,
                 int16_t *__restrict__ comp, sk_prep *__restrict__ prep,
                 uint64_t *__restrict__ maskT, int64_t mask_rows)
 {
@@ -215,7 +215,7 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     int16_t *lcomp = (int16_t *)(hist + nbins + ndev + ((nbins + ndev) & 1));   // 8-byte aligned
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const bool to_global = !(LDSCOMP && mode == SK_PREP_SEGMENT);
+    const bool to_global = !(LDSCOMP && (mode == SK_PREP_SEGMENT || mode == SK_PREP_DRNA));
 
     // Persistent workgroups: each walks reads r, r + grid, ... and has the first tile of its
     // next read in flight while it does the statistics of the current one.
@@ -274,9 +274,11 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
                 const int x = v[k];
                 if (LDSCOMP) lcomp[o] = (int16_t)x;
                 if (to_global) crow[o] = (int16_t)x;
+                if (o >= t0 && o < t1) {                   // statistics window (whole read unless dRNA)
+                    atomicAdd(&hist[x - lo - 1], 1u);
+                    isum += x;
+                }
                 o++;
-                atomicAdd(&hist[x - lo - 1], 1u);
-                isum += x;
             }
         }
         run += tot;
@@ -302,8 +304,22 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
         continue;
     }
 
-    // ---- median: ranks (n-1)/2 and n/2 of the value histogram -------------------------
-    rank_select2(hist, nbins, (n - 1) / 2, n / 2, sc, 0);
+    // statistics are taken over filtered samples [w0, w0 + ns): everything, or the slice
+    // sig[t_start:t_end] of dRNA_segmenter.py:109-110
+    const int w0 = min(n, t0);
+    const int ns = min(n, t1) - w0;
+    if (ns <= 0) {                                         // empty slice: numpy gives NaN, band is empty
+        const double qnan = __builtin_nan("");
+        pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
+        if (tid == 0) prep[r] = pr;
+        if (maskT != nullptr)
+            for (int wi = tid; wi * 64 < n; wi += TPB) maskT[(int64_t)wi * mask_rows + r] = 0ull;
+        lds_barrier();
+        continue;
+    }
+
+    // ---- median: ranks (ns-1)/2 and ns/2 of the value histogram -----------------------
+    rank_select2(hist, nbins, (ns - 1) / 2, ns / 2, sc, 0);
     const int med2 = (sc->sel[0] + lo + 1) + (sc->sel[1] + lo + 1);    // 2 * median, exact
     const double median = (double)med2 * 0.5;
     lds_barrier();
@@ -315,7 +331,7 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
             if (cb) atomicAdd(&dev[abs(2 * (b + lo + 1) - med2)], cb);
         }
         lds_barrier();
-        rank_select2(dev, ndev, (n - 1) / 2, n / 2, sc, 1);
+        rank_select2(dev, ndev, (ns - 1) / 2, ns / 2, sc, 1);
         const double mad = (double)(sc->sel[0] + sc->sel[1]) * 0.25;   // (d1/2 + d2/2) / 2, exact
         pr.center = median;
         pr.scale = mad * 1.4826;                                       // MotifSeq.py:196
@@ -333,13 +349,13 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     long long S = 0;
 #pragma unroll
     for (int i = 0; i < NWAVE; i++) S += sc->wred[i];
-    const double mean = (double)S / (double)n;
+    const double mean = (double)S / (double)ns;
     const int16_t *src = LDSCOMP ? (const int16_t *)lcomp : (const int16_t *)crow;
-    const double ssq = numpy_sum(n, sc, [&](int i) {
-        const double d = (double)src[i] - mean;
+    const double ssq = numpy_sum(ns, sc, [&](int i) {
+        const double d = (double)src[w0 + i] - mean;
         return d * d;
     });
-    const double sd = sqrt(ssq / (double)n);
+    const double sd = sqrt(ssq / (double)ns);
 
     if (mode == SK_PREP_ZSCALE) {
         pr.center = mean;
@@ -352,7 +368,8 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     // ---- segmenter thresholds + in-band mask (segmenter.py:413-414,431) -----------------
     const double spread = sd * std_scale;
     const double top = median + spread;
-    const double bot = median - spread;
+    // dRNA_segmenter.py:111,114 tests `a < top` only
+    const double bot = (mode == SK_PREP_DRNA) ? -__builtin_huge_val() : median - spread;
     pr.center = median; pr.scale = sd; pr.top = top; pr.bot = bot;
     if (tid == 0) prep[r] = pr;
     for (int base = 0; base < n; base += TPB) {
@@ -576,7 +593,8 @@ void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off,
 
 int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len,
                        int32_t nreads, int32_t lo, int32_t hi, int mode, double std_scale,
-                       int16_t *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_stride)
+                       int16_t *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_stride,
+                       int32_t t0, int32_t t1)
 {
     if (nreads <= 0) return SK_OK;
     const int64_t nbins = (int64_t)hi - (int64_t)lo - 1 > 0 ? (int64_t)hi - lo - 1 : 0;
@@ -607,7 +625,7 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
     long long g = (long long)c->num_cu * per_cu * rounds;
     int grid = g > nreads ? nreads : (int)g;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(TPB), lds, c->stream, d_sig, stride, d_len, nreads,
-                       lo, hi, mode, std_scale, vec_ok, d_comp, d_prep, d_mask, mask_stride);
+                       lo, hi, mode, std_scale, vec_ok, t0, t1, d_comp, d_prep, d_mask, mask_stride);
     SK_HIP(hipGetLastError());
     return SK_OK;
 }

@@ -82,7 +82,77 @@ void k_segment_walk(const uint64_t *__restrict__ maskT, int64_t mask_rows,
     if (live) nsegs[r] = nseg;                    // a segment still open at EOF is dropped (:466)
 }
 
+// dRNA_segmenter.py's slow5-branch scan (dRNA_segmenter.py:112-165): same skeleton, but the
+// error budget is re-armed when a segment opens, errors only count from sample no_err_thresh
+// on, `w` is a constant, and the scan stops ("adapter found") once the signal has been out of
+// band for more than seg_dist samples after the last segment.
+struct DrnaWalk { int error, no_err_thresh, w, window, seg_dist; };
+
+__global__ __launch_bounds__(64)
+void k_drna_walk(const uint64_t *__restrict__ maskT, int64_t mask_rows,
+                 const sk_prep *__restrict__ prep, int nreads, DrnaWalk p,
+                 int32_t *__restrict__ segs, int32_t *__restrict__ nsegs, int max_segs)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nreads) return;
+    const int n = prep[r].n;
+    int32_t *my = segs + (int64_t)r * 2 * max_segs;
+    bool prev = false, done = false;
+    int err = 0, prev_err = 0, c = 0, start = 0, nseg = 0, last_end = 0;
+    for (int wi = 0; wi * 64 < n && !done; wi++) {
+        const uint64_t word = maskT[(int64_t)wi * mask_rows + r];
+        const int lim = min(64, n - wi * 64);
+        for (int b = 0; b < lim; b++) {
+            const int i = wi * 64 + b;
+            if ((word >> b) & 1) {                                         // a < top  (:114)
+                if (!prev) { start = i; prev = true; err = 0; }
+                c++; prev_err = 0;
+                if (c >= p.window && c >= p.w && (c % p.w) == 0) err--;
+            } else if (prev) {
+                if (err < p.error) {                                       // :129
+                    c++;
+                    if (i >= p.no_err_thresh) { err++; prev_err++; }
+                    if (c >= p.window && c >= p.w && (c % p.w) == 0) err--;
+                } else {
+                    if (c >= p.window) {                                   // :137 close
+                        const int end = i - prev_err;
+                        if (nseg > 0 && start - last_end < p.seg_dist) {
+                            if (nseg <= max_segs) my[2 * (nseg - 1) + 1] = end;
+                        } else {
+                            if (nseg < max_segs) { my[2 * nseg] = start; my[2 * nseg + 1] = end; }
+                            nseg++;
+                        }
+                        last_end = end;
+                    }
+                    prev = false; c = 0; err = 0; prev_err = 0;
+                }
+            } else if (nseg > 0 && i - last_end > p.seg_dist) {            // :152 adapter found
+                done = true;
+                break;
+            }
+        }
+    }
+    nsegs[r] = nseg;
+}
+
 } // namespace
+
+int sk_launch_drna_walk(sk_ctx *c, const uint64_t *d_mask, int64_t mask_rows, const sk_prep *d_prep,
+                        int32_t nreads, const sk_drna_params *p, int32_t *d_segs, int32_t *d_nsegs,
+                        int32_t max_segs)
+{
+    if (nreads <= 0) return SK_OK;
+    DrnaWalk wp;
+    wp.error = p->error; wp.no_err_thresh = p->no_err_thresh; wp.w = p->w; wp.window = p->window;
+    wp.seg_dist = p->seg_dist;
+    const int grid = (nreads + 63) / 64;
+    SK_HIP(hipEventRecord(c->ev[2], c->stream));
+    hipLaunchKernelGGL(k_drna_walk, dim3(grid), dim3(64), 0, c->stream, d_mask, mask_rows, d_prep, nreads, wp,
+                       d_segs, d_nsegs, max_segs);
+    SK_HIP(hipGetLastError());
+    SK_HIP(hipEventRecord(c->ev[3], c->stream));
+    return SK_OK;
+}
 
 int sk_launch_segment_walk(sk_ctx *c, const uint64_t *d_mask, int64_t mask_rows,
                            const int64_t *, const sk_prep *d_prep, int32_t nreads,

@@ -88,3 +88,24 @@ def synthetic_motif(n_points, seed=7):
         level = float(np.float32(rng.normal(0.0, 1.1)))
         vals.extend([level] * int(rng.integers(6, 13)))
     return np.asarray(vals[:n_points], dtype=np.float64)
+
+
+def drna_reads(n_reads, seed, min_len=6000, max_len=40000):
+    """Ragged dRNA-like int16 reads for the dRNA adapter segmenter (dRNA_segmenter.py): a low
+    adapter stretch, a tight poly(A) plateau, then an event-level body; a few outlier spikes."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_reads):
+        n = int(rng.integers(min_len, max_len))
+        la = int(rng.integers(1500, 6000))
+        lp = int(rng.integers(300, 3000))
+        body = squiggle_batch(1, max(8, n - la - lp), int(rng.integers(1, 2 ** 31)))[0].astype(np.float64) + 30.0
+        sig = np.concatenate([rng.normal(430.0, 25.0, la), rng.normal(560.0, 8.0, lp), body])[:n]
+        # short excursions above the band inside the adapter (exercise err / prev_err / merging)
+        for _k in range(int(rng.integers(0, 6))):
+            p = int(rng.integers(0, max(1, la - 40)))
+            sig[p:p + int(rng.integers(1, 30))] = 640.0
+        pos = rng.integers(0, sig.size, 6)
+        sig[pos] = SPIKES[rng.integers(0, 4, 6)].astype(np.float64) + rng.integers(0, 2, 6) * 300
+        out.append(np.clip(np.rint(sig), -32768, 32767).astype(np.int16))
+    return out

