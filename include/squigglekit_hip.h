@@ -136,6 +136,12 @@ int sk_drna_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t 
 int sk_motifseq_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
                           const double *motif, int32_t nmotif, int32_t scale_mode,
                           int32_t scale_low, int32_t scale_hi, sk_hit *out);
+/* Several motifs against the same reads -- the `for name in m_order` loop of MotifSeq.py:436:
+ * motif k is motifs[motif_off[k] .. motif_off[k+1]); out is [nmotifs][nreads].  Filter and
+ * statistics run once. */
+int sk_motifseq_multi_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
+                                const double *motifs, const int32_t *motif_off, int32_t nmotifs,
+                                int32_t scale_mode, int32_t scale_low, int32_t scale_hi, sk_hit *out);
 int sk_motifseq_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
                           const double *motif, int32_t nmotif, int32_t scale_mode,
                           int32_t scale_low, int32_t scale_hi, sk_hit *out);

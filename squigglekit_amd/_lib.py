@@ -86,6 +86,8 @@ ABI = {
     "sk_drna_segment_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32]),
     "sk_motifseq_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, _vp]),
+    "sk_motifseq_multi_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,
+                                              C.c_int32, C.c_int32, _vp]),
     "sk_motifseq_batch_f64": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, _vp]),
     "sk_motifseq_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,

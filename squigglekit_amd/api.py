@@ -227,6 +227,34 @@ def motifseq_any(reads, motif, scale="medmad", scale_low=0, scale_hi=1200):
     return out
 
 
+def motifseq_multi(reads, motifs, scale="medmad", scale_low=0, scale_hi=1200):
+    """Every motif of `motifs` (list of float vectors) against every read: list (one per motif,
+    in order) of HIT_DTYPE arrays in read order -- the double loop of MotifSeq.py:261-298,436.
+    Integer reads share one filter/statistics pass across motifs."""
+    L = _lib.ensure_init()
+    motifs = [np.ascontiguousarray(m, dtype=np.float64) for m in motifs]
+    outs = [np.zeros(len(reads), dtype=HIT_DTYPE) for _ in motifs]
+    ints = [i for i, r in enumerate(reads) if is_int16_exact(r)]
+    iset = set(ints)
+    flts = [i for i in range(len(reads)) if i not in iset]
+    if ints and motifs:
+        buf, lens = pack_i16([np.asarray(reads[i]).astype(np.int16) for i in ints])
+        moff = np.zeros(len(motifs) + 1, dtype=np.int32)
+        moff[1:] = np.cumsum([m.size for m in motifs])
+        flat = np.ascontiguousarray(np.concatenate(motifs))
+        res = np.zeros((len(motifs), len(ints)), dtype=HIT_DTYPE)
+        check(L.sk_motifseq_multi_batch_i16(ptr(buf), buf.shape[1], ptr(lens), len(ints), ptr(flat), ptr(moff),
+                                            len(motifs), _lib.SK_SCALE[scale], int(scale_low), int(scale_hi),
+                                            ptr(res)))
+        for k in range(len(motifs)):
+            outs[k][ints] = res[k]
+    if flts:
+        sub = [reads[i] for i in flts]
+        for k, m in enumerate(motifs):
+            outs[k][flts] = motifseq_reads_f64(sub, m, scale, scale_low, scale_hi)
+    return outs
+
+
 def normalise(sig, scale="medmad", scale_low=0, scale_hi=1200):
     """Filtered + normalised signal of one read, as MotifSeq hands it to
     dtw_subsequence (MotifSeq.py:274-289)."""

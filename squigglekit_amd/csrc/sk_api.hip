@@ -111,6 +111,53 @@ int sk_motifseq_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len
     return SK_OK;
 }
 
+// Several motifs against the same reads (the `for name in m_order` loop of MotifSeq.py:436):
+// filter + statistics once, one DTW launch set per motif.  out is [nmotifs][nreads].
+int sk_motifseq_multi_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
+                                const double *motifs, const int32_t *motif_off, int32_t nmotifs,
+                                int32_t scale_mode, int32_t scale_low, int32_t scale_hi, sk_hit *out)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    int rc = check_i16(sig, stride, len, nreads);
+    if (rc) return rc;
+    if (!motifs || !motif_off || nmotifs <= 0) return sk_fail(SK_ERR_INVALID, "no motifs");
+    for (int32_t k = 0; k < nmotifs; k++)
+        if (motif_off[k + 1] <= motif_off[k]) return sk_fail(SK_ERR_INVALID, "motif %d is empty", k);
+    if (scale_mode != SK_SCALE_MEDMAD && scale_mode != SK_SCALE_ZSCALE)
+        return sk_fail(SK_ERR_INVALID, "unknown scale mode %d", scale_mode);
+    if (nreads == 0) return SK_OK;
+    if (!out) return sk_fail(SK_ERR_INVALID, "NULL out");
+    clamp_limits(&scale_low, &scale_hi);
+    const size_t sb = (size_t)nreads * (size_t)stride * sizeof(int16_t);
+    const size_t ob = (size_t)nreads * (size_t)nmotifs * sizeof(sk_hit);
+    if ((rc = sk_reserve(c, &c->sig, sb))) return rc;
+    if ((rc = sk_reserve(c, &c->len, (size_t)nreads * sizeof(int32_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->comp, sb))) return rc;
+    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
+    if ((rc = sk_reserve(c, &c->out, ob))) return rc;
+    SK_HIP(hipMemcpyAsync(c->sig.p, sig, sb, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipMemcpyAsync(c->len.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    rc = sk_launch_prep_i16(c, (const int16_t *)c->sig.p, stride, (const int32_t *)c->len.p, nreads, scale_low,
+                            scale_hi, scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE, 0.0,
+                            (int16_t *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
+    if (rc) return rc;
+    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+    for (int32_t k = 0; k < nmotifs; k++) {
+        sk_sdtw_args a;
+        a.feed = SK_FEED_I16; a.samples = c->comp.p; a.stride = stride; a.off = nullptr;
+        a.prep = (const sk_prep *)c->prep.p; a.nreads = nreads; a.motif = motifs + motif_off[k];
+        a.nmotif = motif_off[k + 1] - motif_off[k]; a.out = (sk_hit *)c->out.p + (size_t)k * nreads;
+        a.last_row = nullptr; a.max_len = stride; a.force_single = 0;
+        if ((rc = sk_launch_sdtw(c, &a))) return rc;
+    }
+    c->ev_valid = true;
+    SK_HIP(hipMemcpyAsync(out, c->out.p, ob, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
+
 // Stage a ragged float64 batch: samples -> c->sig, zero-based offsets -> c->off.
 // Returns the total sample count in *total and the longest read in *maxlen.
 static int stage_ragged_f64(sk_ctx *c, const double *sig, const int64_t *off, int32_t nreads,

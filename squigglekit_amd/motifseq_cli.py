@@ -115,8 +115,8 @@ class _Batcher:
         a = self.args
         live = [i for i, s in enumerate(self.sigs) if s is not None]
         sigs = [self.sigs[i] for i in live]
-        hits = [api.motifseq_any(sigs, np.asarray(self.models[name], dtype=np.float64), a.scale,
-                                 a.scale_low, a.scale_hi) if sigs else [] for name in self.order]
+        hits = (api.motifseq_multi(sigs, [np.asarray(self.models[name], dtype=np.float64) for name in self.order],
+                                   a.scale, a.scale_low, a.scale_hi) if sigs else [[] for _ in self.order])
         slot = {i: k for k, i in enumerate(live)}
         for i, (fast5, read_id) in enumerate(self.meta):
             if self.sigs[i] is None:

@@ -119,6 +119,9 @@ def oracle_backend(monkeypatch, ora):
 
     monkeypatch.setattr(api, "segment_any", seg_any)
     monkeypatch.setattr(api, "motifseq_any", mot_any)
+    monkeypatch.setattr(api, "motifseq_multi",
+                        lambda reads, motifs, scale="medmad", lo=0, hi=1200: [mot_any(reads, m, scale, lo, hi)
+                                                                               for m in motifs])
     monkeypatch.setattr(api, "normalise", norm)
     monkeypatch.setattr(_lib, "init", lambda device=None: 0)
 

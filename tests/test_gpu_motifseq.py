@@ -184,3 +184,20 @@ def test_two_pass_l64_long_motif(gpu, ora):
     got = api.motifseq_batch(sig, lens, motif)
     want = ora.motifseq_batch_i16(sig, lens, motif)
     _assert_hits(got, want, "two-pass L64")
+
+
+def test_multi_motif_batch(gpu, ora, example_model):
+    """Several motifs of different lengths (both kernel families) against the same reads, with a
+    float64 read mixed in: equals the per-motif oracle results, motif-major order."""
+    from squigglekit_amd import api, synth
+    motifs = [example_model, synth.synthetic_motif(40, seed=1), synth.synthetic_motif(300, seed=2), np.array([0.5])]
+    sig = synth.squiggle_batch(24, 3000, 606, motif=example_model)
+    reads = [sig[r] for r in range(24)]
+    reads[5] = np.round((sig[5].astype(np.float64) + 16.0) * 0.1824, 2)        # a pA read
+    outs = api.motifseq_multi(reads, motifs, scale="medmad")
+    assert len(outs) == 4
+    for k, m in enumerate(motifs):
+        for r, x in enumerate(reads):
+            f = ora.scale_outliers(np.asarray(x, float), 0, 1200)
+            d, s, e = ora.dtw_subsequence(m, ora.medmad(f)[0])
+            assert (outs[k]["dist"][r], outs[k]["start"][r], outs[k]["end"][r]) == (d, s, e), (k, r)
