@@ -375,6 +375,8 @@ int sk_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_le
     if ((rc = sk_reserve(c, &c->comp, (size_t)nreads * (size_t)stride * sizeof(int16_t)))) return rc;
     if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
     if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * sizeof(uint64_t)))) return rc;
+    // slots past nsegs[r] read as zero, whatever the buffer held before
+    SK_HIP(hipMemsetAsync(d_segs, 0, (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t), c->stream));
     SK_HIP(hipEventRecord(c->ev[0], c->stream));
     rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nreads, lo, hi, SK_PREP_SEGMENT, p->std_scale,
                             (int16_t *)c->comp.p, (sk_prep *)c->prep.p, (uint64_t *)c->mask.p, nreads);
@@ -438,6 +440,7 @@ int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads, 
     if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * sizeof(uint64_t)))) return rc;
     if ((rc = sk_reserve(c, &c->out, gb))) return rc;
     if ((rc = sk_reserve(c, &c->out2, (size_t)nreads * sizeof(int32_t)))) return rc;
+    SK_HIP(hipMemsetAsync(c->out.p, 0, gb, c->stream));
     SK_HIP(hipEventRecord(c->ev[0], c->stream));
     rc = sk_launch_prep_f64(c, (const double *)c->sig.p, (const int64_t *)c->off.p, nreads, (double)p->lim_low,
                             (double)p->lim_hi, SK_PREP_SEGMENT, p->std_scale, (double *)c->comp.p,
@@ -485,6 +488,7 @@ int sk_drna_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t 
     if ((rc = sk_reserve(c, &c->out2, (size_t)nreads * sizeof(int32_t)))) return rc;
     SK_HIP(hipMemcpyAsync(c->sig.p, sig, sb, hipMemcpyHostToDevice, c->stream));
     SK_HIP(hipMemcpyAsync(c->len.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipMemsetAsync(c->out.p, 0, gb, c->stream));
     SK_HIP(hipEventRecord(c->ev[0], c->stream));
     rc = sk_launch_prep_i16(c, (const int16_t *)c->sig.p, stride, (const int32_t *)c->len.p, nreads, lo, hi,
                             SK_PREP_DRNA, p->std_scale, (int16_t *)c->comp.p, (sk_prep *)c->prep.p,
