@@ -135,7 +135,8 @@ def segment_any(reads, params=None):
     """Route each read to the int16 kernels when it is integer valued and fits,
     else to the float64 kernels; results come back in input order."""
     ints = [i for i, r in enumerate(reads) if is_int16_exact(r)]
-    flts = [i for i in range(len(reads)) if i not in set(ints)]
+    iset = set(ints)
+    flts = [i for i in range(len(reads)) if i not in iset]
     out = [None] * len(reads)
     if ints:
         for i, res in zip(ints, segment_reads([np.asarray(reads[i]).astype(np.int16) for i in ints], params)):
