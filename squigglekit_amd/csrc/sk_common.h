@@ -48,7 +48,10 @@ struct sk_ctx {
     sk_buf out;       // sk_hit / segs staging
     sk_buf out2;      // nsegs staging
     sk_buf misc;
-    sk_buf ckpt;      // DTW pass-A checkpoints (systolic state dumps)
+    sk_buf ckpt;      // DTW checkpoints (systolic state dumps: doubles or fixed-point units)
+    sk_buf motifq;    // fixed-point motif layout
+    sk_buf lastq;     // screening pass: last-row costs per column
+    sk_buf qflag;     // screening pass: per-read "left the fixed-point range" flags
     sk_buf retry;     // DTW pass-B retry counter + read list
     int    last_retry = 0;   // reads that needed the exact single-pass retry in the last DTW call
     std::vector<hipEvent_t> evpool;   // per-launch events of the two-pass DTW (3 per chunk)
@@ -102,6 +105,9 @@ struct sk_sdtw_args {
     int           force_single;// 1: always the single FULL pass
 };
 int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a);
+// fixed-point screening + certified window over all reads (sk_sdtwq.hip); leaves the retry list on the device
+int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P, int ck, int span,
+                          int32_t *d_retry_cnt, int32_t *d_retry);
 
 // ---- segment walk (sk_segment.hip) ----
 struct sk_drna_params;

@@ -35,62 +35,13 @@
 //          restart front carry S = -1; if the optimal path crosses the front the read's start
 //          stays -1 and the read is appended to a retry list (FULL pass on those reads only).
 //          The restart reproduces the state bit for bit, so the result is exact either way.
-#include "sk_common.h"
+#include "sk_sdtw_dev.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
 
 namespace {
-
-constexpr int DPP_ROW_SHR1  = 0x111;   // lane i <- lane i-1 inside a row of 16; lane 0 keeps `old`
-constexpr int DPP_ROW_ROL1  = 0x12F;   // row_ror:15 == rotate left by one inside a row of 16
-constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i <- lane i-1 across the wave; lane 0 keeps `old`
-constexpr int DPP_WAVE_ROL1 = 0x134;   // lane i <- lane i+1 across the wave (rotate)
-
-enum { MODE_FULL = 0, MODE_DIST = 1, MODE_START = 2 };
-
-template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int old, int src)
-{
-    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false);
-}
-
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double old, double src)
-{
-    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xF, 0xF, false);
-    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-
-// min of two non-NaN doubles as ONE v_min_f64 (fmin() would add canonicalising ops in IEEE mode)
-__device__ __forceinline__ double vmin(double a, double b)
-{
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-struct sdtw_kargs {
-    const void    *samples;     // int16 or double samples (filtered)
-    int64_t        stride;      // row stride for FEED_I16
-    const int64_t *off;         // ragged offsets for the f64 feeds
-    const sk_prep *prep;        // n / center / scale per read (not for F64_RAW)
-    int            nreads;      // reads (or entries of ridx) covered by this launch
-    int            read0;       // first read of this launch (chunking); checkpoint slot = r - read0
-    const int32_t *ridx;        // optional indirection: launch slot -> read (retry pass)
-    const double  *xlay;        // motif laid out per lane [L][R]
-    int            P;           // number of short lanes
-    sk_hit        *out;
-    double        *last_row;    // FULL only: cost[-1, :] of read 0
-    double        *ckpt;        // [slot][nck][L][R+3]
-    int            nck;         // checkpoints per read
-    int            ck;          // steps between checkpoints (multiple of L)
-    int            span;        // START: look-back in columns
-    int32_t       *retry;       // START: reads whose path crossed the restart front
-    int32_t       *retry_cnt;
-};
 
 template <int L, int R, int FEED, int MODE>
 __global__ __launch_bounds__(256)
@@ -402,6 +353,30 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     sdtw_fn fb = pick_any(a->feed, L, R, MODE_START);
     sdtw_fn ff = pick_any(a->feed, L, R, MODE_FULL);
     if (!fa || !fb || !ff) return sk_fail(SK_ERR_UNSUPPORTED, "no kernel for L=%d R=%d", L, R);
+
+    // ---- fixed-point screening + certified exact window (sk_sdtwq.hip) ------------------------
+    // needs every motif value inside the fixed-point range; SK_DTW_SCHEME=exact2 keeps the
+    // two exact FP64 passes below (A/B runs).
+    bool qok = true;
+    for (int i = 0; i < N; i++) qok = qok && (fabs(a->motif[i]) < QLIM);
+    if (const char *e = getenv("SK_DTW_SCHEME")) qok = qok && strcmp(e, "exact2") != 0;
+    if (qok) {
+        int rc;
+        if ((rc = sk_reserve(c, &c->retry, ((size_t)a->nreads + 1) * sizeof(int32_t)))) return rc;
+        int32_t *cnt = (int32_t *)c->retry.p;
+        SK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), c->stream));
+        if ((rc = sk_launch_sdtw_screen(c, a, L, R, P, ck, span, cnt, cnt + 1))) return rc;
+        int32_t nretry = 0;
+        SK_HIP(hipMemcpyAsync(&nretry, cnt, sizeof nretry, hipMemcpyDeviceToHost, c->stream));
+        SK_HIP(hipStreamSynchronize(c->stream));
+        c->last_retry = nretry;
+        if (nretry > 0) {                                  // exact single pass on the uncertified reads
+            k.read0 = 0; k.nreads = nretry; k.ridx = cnt + 1;
+            if ((rc = launch(c, ff, k, L))) return rc;
+        }
+        SK_HIP(hipEventRecord(c->ev[3], c->stream));
+        return SK_OK;
+    }
     const int nck = (int)((maxlen + L - 1) / ck);          // checkpoints at steps ck, 2ck, ... <= last step
     const size_t per_read = (size_t)(nck > 0 ? nck : 1) * L * (R + 3) * sizeof(double);
     size_t budget = (size_t)12 << 30;                      // checkpoint scratch per chunk

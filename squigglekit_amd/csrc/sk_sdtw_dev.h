@@ -1,0 +1,73 @@
+// sk_sdtw_dev.h -- device helpers and the kernel argument block shared by the DTW kernels
+// (sk_sdtw.hip: exact FP64 passes; sk_sdtwq.hip: fixed-point screening pass + certified window).
+#pragma once
+#include "sk_common.h"
+
+namespace {
+
+constexpr int DPP_ROW_SHR1  = 0x111;   // lane i <- lane i-1 inside a row of 16; lane 0 keeps `old`
+constexpr int DPP_ROW_ROL1  = 0x12F;   // row_ror:15 == rotate left by one inside a row of 16
+constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i <- lane i-1 across the wave; lane 0 keeps `old`
+constexpr int DPP_WAVE_ROL1 = 0x134;   // lane i <- lane i+1 across the wave (rotate)
+
+enum { MODE_FULL = 0, MODE_DIST = 1, MODE_START = 2 };
+
+// Fixed-point screening (sk_sdtwq.hip): one unit = 2^-22 of a normalised signal unit.
+constexpr int      QS     = 22;
+constexpr double   QSCALE = 4194304.0;          // 2^22
+constexpr double   QUNIT  = 1.0 / 4194304.0;
+constexpr double   QLIM   = 400.0;              // |x|, |y| must stay below this (400 * 2^22 < 2^31)
+constexpr unsigned QINF   = 0xFFFFFFFFu;        // "+inf" cost, and the sample fed outside [0, n)
+constexpr unsigned QSAFE  = 0xF0000000u;        // a minimum at or above this may have saturated
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double old, double src)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xF, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// min of two non-NaN doubles as ONE v_min_f64 (fmin() would add canonicalising ops in IEEE mode)
+__device__ __forceinline__ double vmin(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+struct sdtw_kargs {
+    const void    *samples;     // int16 or double samples (filtered)
+    int64_t        stride;      // row stride for FEED_I16
+    const int64_t *off;         // ragged offsets for the f64 feeds
+    const sk_prep *prep;        // n / center / scale per read (not for F64_RAW)
+    int            nreads;      // reads (or entries of ridx) covered by this launch
+    int            read0;       // first read of this launch (chunking); checkpoint slot = r - read0
+    const int32_t *ridx;        // optional indirection: launch slot -> read (retry pass)
+    const double  *xlay;        // motif laid out per lane [L][R]
+    int            P;           // number of short lanes
+    sk_hit        *out;
+    double        *last_row;    // FULL only: cost[-1, :] of read 0
+    double        *ckpt;        // exact scheme: [slot][nck][L][R+3] doubles
+    int            nck;         // checkpoints per read
+    int            ck;          // steps between checkpoints (multiple of L)
+    int            span;        // START: look-back in columns
+    int32_t       *retry;       // START: reads whose result could not be certified
+    int32_t       *retry_cnt;
+    // fixed-point screening scheme
+    const unsigned *xlayq;      // motif, quantised + biased, laid out per lane [L][R]
+    unsigned      *ckq;         // [slot][nck][L][R+2] unsigned
+    unsigned      *lastq;       // [slot][lq_stride]: screening cost of the last row per column
+    int64_t        lq_stride;
+    int32_t       *qflag;       // [slot]: 1 = a sample left the fixed-point range (|y| >= QLIM)
+    unsigned       qerr;        // E: bound (in units) on |screening cost - exact cost| of any cell
+    int            wmax;        // widest candidate-column range the window pass accepts
+};
+
+} // namespace

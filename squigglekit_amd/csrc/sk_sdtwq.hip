@@ -1,0 +1,453 @@
+// sk_sdtwq.hip -- subsequence DTW by fixed-point screening + a certified exact window.
+//
+// The exact FP64 recurrence costs 16 VALU cycles per cell (28 with start tracking), and it has to
+// be exact: MotifSeq prints the distance with 17 digits and the path's start/end columns
+// (/root/reference/MotifSeq.py:437-449).  But almost all of those cells only serve to show that
+// they do NOT hold the minimum.  So:
+//
+//  pass Q  (k_sdtw_q)   the same wave-systolic sweep in 32-bit fixed point (1 unit = 2^-22):
+//          v_min3_u32 + v_sad_u32(clamp) = 2 instructions, 4 cycles per cell.  Its cost matrix Dq
+//          differs from the exact one by at most E = N + n + 2 units in any cell (each local cost
+//          |q(x)-q(y)| is within one unit of |x-y|, a path has at most N + n cells, FP64 rounding
+//          is 10^-10 of a unit).  It stores the last row and, every CK steps, its systolic state.
+//  pass W  (k_sdtw_w)   per read: columns whose screening cost is within 2E of the screening
+//          minimum are the only ones that can hold the exact minimum [jlo..jhi].  Restart from the
+//          checkpoint `span` columns before jlo with every restored cell set to a LOWER BOUND of
+//          its exact value ((Dq - E) units) and S = -1, run the exact FP64 recurrence with start
+//          tracking up to jhi, take the first exact argmin inside [jlo, jhi].
+//          Certificate: every cell computed from lower bounds is itself a lower bound (the
+//          recurrence is monotone, also after rounding).  If the tie-ordered back-trace of the
+//          winning cell never touches a restored cell (S >= 0), then along it lower bound == exact
+//          value, cell by cell from row 0 up, and every rejected predecessor is rejected in the
+//          exact matrix too -- so distance, end and start are the reference's, bit for bit.
+//          Otherwise (S = -1), or if the range is too wide, a sample left the fixed-point range,
+//          or the minimum may have saturated: the read goes to the retry list.
+//  retry   the exact single pass (k_sdtw FULL) on the listed reads only.
+#include "sk_sdtw_dev.h"
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+__device__ __forceinline__ unsigned sad_clamp(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;                                   // min(|a - b| + c, 2^32 - 1)
+    asm("v_sad_u32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ unsigned min3u(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// One column of R cells: nw[k] = min(|xq[k] - yq| + min3(old[k-1], old[k], nw[k-1]), 2^32-1), with
+// dg standing in for old[-1] and up for nw[-1].  Written as asm blocks of four cells because the
+// compiler has no v_sad_u32 pattern, and because it pads every asm statement boundary with a
+// wait state (it cannot see inside): 4 statements per column instead of 26.
+template <int R>
+__device__ __forceinline__ void qcolumn(const unsigned (&old)[R], unsigned (&nw)[R], const unsigned (&xq)[R],
+                                        unsigned yq, unsigned dg, unsigned up)
+{
+    constexpr int R4 = R & ~3;
+#pragma unroll
+    for (int k = 0; k < R4; k += 4) {
+        asm("v_min3_u32 %0, %12, %4, %13\n\t"
+            "v_sad_u32 %0, %8, %14, %0 clamp\n\t"
+            "v_min3_u32 %1, %4, %5, %0\n\t"
+            "v_sad_u32 %1, %9, %14, %1 clamp\n\t"
+            "v_min3_u32 %2, %5, %6, %1\n\t"
+            "v_sad_u32 %2, %10, %14, %2 clamp\n\t"
+            "v_min3_u32 %3, %6, %7, %2\n\t"
+            "v_sad_u32 %3, %11, %14, %3 clamp"
+            : "=&v"(nw[k]), "=&v"(nw[k + 1]), "=&v"(nw[k + 2]), "=&v"(nw[k + 3])
+            : "v"(old[k]), "v"(old[k + 1]), "v"(old[k + 2]), "v"(old[k + 3]),
+              "v"(xq[k]), "v"(xq[k + 1]), "v"(xq[k + 2]), "v"(xq[k + 3]),
+              "v"(dg), "v"(up), "v"(yq));
+        dg = old[k + 3];
+        up = nw[k + 3];
+    }
+#pragma unroll
+    for (int k = R4; k < R; k++) {
+        asm("v_min3_u32 %0, %3, %1, %4\n\t"
+            "v_sad_u32 %0, %2, %5, %0 clamp"
+            : "=&v"(nw[k])
+            : "v"(old[k]), "v"(xq[k]), "v"(dg), "v"(up), "v"(yq));
+        dg = old[k];
+        up = nw[k];
+    }
+}
+
+// biased fixed-point image of a normalised value, |v| < QLIM
+__device__ __forceinline__ unsigned qimg(double v)
+{
+    return (unsigned)((int)rint(v * QSCALE)) + 0x80000000u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass Q
+// ---------------------------------------------------------------------------------------------
+template <int L, int R, int FEED>
+__global__ __launch_bounds__(256)
+void k_sdtw_q(const sdtw_kargs a)
+{
+    constexpr int G = 64 / L;
+    constexpr int SHR = (L == 16) ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
+    constexpr int ROL = (L == 16) ? DPP_ROW_ROL1 : DPP_WAVE_ROL1;
+    constexpr int CKW = R + 2;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int g = lane / L, l = lane % L;
+    int slot = wave * G + g;
+    const bool live = slot < a.nreads;
+    if (!live) slot = a.nreads - 1;
+    const int r = a.read0 + slot;
+
+    int n;
+    double center = 0.0, scale = 1.0;
+    const int16_t *s16 = nullptr;
+    const double  *s64 = nullptr;
+    if constexpr (FEED == SK_FEED_I16) {
+        const sk_prep pr = a.prep[r];
+        n = pr.n; center = pr.center; scale = pr.scale;
+        s16 = (const int16_t *)a.samples + (int64_t)r * a.stride;
+    } else if constexpr (FEED == SK_FEED_F64_NORM) {
+        const sk_prep pr = a.prep[r];
+        n = pr.n; center = pr.center; scale = pr.scale;
+        s64 = (const double *)a.samples + a.off[r];
+    } else {
+        n = (int)(a.off[r + 1] - a.off[r]);
+        s64 = (const double *)a.samples + a.off[r];
+    }
+    if (!live) n = 0;
+
+    int nsteps = (n > 0) ? n - 1 + L : 0;
+#pragma unroll
+    for (int d = L; d < 64; d <<= 1) nsteps = max(nsteps, __shfl_xor(nsteps, d));
+    nsteps = __builtin_amdgcn_readfirstlane(nsteps);
+    const int nblk = (nsteps + L - 1) / L;
+
+    unsigned xq[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) xq[k] = a.xlayq[l * R + k];
+    const bool shortlane = l < a.P;
+
+    unsigned Da[R], Db[R];                          // ping-pong: a column reads one, writes the other
+#pragma unroll
+    for (int k = 0; k < R; k++) { Da[k] = QINF; Db[k] = QINF; }
+    unsigned botq = (R == 1 && l == 0 && shortlane) ? 0u : QINF;
+    unsigned diagq = (l == 0) ? 0u : QINF;
+    unsigned yq = QINF;
+    int bad = 0;
+
+    auto fetchq = [&](int idx) -> unsigned {
+        if (idx >= n) return QINF;
+        double v;
+        if constexpr (FEED == SK_FEED_I16)           v = ((double)s16[idx] - center) / scale;
+        else if constexpr (FEED == SK_FEED_F64_NORM) v = (s64[idx] - center) / scale;
+        else                                         v = s64[idx];
+        const bool ok = fabs(v) < QLIM;              // false for NaN / inf too
+        bad |= ok ? 0 : 1;
+        return ok ? qimg(v) : QINF;
+    };
+
+    unsigned *lastq = a.lastq + (int64_t)(r - a.read0) * a.lq_stride;
+    unsigned F = fetchq(l);
+    // one step: shift the sample and lane l-1's bottom row in, run the column old -> nw
+    auto step = [&](const unsigned (&old)[R], unsigned (&nw)[R], int t) {
+        yq = (unsigned)dpp_i32<SHR>((int)F, (int)yq);
+        F = (unsigned)dpp_i32<ROL>((int)F, (int)F);
+        const unsigned upq = (unsigned)dpp_i32<SHR>(0, (int)botq);
+        qcolumn<R>(old, nw, xq, yq, diagq, upq);
+        diagq = upq;
+        if constexpr (R >= 2) botq = shortlane ? nw[R - 2] : nw[R - 1];
+        else                  botq = shortlane ? upq : nw[0];
+        const int j = t - l;
+        if (l == L - 1 && j >= 0 && j < n) lastq[j] = nw[R - 1];
+    };
+    for (int blk = 0; blk < nblk; blk++) {
+        const unsigned Fnext = fetchq((blk + 1) * L + l);
+        const int t0 = blk * L;
+        if (t0 > 0 && (t0 % a.ck) == 0 && t0 / a.ck <= a.nck && live) {
+            unsigned *cp = a.ckq + (((int64_t)(r - a.read0) * a.nck + (t0 / a.ck - 1)) * L + l) * CKW;
+#pragma unroll
+            for (int k = 0; k < R; k++) cp[k] = Da[k];
+            cp[R] = botq; cp[R + 1] = diagq;
+        }
+#pragma unroll 1
+        for (int q = 0; q < L; q += 2) {            // L is even: after two steps the roles are back
+            step(Da, Db, t0 + q);
+            step(Db, Da, t0 + q + 1);
+        }
+        F = Fnext;
+    }
+    // a sample outside the fixed-point range anywhere in the read disqualifies the screening
+#pragma unroll
+    for (int d = 1; d < L; d <<= 1) bad |= __shfl_xor(bad, d);
+    if (live && l == 0) a.qflag[r - a.read0] = bad;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass W
+// ---------------------------------------------------------------------------------------------
+template <int L, int R, int FEED>
+__global__ __launch_bounds__(256)
+void k_sdtw_w(const sdtw_kargs a)
+{
+    constexpr int G = 64 / L;
+    constexpr int SHR = (L == 16) ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
+    constexpr int ROL = (L == 16) ? DPP_ROW_ROL1 : DPP_WAVE_ROL1;
+    constexpr int CKW = R + 2;
+    const double INF = __builtin_huge_val();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int g = lane / L, l = lane % L;
+    int slot = wave * G + g;
+    const bool live = slot < a.nreads;
+    if (!live) slot = a.nreads - 1;
+    const int r = a.read0 + slot;
+
+    int n, flags = 0;
+    double center = 0.0, scale = 1.0;
+    const int16_t *s16 = nullptr;
+    const double  *s64 = nullptr;
+    if constexpr (FEED == SK_FEED_I16) {
+        const sk_prep pr = a.prep[r];
+        n = pr.n; flags = pr.flags; center = pr.center; scale = pr.scale;
+        s16 = (const int16_t *)a.samples + (int64_t)r * a.stride;
+    } else if constexpr (FEED == SK_FEED_F64_NORM) {
+        const sk_prep pr = a.prep[r];
+        n = pr.n; flags = pr.flags; center = pr.center; scale = pr.scale;
+        s64 = (const double *)a.samples + a.off[r];
+    } else {
+        n = (int)(a.off[r + 1] - a.off[r]);
+        if (n == 0) flags = SK_FLAG_EMPTY;
+        s64 = (const double *)a.samples + a.off[r];
+    }
+    if (!live) n = 0;
+
+    // ---- candidate columns: screening cost within 2E of the screening minimum ----------------
+    const unsigned *lastq = a.lastq + (int64_t)(r - a.read0) * a.lq_stride;
+    unsigned b = QINF;
+    for (int j = l; j < n; j += L) b = min(b, lastq[j]);
+#pragma unroll
+    for (int d = 1; d < L; d <<= 1) b = min(b, (unsigned)__shfl_xor((int)b, d));
+    const unsigned thr = (b > QINF - 2u * a.qerr) ? QINF : b + 2u * a.qerr;
+    int jlo = 0x7fffffff, jhi = -1;
+    for (int j = l; j < n; j += L)
+        if (lastq[j] <= thr) { jlo = min(jlo, j); jhi = max(jhi, j); }
+#pragma unroll
+    for (int d = 1; d < L; d <<= 1) { jlo = min(jlo, __shfl_xor(jlo, d)); jhi = max(jhi, __shfl_xor(jhi, d)); }
+    const bool screened = (n > 0) && (a.qflag[r - a.read0] == 0) && (b < QSAFE) && (jhi >= jlo) &&
+                          (jhi - jlo <= a.wmax);
+
+    int tbase = 0, tlast = -1, c0 = 0;
+    if (screened) {
+        c0 = max(0, jlo - a.span) / a.ck;
+        if (c0 > a.nck) c0 = a.nck;
+        tbase = c0 * a.ck;
+        tlast = jhi + L - 1;
+    }
+    int nsteps = tlast - tbase + 1;
+    if (nsteps < 0) nsteps = 0;
+#pragma unroll
+    for (int d = L; d < 64; d <<= 1) nsteps = max(nsteps, __shfl_xor(nsteps, d));
+    nsteps = __builtin_amdgcn_readfirstlane(nsteps);
+    const int nblk = (nsteps + L - 1) / L;
+
+    double x[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) x[k] = a.xlay[l * R + k];
+    const bool shortlane = l < a.P;
+
+    auto fetch = [&](int idx) -> double {
+        if (idx < 0 || idx >= n) return INF;
+        if constexpr (FEED == SK_FEED_I16)           return ((double)s16[idx] - center) / scale;
+        else if constexpr (FEED == SK_FEED_F64_NORM) return (s64[idx] - center) / scale;
+        else                                         return s64[idx];
+    };
+    // lower bound (in signal units) of a cell whose screening cost is q
+    auto lb = [&](unsigned q) -> double { return (double)(q > a.qerr ? q - a.qerr : 0u) * QUNIT; };
+
+    double D[R];
+    int    S[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) { D[k] = INF; S[k] = -1; }
+    double botD = (R == 1 && l == 0 && shortlane) ? 0.0 : INF;
+    int    botS = (R == 1 && l == 0 && shortlane) ? 0 : -1;
+    double diagD = (l == 0) ? 0.0 : INF;
+    int    diagS = (l == 0) ? tbase : -1;
+    double y = INF;
+    if (c0 > 0) {
+        const unsigned *cp = a.ckq + (((int64_t)(r - a.read0) * a.nck + (c0 - 1)) * L + l) * CKW;
+#pragma unroll
+        for (int k = 0; k < R; k++) D[k] = lb(cp[k]);
+        botD = lb(cp[R]);
+        if (l > 0) diagD = lb(cp[R + 1]);           // lane 0's diag is the virtual row: exactly 0
+        if (R == 1 && l == 0 && shortlane) { botD = 0.0; botS = tbase; }   // forwards the virtual row
+        y = fetch(tbase - 1 - l);                   // the sample this lane held after step tbase-1
+    }
+    double best = INF;  int bestS = -1, bestJ = -1;
+
+    double F = fetch(tbase + l);
+    for (int blk = 0; blk < nblk; blk++) {
+        const double Fnext = fetch(tbase + (blk + 1) * L + l);
+#pragma unroll 2
+        for (int q = 0; q < L; q++) {
+            const int t = tbase + blk * L + q;
+            y = dpp_f64<SHR>(F, y);
+            F = dpp_f64<ROL>(F, F);
+            const double upD = dpp_f64<SHR>(0.0, botD);
+            const int    upS = dpp_i32<SHR>(t + 1, botS);
+            double dgD = diagD;  int dgS = diagS;
+            double uD = upD;     int uS = upS;
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const double lfD = D[k];  const int lfS = S[k];
+                const double c = fabs(x[k] - y);
+                const bool lt1 = lfD < dgD;
+                const double m1 = lt1 ? lfD : dgD;
+                const int    s1 = lt1 ? lfS : dgS;
+                const bool lt2 = uD < m1;
+                const double m = lt2 ? uD : m1;
+                const int    s = lt2 ? uS : s1;
+                const double nd = c + m;
+                dgD = lfD;  dgS = lfS;
+                D[k] = nd;  S[k] = s;
+                uD = nd;    uS = s;
+            }
+            diagD = upD;  diagS = upS;
+            if constexpr (R >= 2) {
+                botD = shortlane ? D[R - 2] : D[R - 1];
+                botS = shortlane ? S[R - 2] : S[R - 1];
+            } else {
+                botD = shortlane ? upD : D[0];
+                botS = shortlane ? upS : S[0];
+            }
+            const int j = t - l;
+            if (j >= jlo && j <= jhi && D[R - 1] < best) { best = D[R - 1]; bestS = S[R - 1]; bestJ = j; }
+        }
+        F = Fnext;
+    }
+
+    if (live && l == L - 1) {
+        sk_hit h;
+        h.n = n; h.flags = flags;
+        if (n <= 0) {
+            h.dist = __builtin_nan(""); h.start = -1; h.end = -1;
+            a.out[r] = h;
+        } else if (screened && bestS >= 0) {
+            h.dist = best; h.start = bestS; h.end = bestJ;
+            a.out[r] = h;
+        } else {
+            h.dist = __builtin_nan(""); h.start = -1; h.end = -1;    // overwritten by the retry pass
+            a.out[r] = h;
+            a.retry[atomicAdd(a.retry_cnt, 1)] = r;
+        }
+    }
+}
+
+typedef void (*sdtw_fn)(const sdtw_kargs);
+
+template <int L, int FEED, int WHICH>
+sdtw_fn pick_r(int R)
+{
+    switch (R) {
+#define SK_CASE(RR) case RR: return WHICH == 0 ? (sdtw_fn)k_sdtw_q<L, RR, FEED> : (sdtw_fn)k_sdtw_w<L, RR, FEED>;
+        SK_CASE(1) SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5) SK_CASE(6) SK_CASE(7) SK_CASE(8)
+        SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16)
+#undef SK_CASE
+    }
+    return nullptr;
+}
+
+template <int WHICH>
+sdtw_fn pick(int feed, int L, int R)
+{
+    if (L == 16) {
+        if (feed == SK_FEED_I16) return pick_r<16, SK_FEED_I16, WHICH>(R);
+        if (feed == SK_FEED_F64_NORM) return pick_r<16, SK_FEED_F64_NORM, WHICH>(R);
+        return pick_r<16, SK_FEED_F64_RAW, WHICH>(R);
+    }
+    if (feed == SK_FEED_I16) return pick_r<64, SK_FEED_I16, WHICH>(R);
+    if (feed == SK_FEED_F64_NORM) return pick_r<64, SK_FEED_F64_NORM, WHICH>(R);
+    return pick_r<64, SK_FEED_F64_RAW, WHICH>(R);
+}
+
+} // namespace
+
+// Screening + certified window over all reads; fills out[] and the retry list (device).
+// The caller (sk_launch_sdtw) reads the retry count and runs the exact pass on those reads.
+int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P, int ck, int span,
+                          int32_t *d_retry_cnt, int32_t *d_retry)
+{
+    const int N = a->nmotif;
+    // quantised motif in the same per-lane layout as the exact one
+    std::vector<unsigned> layq((size_t)L * R, 0x80000000u);
+    int row = 0;
+    for (int l = 0; l < L; l++) {
+        const int cnt = (l < P) ? R - 1 : R;
+        for (int k = 0; k < cnt; k++)
+            layq[(size_t)l * R + k] = (unsigned)((int)rint(a->motif[row++] * QSCALE)) + 0x80000000u;
+    }
+    int rc;
+    if ((rc = sk_reserve(c, &c->motifq, layq.size() * sizeof(unsigned)))) return rc;
+    SK_HIP(hipMemcpyAsync(c->motifq.p, layq.data(), layq.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));            // layq is a local
+
+    const int64_t maxlen = a->max_len;
+    const int nck = (int)((maxlen + L - 1) / ck);
+    const size_t lq_stride = (size_t)((maxlen + 3) & ~(int64_t)3);
+    const size_t per_read = (size_t)(nck > 0 ? nck : 1) * L * (R + 2) * sizeof(unsigned) +
+                            lq_stride * sizeof(unsigned) + sizeof(int32_t);
+    const size_t budget = (size_t)12 << 30;
+    int64_t chunk = (int64_t)(budget / per_read);
+    if (chunk > a->nreads) chunk = a->nreads;
+    if (chunk < 1024) chunk = 1024 < a->nreads ? 1024 : a->nreads;
+    if ((rc = sk_reserve(c, &c->ckpt, (size_t)chunk * (size_t)(nck > 0 ? nck : 1) * L * (R + 2) * sizeof(unsigned)))) return rc;
+    if ((rc = sk_reserve(c, &c->lastq, (size_t)chunk * lq_stride * sizeof(unsigned)))) return rc;
+    if ((rc = sk_reserve(c, &c->qflag, (size_t)chunk * sizeof(int32_t)))) return rc;
+
+    sdtw_fn fq = pick<0>(a->feed, L, R), fw = pick<1>(a->feed, L, R);
+    if (!fq || !fw) return sk_fail(SK_ERR_UNSUPPORTED, "no screening kernel for L=%d R=%d", L, R);
+
+    sdtw_kargs k;
+    memset(&k, 0, sizeof k);
+    k.samples = a->samples; k.stride = a->stride; k.off = a->off; k.prep = a->prep;
+    k.xlay = (const double *)c->motif.p; k.xlayq = (const unsigned *)c->motifq.p; k.P = P; k.out = a->out;
+    k.nck = nck; k.ck = ck; k.span = span; k.retry = d_retry; k.retry_cnt = d_retry_cnt;
+    k.ckq = (unsigned *)c->ckpt.p; k.lastq = (unsigned *)c->lastq.p; k.lq_stride = (int64_t)lq_stride;
+    k.qflag = (int32_t *)c->qflag.p;
+    k.qerr = (unsigned)(N + maxlen + 2);
+    k.wmax = 4 * ck;
+
+    const size_t nchunks = (size_t)((a->nreads + chunk - 1) / chunk);
+    while (c->evpool.size() < 3 * nchunks) {
+        hipEvent_t e;
+        SK_HIP(hipEventCreate(&e));
+        c->evpool.push_back(e);
+    }
+    c->prof_chunks = 0;
+    const int reads_per_block = 4 * (64 / L);
+    for (int64_t r0 = 0; r0 < a->nreads; r0 += chunk) {
+        k.read0 = (int)r0;
+        k.nreads = (int)((a->nreads - r0 < chunk) ? a->nreads - r0 : chunk);
+        const int grid = (k.nreads + reads_per_block - 1) / reads_per_block;
+        hipEvent_t *ev = &c->evpool[3 * (size_t)c->prof_chunks];
+        SK_HIP(hipEventRecord(ev[0], c->stream));
+        hipLaunchKernelGGL(fq, dim3(grid), dim3(256), 0, c->stream, k);
+        SK_HIP(hipGetLastError());
+        SK_HIP(hipEventRecord(ev[1], c->stream));
+        hipLaunchKernelGGL(fw, dim3(grid), dim3(256), 0, c->stream, k);
+        SK_HIP(hipGetLastError());
+        SK_HIP(hipEventRecord(ev[2], c->stream));
+        c->prof_reads[c->prof_chunks < 64 ? c->prof_chunks : 63] = k.nreads;
+        c->prof_chunks++;
+    }
+    return SK_OK;
+}
