@@ -233,14 +233,30 @@ void k_sdtw_w(const sdtw_kargs a)
 
     // ---- candidate columns: screening cost within 2E of the screening minimum ----------------
     const unsigned *lastq = a.lastq + (int64_t)(r - a.read0) * a.lq_stride;
+    // (rows are 16-byte aligned and padded to a multiple of 4 columns: four columns per load)
+    const uint4 *lq4 = (const uint4 *)lastq;
+    const int n4 = (n + 3) >> 2;
     unsigned b = QINF;
-    for (int j = l; j < n; j += L) b = min(b, lastq[j]);
+    for (int q4 = l; q4 < n4; q4 += L) {
+        const uint4 v = lq4[q4];
+        const int j = q4 * 4;
+        b = min(b, v.x);
+        if (j + 1 < n) b = min(b, v.y);
+        if (j + 2 < n) b = min(b, v.z);
+        if (j + 3 < n) b = min(b, v.w);
+    }
 #pragma unroll
     for (int d = 1; d < L; d <<= 1) b = min(b, (unsigned)__shfl_xor((int)b, d));
     const unsigned thr = (b > QINF - 2u * a.qerr) ? QINF : b + 2u * a.qerr;
     int jlo = 0x7fffffff, jhi = -1;
-    for (int j = l; j < n; j += L)
-        if (lastq[j] <= thr) { jlo = min(jlo, j); jhi = max(jhi, j); }
+    for (int q4 = l; q4 < n4; q4 += L) {
+        const uint4 v = lq4[q4];
+        const int j = q4 * 4;
+        if (v.x <= thr) { jlo = min(jlo, j); jhi = max(jhi, j); }
+        if (j + 1 < n && v.y <= thr) { jlo = min(jlo, j + 1); jhi = max(jhi, j + 1); }
+        if (j + 2 < n && v.z <= thr) { jlo = min(jlo, j + 2); jhi = max(jhi, j + 2); }
+        if (j + 3 < n && v.w <= thr) { jlo = min(jlo, j + 3); jhi = max(jhi, j + 3); }
+    }
 #pragma unroll
     for (int d = 1; d < L; d <<= 1) { jlo = min(jlo, __shfl_xor(jlo, d)); jhi = max(jhi, __shfl_xor(jhi, d)); }
     const bool screened = (n > 0) && (a.qflag[r - a.read0] == 0) && (b < QSAFE) && (jhi >= jlo) &&
