@@ -201,3 +201,71 @@ def test_multi_motif_batch(gpu, ora, example_model):
             f = ora.scale_outliers(np.asarray(x, float), 0, 1200)
             d, s, e = ora.dtw_subsequence(m, ora.medmad(f)[0])
             assert (outs[k]["dist"][r], outs[k]["start"][r], outs[k]["end"][r]) == (d, s, e), (k, r)
+
+
+def test_screening_scheme_adversarial(gpu, ora):
+    """The default DTW scheme screens in 32-bit fixed point and certifies an exact window; these
+    inputs aim at its corners: exact and near ties between far-apart columns (two copies of the
+    motif, one perturbed by 1e-7 or by nothing), values at the edge of / beyond the fixed-point
+    range, constant and tiny reads, costs large enough to saturate.  Everything must equal the
+    oracle bit for bit (the scheme falls back to the exact pass whenever it cannot certify)."""
+    from squigglekit_amd import api
+    L = gpu.load()
+    rng = np.random.default_rng(2024)
+    motif = np.round(rng.normal(0, 1.0, 120), 3)
+    ys = []
+    for r in range(288):
+        n = 2700 + (r % 5) * 13
+        y = rng.normal(0.0, 1.3, n)
+        kind = r % 12
+        if kind == 0:                                   # two exact copies: exact tie, first column wins
+            y[200:320] = motif
+            y[1800:1920] = motif
+        elif kind == 1:                                 # second copy better by 1e-7
+            y[300:420] = motif
+            y[300] += 1e-7
+            y[2000:2120] = motif
+        elif kind == 2:                                 # first copy better by 1e-9 (below one fixed-point unit)
+            y[2000:2120] = motif
+            y[2000] += 1e-9
+            y[400:520] = motif
+        elif kind == 3:                                 # samples at the edge of the fixed-point range
+            y[::97] = 399.9999
+            y[50::101] = -399.9999
+        elif kind == 4:                                 # samples beyond it -> exact fallback
+            y[1234] = 1.0e6
+            y[77] = -401.0
+        elif kind == 5:                                 # huge costs everywhere (saturation)
+            y += 350.0
+        elif kind == 6:                                 # constant read
+            y[:] = 0.25
+        elif kind == 7:                                 # integer-valued, tie heavy
+            y = rng.integers(-2, 3, n).astype(float)
+        elif kind == 8:                                 # tiny read inside a big batch
+            y = y[:int(rng.integers(1, 40))]
+        ys.append(y)
+    for q in (motif, np.round(motif)):                  # second query: integers -> ties with kind 7
+        got = api.dtw_subsequence_batch(q, ys)
+        for r, y in enumerate(ys):
+            d, s, e = ora.dtw_subsequence(q, y)
+            assert (got["dist"][r], got["start"][r], got["end"][r]) == (d, s, e), (r, r % 12)
+    assert L.sk_last_dtw_retries() > 0                  # some of these must have taken the fallback
+
+
+def test_exact_two_pass_scheme_still_exact(gpu, ora, monkeypatch):
+    """Motif values outside the fixed-point range (and SK_DTW_SCHEME=exact2) select the exact FP64
+    two-pass scheme (distance pass + checkpointed start pass); it must agree with the oracle too."""
+    from squigglekit_amd import api
+    rng = np.random.default_rng(77)
+    motif = rng.normal(0, 1.0, 150)
+    ys = [rng.normal(0.0, 1.2, 2900 + (r % 7)) for r in range(264)]
+    for r in range(0, 264, 3):
+        ys[r][500:650] = motif
+    big = motif * 1000.0                                   # |x| >= 400: screening is not applicable
+    got = api.dtw_subsequence_batch(big, [y * 1000.0 for y in ys])
+    for r in range(0, 264, 11):
+        assert (got["dist"][r], got["start"][r], got["end"][r]) == ora.dtw_subsequence(big, ys[r] * 1000.0)
+    monkeypatch.setenv("SK_DTW_SCHEME", "exact2")
+    got = api.dtw_subsequence_batch(motif, ys)
+    for r in range(0, 264, 7):
+        assert (got["dist"][r], got["start"][r], got["end"][r]) == ora.dtw_subsequence(motif, ys[r])
