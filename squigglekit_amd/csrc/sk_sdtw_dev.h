@@ -8,6 +8,8 @@ namespace {
 constexpr int DPP_ROW_SHR1  = 0x111;   // lane i <- lane i-1 inside a row of 16; lane 0 keeps `old`
 constexpr int DPP_ROW_ROL1  = 0x12F;   // row_ror:15 == rotate left by one inside a row of 16
 constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i <- lane i-1 across the wave; lane 0 keeps `old`
+constexpr int DPP_ROW_SHL1  = 0x101;   // lane i <- lane i+1 inside a row of 16; lane 15 keeps `old`
+constexpr int DPP_WAVE_SHL1 = 0x130;   // lane i <- lane i+1 across the wave; lane 63 keeps `old`
 constexpr int DPP_WAVE_ROL1 = 0x134;   // lane i <- lane i+1 across the wave (rotate)
 
 enum { MODE_FULL = 0, MODE_DIST = 1, MODE_START = 2 };

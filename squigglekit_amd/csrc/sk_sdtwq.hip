@@ -97,6 +97,7 @@ void k_sdtw_q(const sdtw_kargs a)
     constexpr int G = 64 / L;
     constexpr int SHR = (L == 16) ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
     constexpr int ROL = (L == 16) ? DPP_ROW_ROL1 : DPP_WAVE_ROL1;
+    constexpr int SHL = (L == 16) ? DPP_ROW_SHL1 : DPP_WAVE_SHL1;
     constexpr int CKW = R + 2;
 
     const int lane = threadIdx.x & 63;
@@ -145,35 +146,45 @@ void k_sdtw_q(const sdtw_kargs a)
     unsigned yq = QINF;
     int bad = 0;
 
-    auto fetchq = [&](int idx) -> unsigned {
+    // the sample feed in two halves, so that the load for the next block is in flight during this
+    // block's L steps and only converted afterwards
+    // (unconditional load from a clamped index: a load under a branch is waited for at the join)
+    const int nlast = max(n - 1, 0);
+    if (n == 0) { s16 = (const int16_t *)a.xlayq; s64 = (const double *)a.xlayq; }   // any valid address
+    auto loadraw = [&](int idx) {
+        if constexpr (FEED == SK_FEED_I16) return (int)s16[min(idx, nlast)];
+        else                               return s64[min(idx, nlast)];
+    };
+    auto toq = [&](auto raw_, int idx) -> unsigned {
         if (idx >= n) return QINF;
-        double v;
+        const double raw = (double)raw_;
+        double v = raw;
         // screening only: (x - c) * (1/s) instead of the reference's division -- the two differ by
         // < 1e-6 of a fixed-point unit, covered by the slack in E (pass W divides, exactly)
-        if constexpr (FEED == SK_FEED_I16)           v = ((double)s16[idx] - center) * inv_scale;
-        else if constexpr (FEED == SK_FEED_F64_NORM) v = (s64[idx] - center) * inv_scale;
-        else                                         v = s64[idx];
+        if constexpr (FEED != SK_FEED_F64_RAW) v = (raw - center) * inv_scale;
         const bool ok = fabs(v) < QLIM;              // false for NaN / inf too
         bad |= ok ? 0 : 1;
         return ok ? qimg(v) : QINF;
     };
 
     unsigned *lastq = a.lastq + (int64_t)(r - a.read0) * a.lq_stride;
-    unsigned F = fetchq(l);
+    unsigned F = toq(loadraw(l), l);
+    unsigned H = 0;                                 // last-row values of this block, one per lane
     // one step: shift the sample and lane l-1's bottom row in, run the column old -> nw
-    auto step = [&](const unsigned (&old)[R], unsigned (&nw)[R], int t) {
+    auto step = [&](const unsigned (&old)[R], unsigned (&nw)[R]) {
         yq = (unsigned)dpp_i32<SHR>((int)F, (int)yq);
         F = (unsigned)dpp_i32<ROL>((int)F, (int)F);
-        const unsigned upq = (unsigned)dpp_i32<SHR>(0, (int)botq);
+        const unsigned upq = (unsigned)__builtin_amdgcn_update_dpp(0, (int)botq, SHR, 0xF, 0xF, true);
         qcolumn<R>(old, nw, xq, yq, diagq, upq);
         diagq = upq;
         if constexpr (R >= 2) botq = shortlane ? nw[R - 2] : nw[R - 1];
         else                  botq = shortlane ? upq : nw[0];
-        const int j = t - l;
-        if (l == L - 1 && j >= 0 && j < n) lastq[j] = nw[R - 1];
+        // lane L-1 produces one last-row value per step: shift them towards lane 0, so that after
+        // the L steps of a block lane i holds the value of step t0 + i (one coalesced store)
+        H = (unsigned)dpp_i32<SHL>((int)nw[R - 1], (int)H);
     };
     for (int blk = 0; blk < nblk; blk++) {
-        const unsigned Fnext = fetchq((blk + 1) * L + l);
+        const auto rawnext = loadraw((blk + 1) * L + l);
         const int t0 = blk * L;
         if (t0 > 0 && (t0 % a.ck) == 0 && t0 / a.ck <= a.nck && live) {
             unsigned *cp = a.ckq + (((int64_t)(r - a.read0) * a.nck + (t0 / a.ck - 1)) * L + l) * CKW;
@@ -183,10 +194,12 @@ void k_sdtw_q(const sdtw_kargs a)
         }
 #pragma unroll 1
         for (int q = 0; q < L; q += 2) {            // L is even: after two steps the roles are back
-            step(Da, Db, t0 + q);
-            step(Db, Da, t0 + q + 1);
+            step(Da, Db);
+            step(Db, Da);
         }
-        F = Fnext;
+        F = toq(rawnext, (blk + 1) * L + l);
+        const int j = t0 + l - (L - 1);             // lane L-1's column at step t0 + l
+        if (j >= 0 && j < n) lastq[j] = H;
     }
     // a sample outside the fixed-point range anywhere in the read disqualifies the screening
 #pragma unroll
