@@ -34,6 +34,12 @@ struct Scratch {
     int       sel[4];                 // rank-select results
     double    node_sum[MAX_NODES];    // pairwise-tree partial sums, heap order (node 1 = chunk)
     double    bcast[2];
+    // numpy's pairwise split tree of a chunk of tree_m elements, heap order: start << 16 | len,
+    // 0 = no such node.  Built by wave 0 and kept across reads (a persistent workgroup mostly
+    // sees one or two distinct lengths).
+    unsigned  tab[MAX_NODES];
+    unsigned short leaf[MAX_NODES / 2];   // heap ids of the leaves (len <= PW_BLOCK), any order
+    int       tree_m, tree_depth, nleaf;
 };
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would
@@ -96,28 +102,38 @@ __device__ void rank_select2(const unsigned *hist, int nbins, int k1, int k2, Sc
     lds_barrier();
 }
 
-// numpy's pairwise split tree of a chunk of m elements, addressed without storing it: walk
-// from the root along `bits` (MSB first, nbits of them); a node longer than PW_BLOCK splits at
-// n2 = (len/2) rounded down to a multiple of 8.  With stop_at_leaf the walk ends at the first
-// leaf and succeeds only for the canonical path (remaining bits zero) -- that enumerates every
-// leaf exactly once over the 2^7 possible paths; without it the walk fails if the node does
-// not exist.  id is the heap index (root 1, children 2id, 2id+1).
-__device__ __forceinline__ bool tree_node(int m, unsigned bits, int nbits, bool stop_at_leaf,
-                                          int &start, int &len, int &id)
+// numpy's pairwise split tree of a chunk of m elements (8 <= m <= 8192): a node longer than
+// PW_BLOCK splits at n2 = (len/2) rounded down to a multiple of 8, at most 7 levels deep.  Wave 0
+// fills sc->tab level by level (children from parents) and lists the leaves.
+__device__ void build_tree(int m, Scratch *sc)
 {
-    start = 0; len = m; id = 1;
-    for (int b = nbits - 1; b >= 0; b--) {
-        if (len <= PW_BLOCK) {
-            if (!stop_at_leaf) return false;
-            return (bits & ((2u << b) - 1u)) == 0u;
+    const int lane = threadIdx.x;
+    volatile unsigned *tab = sc->tab;
+    if (lane == 0) { tab[1] = (unsigned)m; sc->nleaf = 0; }
+    int depth = 0;
+    for (int lvl = 1; lvl <= 7; lvl++) {
+        __builtin_amdgcn_wave_barrier();
+        bool any = false;
+        for (int id = (1 << lvl) + lane; id < (2 << lvl); id += 64) {
+            const unsigned par = tab[id >> 1];
+            const int plen = (int)(par & 0xffffu), ps = (int)(par >> 16);
+            unsigned me = 0u;
+            if (plen > PW_BLOCK) {
+                int n2 = plen / 2;
+                n2 -= n2 % 8;
+                me = (id & 1) ? ((unsigned)(ps + n2) << 16 | (unsigned)(plen - n2)) : ((unsigned)ps << 16 | (unsigned)n2);
+            }
+            tab[id] = me;
+            any |= (me != 0u);
         }
-        int n2 = len / 2;
-        n2 -= n2 % 8;
-        const unsigned bit = (bits >> b) & 1u;
-        if (bit) { start += n2; len -= n2; } else { len = n2; }
-        id = 2 * id + (int)bit;
+        if (__ballot(any)) depth = lvl;
     }
-    return true;
+    __builtin_amdgcn_wave_barrier();
+    for (int id = 1 + lane; id < MAX_NODES; id += 64) {
+        const unsigned e = tab[id];
+        if (e != 0u && (int)(e & 0xffffu) <= PW_BLOCK) sc->leaf[atomicAdd(&sc->nleaf, 1)] = (unsigned short)id;
+    }
+    if (lane == 0) { sc->tree_m = m; sc->tree_depth = depth; }
 }
 
 // Sum of term(i), i in [0, m), in the order numpy's pairwise_sum uses (m <= 8192).
@@ -140,38 +156,34 @@ __device__ double pairwise_chunk(int m, Scratch *sc, Term term)
         lds_barrier();
         return r;
     }
-    // deepest leaf level: follow the larger (right) child
-    int depth = 0;
-    for (int len = m; len > PW_BLOCK; depth++) { int n2 = len / 2; n2 -= n2 % 8; len -= n2; }
-    const int npaths = 1 << depth;                 // bit-reversed path order packs the leaves first
+    if (sc->tree_m != m) {                         // (block-uniform: written before the last barrier)
+        lds_barrier();                             // nobody still reads the old tree
+        if (tid < 64) build_tree(m, sc);
+        lds_barrier();
+    }
     const int grp = tid >> 3, j = tid & 7;
-    for (int idx = grp; idx < ((npaths + 31) & ~31); idx += TPB / 8) {
-        const unsigned path = __brev((unsigned)idx) >> 25;     // 7-bit reversal
-        int s, len, id;
-        const bool act = (idx < 128) && tree_node(m, path, 7, true, s, len, id);
-        double r = 0.0;
-        if (act) {
-            r = term(s + j);
-            const int full = len - (len % 8);
-            for (int i = 8; i < full; i += 8) r += term(s + i + j);
-        }
+    const int nleaf = sc->nleaf;
+    for (int li = grp; li < nleaf; li += TPB / 8) {
+        const int id = sc->leaf[li];
+        const unsigned e = sc->tab[id];
+        const int s = (int)(e >> 16), len = (int)(e & 0xffffu);
+        double r = term(s + j);
+        const int full = len - (len % 8);
+        for (int i = 8; i < full; i += 8) r += term(s + i + j);
         r += __shfl_xor(r, 1);                      // (r0+r1) (r2+r3) (r4+r5) (r6+r7)
         r += __shfl_xor(r, 2);                      // ((r0+r1)+(r2+r3)) ...
         r += __shfl_xor(r, 4);
-        if (act && j == 0) {
-            for (int i = len - (len % 8); i < len; i++) r += term(s + i);
+        if (j == 0) {
+            for (int i = full; i < len; i++) r += term(s + i);
             sc->node_sum[id] = r;
         }
     }
     lds_barrier();
     if (tid < 64) {
         volatile double *ns = sc->node_sum;
-        for (int lvl = depth - 1; lvl >= 0; lvl--) {
-            if (tid < (1 << lvl)) {
-                int s, len, id;
-                if (tree_node(m, (unsigned)tid, lvl, false, s, len, id) && len > PW_BLOCK)
-                    ns[id] = ns[2 * id] + ns[2 * id + 1];
-            }
+        for (int lvl = sc->tree_depth - 1; lvl >= 0; lvl--) {
+            for (int id = (1 << lvl) + tid; id < (2 << lvl); id += 64)
+                if ((int)(sc->tab[id] & 0xffffu) > PW_BLOCK) ns[id] = ns[2 * id] + ns[2 * id + 1];
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -232,6 +244,7 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
         }
     };
 
+    if (tid == 0) sc->tree_m = -1;                         // no pairwise tree cached yet
     int16_t v[8], vn[8];
     int Mnext = (blockIdx.x < nreads) ? len[blockIdx.x] : 0;
     if (blockIdx.x < nreads) load8(sig + (int64_t)blockIdx.x * stride, Mnext, tid * 8, v);
@@ -355,30 +368,41 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
         const double d = (double)src[w0 + i] - mean;
         return d * d;
     });
-    const double sd = sqrt(ssq / (double)ns);
-
+    // sqrt / divisions / thresholds once per read (thread 0), not once per wavefront
+    if (tid == 0) {
+        const double sd = sqrt(ssq / (double)ns);
+        if (mode == SK_PREP_ZSCALE) {
+            pr.center = mean;
+            pr.scale = (sd == 0.0) ? 1.0 : sd;             // sklearn _handle_zeros_in_scale
+        } else {
+            // ---- segmenter thresholds (segmenter.py:413-414) ---------------------------------
+            const double spread = sd * std_scale;
+            const double top = median + spread;
+            // dRNA_segmenter.py:111,114 tests `a < top` only
+            const double bot = (mode == SK_PREP_DRNA) ? -__builtin_huge_val() : median - spread;
+            pr.center = median; pr.scale = sd; pr.top = top; pr.bot = bot;
+            // Samples are integers, so `a < top and a > bot` (segmenter.py:431) is the integer test
+            // floor(bot) < a < ceil(top); clamped just outside the int16 range, NaN -> empty band.
+            const double ct = ceil(top), fb = floor(bot);
+            int itop = (top == top) ? (ct > 32768.0 ? 32768 : (ct < -32768.0 ? -32768 : (int)ct)) : -32768;
+            int ibot = (bot == bot) ? (fb > 32767.0 ? 32767 : (fb < -32769.0 ? -32769 : (int)fb)) : 32767;
+            sc->sel[2] = ibot + 1;                         // first in-band value
+            sc->sel[3] = max(itop - ibot - 1, 0);          // number of in-band values
+        }
+        prep[r] = pr;
+    }
     if (mode == SK_PREP_ZSCALE) {
-        pr.center = mean;
-        pr.scale = (sd == 0.0) ? 1.0 : sd;                 // sklearn _handle_zeros_in_scale
-        if (tid == 0) prep[r] = pr;
         lds_barrier();
         continue;
     }
-
-    // ---- segmenter thresholds + in-band mask (segmenter.py:413-414,431) -----------------
-    const double spread = sd * std_scale;
-    const double top = median + spread;
-    // dRNA_segmenter.py:111,114 tests `a < top` only
-    const double bot = (mode == SK_PREP_DRNA) ? -__builtin_huge_val() : median - spread;
-    pr.center = median; pr.scale = sd; pr.top = top; pr.bot = bot;
-    if (tid == 0) prep[r] = pr;
+    lds_barrier();
+    // ---- in-band mask: one compare per sample, the lane mask of the compare is the word -------
+    const int first = sc->sel[2];
+    const unsigned width = (unsigned)sc->sel[3];
     for (int base = 0; base < n; base += TPB) {
         const int i = base + tid;
         bool in = false;
-        if (i < n) {
-            const double a = (double)src[i];
-            in = (a < top) && (a > bot);
-        }
+        if (i < n) in = (unsigned)((int)src[i] - first) < width;
         const unsigned long long bits = __ballot(in);
         if (lane == 0) maskT[(int64_t)(i >> 6) * mask_rows + r] = bits;
     }
@@ -487,6 +511,7 @@ void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off,
     const double *row = sig + o0;
     double *crow = comp + o0;
     if (tid < 4) sc->sel[tid] = 0;
+    if (tid == 0) sc->tree_m = -1;
 
     // ---- pass A: filter + order-preserving compaction + key extremes --------------------
     unsigned long long kmin = ~0ull, kmax = 0ull;

@@ -10,6 +10,7 @@
 // ceil(window * stall_len) because c is an integer.
 #include "sk_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -17,10 +18,104 @@ struct WalkParams {
     int error, corrector, window, seg_dist, first_len;   // first_len = ceil(window * stall_len)
 };
 
-// Per-sample update written as straight-line selects: the 64 lanes of a wave are 64 different
+// Per-sample update written as straight-line arithmetic: the 64 lanes of a wave are 64 different
 // reads in 64 different states, so `if` ladders would execute every arm at every step.  Only the
-// two rare events leave the straight line: closing a segment that is long enough to be reported
-// (a handful per read) and the corrector test (dead unless error >= corrector).
+// rare events leave the straight line: closing a segment that is long enough to be reported
+// (a handful per read) and, in the general variant, the corrector test.
+//
+// FAST variant (error < corrector, the defaults included): the corrector test of
+// segmenter.py:439/446 can never fire -- c <= (in-band samples of this segment) + err and
+// w = corrector + (all in-band samples so far), so c >= w needs err >= corrector -- hence err
+// never decreases, `w` needs no tracking, and every state variable is a product/sum of 0/1 flags:
+//     c' = c*act + act      err' = err*act + tol      prev_err' = prev_err*tol + tol
+// A segment's `start` is not stored either: from the opening sample on every step is `act`
+// until the one that closes it, so start == i - c there.  11 vector instructions per sample.
+struct WalkState {
+    int prev, err, prev_err, c, w, start, nseg, last_end;
+};
+
+__device__ __forceinline__ void report_segment(WalkState &st, int start, int end, const WalkParams &p,
+                                               int32_t *my, int max_segs)
+{
+    if (st.nseg > 0 && start - st.last_end < p.seg_dist) {                         // :451 merge
+        if (st.nseg <= max_segs) my[2 * (st.nseg - 1) + 1] = end;
+    } else {
+        if (st.nseg < max_segs) { my[2 * st.nseg] = start; my[2 * st.nseg + 1] = end; }
+        st.nseg++;
+    }
+    st.last_end = end;
+}
+
+// v_mad_u32_u24 / v_mul_u32_u24 (one issue slot each; the compiler will not pick them on its own)
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned mul24(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// one 32-sample half word, every lane's samples valid, corrector dead
+__device__ __forceinline__ void walk_fast32(WalkState &st, unsigned bits, int i0, const WalkParams &p,
+                                            int thr_first, int32_t *my, int max_segs)
+{
+    unsigned prev = (unsigned)st.prev, err = (unsigned)st.err, perr = (unsigned)st.prev_err, c = (unsigned)st.c;
+    // report threshold: window, or min(window, first_len) until the first segment (:448);
+    // 0x7fffffff for lanes that own no read
+    unsigned thr = (st.nseg == 0) ? (unsigned)thr_first : (unsigned)p.window;
+#pragma unroll 16
+    for (int b = 0; b < 32; b++) {
+        const unsigned inb = (bits >> b) & 1u;                                     // :431 in band
+        const unsigned ltm = (unsigned)(((int)err - p.error) >> 31);               // all ones: err < error
+        const unsigned tol = prev & ~inb & ltm;                                    // :442 tolerated
+        const unsigned closing = prev & ~inb & ~ltm;                               // :448 / :458
+        const unsigned act = inb | tol;
+        if (mul24(closing, c) >= thr) {                                            // thr >= 1
+            report_segment(st, i0 + b - (int)c, i0 + b - (int)perr, p, my, max_segs);   // :449
+            thr = (unsigned)p.window;
+        }
+        c = mad24(c, act, act);
+        err = mad24(err, act, tol);
+        perr = mad24(perr, tol, tol);
+        prev = act;
+    }
+    st.prev = (int)prev; st.err = (int)err; st.prev_err = (int)perr; st.c = (int)c;
+}
+
+// general step (any parameters, samples past a lane's n ignored); keeps `start` and `w`
+__device__ __forceinline__ void walk_general32(WalkState &st, unsigned bits, int i0, int n, const WalkParams &p,
+                                               int32_t *my, int max_segs)
+{
+    int prev = st.prev, err = st.err, prev_err = st.prev_err, c = st.c, w = st.w, start = st.start;
+#pragma unroll 4
+    for (int b = 0; b < 32; b++) {
+        const int i = i0 + b;
+        const int valid = i < n;
+        const int inb = (int)((bits >> b) & 1u) & valid;                           // :431 in band
+        const int tol = (inb ^ 1) & prev & (int)(err < p.error) & valid;           // :442 tolerated
+        const int act = inb | tol;
+        const int closing = prev & (act ^ 1) & valid;                              // :448 / :458
+        if (closing && (c >= p.window || (st.nseg == 0 && c >= p.first_len)))
+            report_segment(st, start, i - prev_err, p, my, max_segs);              // :449
+        start = (inb & (prev ^ 1)) ? i : start;
+        c = act ? c + 1 : (valid ? 0 : c);
+        w += inb;
+        err = tol ? err + 1 : (act ? err : (valid ? 0 : err));
+        prev_err = tol ? prev_err + 1 : (valid ? 0 : prev_err);
+        prev = valid ? act : prev;
+        if (act && c >= p.window && c >= w) {                                      // :439 / :446
+            if ((c % w) == 0) err--;
+        }
+    }
+    st.prev = prev; st.err = err; st.prev_err = prev_err; st.c = c; st.w = w; st.start = start;
+}
+
+template <bool FAST>
 __global__ __launch_bounds__(64)
 void k_segment_walk(const uint64_t *__restrict__ maskT, int64_t mask_rows,
                     const sk_prep *__restrict__ prep, int nreads, WalkParams p,
@@ -31,55 +126,41 @@ void k_segment_walk(const uint64_t *__restrict__ maskT, int64_t mask_rows,
     const int n = live ? prep[r].n : 0;
     int32_t *my = segs + (int64_t)(live ? r : 0) * 2 * max_segs;
 
-    int prev = 0;                                 // inside a candidate segment
-    int err = 0, prev_err = 0, c = 0;
-    int w = p.corrector;                          // segmenter.py:424 -- never reset inside a read
-    int start = 0, nseg = 0, last_end = 0;
+    WalkState st;
+    st.prev = 0;                                  // inside a candidate segment
+    st.err = 0; st.prev_err = 0; st.c = 0;
+    st.w = p.corrector;                           // segmenter.py:424 -- never reset inside a read
+    st.start = 0; st.nseg = 0; st.last_end = 0;
 
     int nmax = n;                                 // wave-uniform trip count (lanes past their n idle)
+    int nmin = (n > 0) ? n : 0x7fffffff;          // shortest read of the wave: words all lanes own
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+    for (int d = 32; d >= 1; d >>= 1) {
+        nmax = max(nmax, __shfl_xor(nmax, d));
+        nmin = min(nmin, __shfl_xor(nmin, d));
+    }
     const int nwords = (nmax + 63) >> 6;
+    // the fast steps use 24-bit multiplies on counters bounded by n
+    const int nfast = (FAST && nmax < (1 << 24)) ? min(nwords, nmin >> 6) : 0;
+    const int thr_first = (n > 0) ? min(p.window, p.first_len) : 0x7fffffff;
 
     uint64_t next = (n > 0) ? maskT[r] : 0ull;
     for (int wi = 0; wi < nwords; wi++) {
         const uint64_t word = next;
         if ((wi + 1) * 64 < n) next = maskT[(int64_t)(wi + 1) * mask_rows + r];     // prefetch
-        const unsigned half[2] = {(unsigned)word, (unsigned)(word >> 32)};
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const unsigned bits = half[h];
-#pragma unroll 4
-            for (int b = 0; b < 32; b++) {
-                const int i = wi * 64 + h * 32 + b;
-                const int valid = i < n;
-                const int inb = (int)((bits >> b) & 1u) & valid;                   // :431 in band
-                const int tol = (inb ^ 1) & prev & (int)(err < p.error) & valid;   // :442 tolerated
-                const int act = inb | tol;
-                const int closing = prev & (act ^ 1) & valid;                      // :448 / :458
-                if (closing && (c >= p.window || (nseg == 0 && c >= p.first_len))) {
-                    const int end = i - prev_err;                                  // :449
-                    if (nseg > 0 && start - last_end < p.seg_dist) {               // :451 merge
-                        if (nseg <= max_segs) my[2 * (nseg - 1) + 1] = end;
-                    } else {
-                        if (nseg < max_segs) { my[2 * nseg] = start; my[2 * nseg + 1] = end; }
-                        nseg++;
-                    }
-                    last_end = end;
-                }
-                start = (inb & (prev ^ 1)) ? i : start;
-                c = act ? c + 1 : (valid ? 0 : c);
-                w += inb;
-                err = tol ? err + 1 : (act ? err : (valid ? 0 : err));
-                prev_err = tol ? prev_err + 1 : (valid ? 0 : prev_err);
-                prev = valid ? act : prev;
-                if (act && c >= p.window && c >= w) {                              // :439 / :446
-                    if ((c % w) == 0) err--;
-                }
+        if (wi < nfast) {
+            walk_fast32(st, (unsigned)word, wi * 64, p, thr_first, my, max_segs);
+            walk_fast32(st, (unsigned)(word >> 32), wi * 64 + 32, p, thr_first, my, max_segs);
+            if (wi + 1 == nfast) {                // hand over to the general steps
+                st.start = (wi + 1) * 64 - st.c;
+                st.w = 0x7fffffff;                // the corrector test stays dead
             }
+        } else {
+            walk_general32(st, (unsigned)word, wi * 64, n, p, my, max_segs);
+            walk_general32(st, (unsigned)(word >> 32), wi * 64 + 32, n, p, my, max_segs);
         }
     }
-    if (live) nsegs[r] = nseg;                    // a segment still open at EOF is dropped (:466)
+    if (live) nsegs[r] = st.nseg;                 // a segment still open at EOF is dropped (:466)
 }
 
 // dRNA_segmenter.py's slow5-branch scan (dRNA_segmenter.py:112-165): same skeleton, but the
@@ -168,8 +249,15 @@ int sk_launch_segment_walk(sk_ctx *c, const uint64_t *d_mask, int64_t mask_rows,
     else                       wp.first_len = (int)ceil(fl);
     const int grid = (nreads + 63) / 64;
     SK_HIP(hipEventRecord(c->ev[2], c->stream));
-    hipLaunchKernelGGL(k_segment_walk, dim3(grid), dim3(64), 0, c->stream, d_mask, mask_rows, d_prep, nreads,
-                       wp, d_segs, d_nsegs, max_segs);
+    // the straight-line variant needs a dead corrector test and positive report thresholds
+    const bool fast = wp.error < wp.corrector && wp.window >= 1 && wp.first_len >= 1 &&
+                      getenv("SK_WALK_GENERAL") == nullptr;
+    if (fast)
+        hipLaunchKernelGGL(k_segment_walk<true>, dim3(grid), dim3(64), 0, c->stream, d_mask, mask_rows, d_prep,
+                           nreads, wp, d_segs, d_nsegs, max_segs);
+    else
+        hipLaunchKernelGGL(k_segment_walk<false>, dim3(grid), dim3(64), 0, c->stream, d_mask, mask_rows, d_prep,
+                           nreads, wp, d_segs, d_nsegs, max_segs);
     SK_HIP(hipGetLastError());
     SK_HIP(hipEventRecord(c->ev[3], c->stream));
     return SK_OK;

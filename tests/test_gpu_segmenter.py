@@ -82,6 +82,34 @@ def test_vs_oracle_random_params_and_lengths(gpu, ora):
             assert np.array_equal(segs[r, :nsegs[r]], osegs[r, :nsegs[r]]), (kw, r)
 
 
+def test_fast_and_general_walk_agree(gpu, ora, monkeypatch):
+    """The straight-line walk (error < corrector) against the general one and the oracle, with
+    ragged lengths so that the hand-over between the two step forms is exercised inside a wave."""
+    from squigglekit_amd import api, synth
+    rng = np.random.default_rng(99)
+    sig = synth.squiggle_batch(192, 5000, 777)
+    lens = rng.integers(1, 5001, size=192).astype(np.int32)
+    lens[64:128] = 5000                      # one wave with no ragged tail at all
+    lens[130] = 0
+    for kw in (dict(), dict(error=49, corrector=50, window=20), dict(error=1, corrector=2, window=5, seg_dist=3),
+               dict(error=3, window=2, stall_len=0.5, seg_dist=0), dict(error=-1), dict(std_scale=0.1, window=3)):
+        p = _params(kw)
+        osegs = onsegs = None
+        for general in (False, True):
+            if general:
+                monkeypatch.setenv("SK_WALK_GENERAL", "1")
+            else:
+                monkeypatch.delenv("SK_WALK_GENERAL", raising=False)
+            segs, nsegs = api.segment_batch(sig, lens, p, max_segs=64)
+            if osegs is None:
+                osegs, onsegs = ora.segment_batch_i16(sig, lens, ora.SegParams(**kw), lo=p.lim_low, hi=p.lim_hi,
+                                                      max_segs=segs.shape[1])
+            assert np.array_equal(nsegs, onsegs), (kw, general, np.nonzero(nsegs != onsegs)[0][:5])
+            for r in range(192):
+                assert np.array_equal(segs[r, :nsegs[r]], osegs[r, :nsegs[r]]), (kw, general, r)
+    monkeypatch.delenv("SK_WALK_GENERAL", raising=False)
+
+
 def test_long_read_chunks_numpy_sum_order(gpu, ora):
     """n > 8192 exercises numpy's chunked pairwise summation inside np.std."""
     from squigglekit_amd import api, synth
