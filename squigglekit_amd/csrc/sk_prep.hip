@@ -39,8 +39,9 @@ struct Scratch {
     // sees one or two distinct lengths).
     unsigned  tab[MAX_NODES];
     unsigned short leaf[MAX_NODES / 2];   // heap ids of the leaves (len <= PW_BLOCK), any order
-    int       tree_m, tree_depth, nleaf;
+    int       tree_m, tree_depth, nleaf, pad_;
 };
+static_assert(sizeof(Scratch) % 16 == 0, "the histograms / sample buffer behind Scratch are 16-byte aligned");
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would
 // serialise the global loads we keep in flight across the statistics phase.  Use it wherever the
@@ -211,7 +212,37 @@ __device__ double numpy_sum(int n, Scratch *sc, Term term)
 // LDSCOMP: the compacted samples also live in LDS (reads up to lds_cap samples), so the std
 // leaf sums and the in-band classification never go back to global memory; the segmenter
 // variant then writes no compacted samples to HBM at all (the walk kernel only needs the mask).
-template <bool LDSCOMP>
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned clamp_pk_i16(unsigned q, unsigned lo2, unsigned hi2)
+{
+    const i16x2 x = __builtin_bit_cast(i16x2, q);
+    const i16x2 c = __builtin_elementwise_min(__builtin_elementwise_max(x, __builtin_bit_cast(i16x2, lo2)),
+                                              __builtin_bit_cast(i16x2, hi2));
+    return __builtin_bit_cast(unsigned, c);
+}
+
+// eight consecutive samples (four packed pairs) to dst; al = (element offset of dst) mod 8 when the
+// row base is 16-byte aligned, odd when nothing is known
+template <typename P>
+__device__ __forceinline__ void put8(P *dst, const unsigned (&q)[4], int al)
+{
+    if (al == 0) {
+        *(uint4 *)dst = make_uint4(q[0], q[1], q[2], q[3]);
+    } else if ((al & 1) == 0) {
+        unsigned *d = (unsigned *)dst;
+        d[0] = q[0]; d[1] = q[1]; d[2] = q[2]; d[3] = q[3];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            dst[2 * k] = (int16_t)(q[k] & 0xffffu);
+            dst[2 * k + 1] = (int16_t)(q[k] >> 16);
+        }
+    }
+}
+
+// WINDOWED: statistics over filtered samples [t0, t1) only (dRNA_segmenter.py:109-110)
+template <bool LDSCOMP, bool WINDOWED>
 __global__ __launch_bounds__(TPB, 8) __attribute__((amdgpu_num_sgpr(80)))
 void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *__restrict__ len, int nreads,
                 int lo, int hi, int mode, double std_scale, int vec_ok, int t0, int t1,
@@ -224,28 +255,41 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     const int nbins = max(0, hi - lo - 1);                 // values lo+1 .. hi-1
     unsigned *dev = hist + nbins;                          // medmad: 2*nbins+1 bins of |2x - 2med|
     const int ndev = (mode == SK_PREP_MEDMAD) ? 2 * nbins + 1 : 0;
-    int16_t *lcomp = (int16_t *)(hist + nbins + ndev + ((nbins + ndev) & 1));   // 8-byte aligned
+    int16_t *lcomp = (int16_t *)(hist + nbins + ndev + ((4 - ((nbins + ndev) & 3)) & 3));   // 16-byte aligned
+    unsigned *hist_v = hist - (lo + 1);                    // hist_v[x] counts value x
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool to_global = !(LDSCOMP && (mode == SK_PREP_SEGMENT || mode == SK_PREP_DRNA));
+    if (!WINDOWED) { t0 = 0; t1 = 0x7fffffff; }
+    // bit 0: sig rows 16-byte aligned, bit 1: comp rows too
+    const bool in_vec = (vec_ok & 1) != 0, out_vec = (vec_ok & 2) != 0;
+    // the keep range as packed int16 pairs, for the "all eight samples survive" test
+    const int lo1 = max(lo + 1, -32768), hi1 = min(hi - 1, 32767);
+    const bool range_ok = lo1 <= hi1;
+    const unsigned lo2 = (unsigned)(lo1 & 0xffff) * 0x10001u, hi2 = (unsigned)(hi1 & 0xffff) * 0x10001u;
 
     // Persistent workgroups: each walks reads r, r + grid, ... and has the first tile of its
-    // next read in flight while it does the statistics of the current one.
-    auto load8 = [&](const int16_t *row, int M, int i0, int16_t (&v)[8]) {
-        if (vec_ok && i0 + 8 <= M) {
-            const int4 q = *(const int4 *)(row + i0);
-            v[0] = (int16_t)(q.x & 0xffff); v[1] = (int16_t)(q.x >> 16);
-            v[2] = (int16_t)(q.y & 0xffff); v[3] = (int16_t)(q.y >> 16);
-            v[4] = (int16_t)(q.z & 0xffff); v[5] = (int16_t)(q.z >> 16);
-            v[6] = (int16_t)(q.w & 0xffff); v[7] = (int16_t)(q.w >> 16);
+    // next read in flight while it does the statistics of the current one.  Samples stay packed
+    // (two per register) until they are scattered.
+    auto load8 = [&](const int16_t *row, int M, int i0, unsigned (&q)[4]) {
+        if (in_vec && i0 + 8 <= M) {
+            const uint4 t = *(const uint4 *)(row + i0);
+            q[0] = t.x; q[1] = t.y; q[2] = t.z; q[3] = t.w;
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = (i0 + k < M) ? row[i0 + k] : (int16_t)lo;   // lo is filtered out
+            for (int k = 0; k < 4; k++) {
+                const unsigned a = (i0 + 2 * k < M) ? (unsigned short)row[i0 + 2 * k] : 0u;
+                const unsigned b = (i0 + 2 * k + 1 < M) ? (unsigned short)row[i0 + 2 * k + 1] : 0u;
+                q[k] = a | (b << 16);
+            }
         }
+    };
+    auto sample = [](const unsigned (&q)[4], int k) -> int {
+        return (k & 1) ? (int)q[k >> 1] >> 16 : (int)(short)(q[k >> 1] & 0xffffu);
     };
 
     if (tid == 0) sc->tree_m = -1;                         // no pairwise tree cached yet
-    int16_t v[8], vn[8];
+    unsigned v[4], vn[4];
     int Mnext = (blockIdx.x < nreads) ? len[blockIdx.x] : 0;
     if (blockIdx.x < nreads) load8(sig + (int64_t)blockIdx.x * stride, Mnext, tid * 8, v);
     for (int r = blockIdx.x; r < nreads; r += gridDim.x) {
@@ -256,21 +300,30 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     if (tid < 4) sc->sel[tid] = 0;
     lds_barrier();
 
-    // ---- pass A: filter, compact (order preserving), histogram, exact integer sum ----
-    long long isum = 0;
+    // ---- pass A: filter, compact (order preserving), histogram ----------------------------
     int run = 0;                                           // survivors so far (block uniform)
     int parity = 0;
     for (int base = 0; base < M; base += TPB * 8, parity ^= 1) {
         const int i0 = base + tid * 8;
         if (base + TPB * 8 < M) load8(row, M, i0 + TPB * 8, vn);   // prefetch the next tile
-        unsigned keep = 0;
+        // Outliers are rare: when every sample of the wavefront's 512 survives (clamping the
+        // packed pairs to the keep range changes nothing) there is nothing to scan or to test.
+        unsigned changed = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int x = v[k];
-            if (i0 + k < M && x > lo && x < hi) keep |= 1u << k;
+        for (int k = 0; k < 4; k++) changed |= clamp_pk_i16(v[k], lo2, hi2) ^ v[k];
+        const bool wave_all = __all(range_ok && i0 + 8 <= M && changed == 0u);
+        unsigned keep = 0xffu;
+        int cnt = 8, inc = 8 * (lane + 1);
+        if (!wave_all) {
+            keep = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int x = sample(v, k);
+                if (i0 + k < M && x > lo && x < hi) keep |= 1u << k;
+            }
+            cnt = __popc(keep);
+            inc = wave_incl_scan(cnt, lane);
         }
-        const int cnt = __popc(keep);
-        const int inc = wave_incl_scan(cnt, lane);
         if (lane == 63) sc->wsum[parity][w] = inc;
         lds_barrier();
         int wbase = 0, tot = 0;
@@ -281,22 +334,28 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
             tot += s;
         }
         int o = run + wbase + inc - cnt;
+        if (wave_all) {
+            const int al = (run + wbase) & 7;              // wave uniform: o = run + wbase + 8 * lane
+            if (LDSCOMP) put8(lcomp + o, v, al);
+            if (to_global) put8(crow + o, v, out_vec ? al : 1);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (keep & (1u << k)) {
-                const int x = v[k];
-                if (LDSCOMP) lcomp[o] = (int16_t)x;
-                if (to_global) crow[o] = (int16_t)x;
-                if (o >= t0 && o < t1) {                   // statistics window (whole read unless dRNA)
-                    atomicAdd(&hist[x - lo - 1], 1u);
-                    isum += x;
+            for (int k = 0; k < 8; k++)
+                if (!WINDOWED || (o + k >= t0 && o + k < t1)) atomicAdd(&hist_v[sample(v, k)], 1u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (keep & (1u << k)) {
+                    const int x = sample(v, k);
+                    if (LDSCOMP) lcomp[o] = (int16_t)x;
+                    if (to_global) crow[o] = (int16_t)x;
+                    if (!WINDOWED || (o >= t0 && o < t1)) atomicAdd(&hist_v[x], 1u);   // statistics window
+                    o++;
                 }
-                o++;
             }
         }
         run += tot;
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = vn[k];
+        for (int k = 0; k < 4; k++) v[k] = vn[k];
     }
     const int n = run;
     {                                                      // first tile of my next read
@@ -354,7 +413,9 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
         continue;
     }
 
-    // ---- mean (exact integer sum) and numpy-order std ----------------------------------
+    // ---- mean (exact integer sum, taken from the histogram) and numpy-order std -----------
+    long long isum = 0;
+    for (int b = tid; b < nbins; b += TPB) isum += (long long)hist[b] * (long long)(b + lo + 1);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) isum += __shfl_xor(isum, d);
     if (lane == 0) sc->wred[w] = isum;
@@ -624,19 +685,22 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
     if (nreads <= 0) return SK_OK;
     const int64_t nbins = (int64_t)hi - (int64_t)lo - 1 > 0 ? (int64_t)hi - lo - 1 : 0;
     const int64_t words = (mode == SK_PREP_MEDMAD) ? 3 * nbins + 1 : nbins;
-    size_t lds = sizeof(Scratch) + (size_t)(words + (words & 1)) * 4;
+    size_t lds = sizeof(Scratch) + (size_t)((words + 3) & ~(int64_t)3) * 4;
     if (lds > 160 * 1024)
         return sk_fail(SK_ERR_UNSUPPORTED,
                        "outlier limits (%d, %d) span %lld integer values: the LDS histogram holds %d (%s)",
                        lo, hi, (long long)nbins, (mode == SK_PREP_MEDMAD) ? 12900 : 38900,
                        "narrow -scale_low/-scale_hi / -lim_low/-lim_hi");
-    const int vec_ok = (((uintptr_t)d_sig & 15) == 0 && (stride % 8) == 0) ? 1 : 0;
+    const int vec_ok = ((((uintptr_t)d_sig & 15) == 0 && (stride % 8) == 0) ? 1 : 0) |
+                       ((((uintptr_t)d_comp & 15) == 0 && (stride % 8) == 0) ? 2 : 0);
     // keep the compacted samples in LDS when the whole read fits next to the histograms without
     // dropping below ~4 workgroups per CU (mean/std modes only; medmad never re-reads samples)
     const size_t lds_comp = (size_t)stride * sizeof(int16_t);
     const bool ldscomp = mode != SK_PREP_MEDMAD && lds + lds_comp <= 40 * 1024;
     if (ldscomp) lds += lds_comp;
-    auto fn = ldscomp ? k_prep_i16<true> : k_prep_i16<false>;
+    const bool windowed = t0 > 0 || t1 < 0x7fffffff;
+    auto fn = ldscomp ? (windowed ? k_prep_i16<true, true> : k_prep_i16<true, false>)
+                      : (windowed ? k_prep_i16<false, true> : k_prep_i16<false, false>);
     if (lds > 64 * 1024)
         SK_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent grid: as many workgroups as the chip holds (8 x 256 threads per CU, LDS permitting)

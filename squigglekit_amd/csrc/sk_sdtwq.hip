@@ -96,8 +96,6 @@ void k_sdtw_q(const sdtw_kargs a)
 {
     constexpr int G = 64 / L;
     constexpr int SHR = (L == 16) ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
-    constexpr int ROL = (L == 16) ? DPP_ROW_ROL1 : DPP_WAVE_ROL1;
-    constexpr int SHL = (L == 16) ? DPP_ROW_SHL1 : DPP_WAVE_SHL1;
     constexpr int CKW = R + 2;
 
     const int lane = threadIdx.x & 63;
@@ -143,7 +141,6 @@ void k_sdtw_q(const sdtw_kargs a)
     for (int k = 0; k < R; k++) { Da[k] = QINF; Db[k] = QINF; }
     unsigned botq = (R == 1 && l == 0 && shortlane) ? 0u : QINF;
     unsigned diagq = (l == 0) ? 0u : QINF;
-    unsigned yq = QINF;
     int bad = 0;
 
     // the sample feed in two halves, so that the load for the next block is in flight during this
@@ -168,20 +165,25 @@ void k_sdtw_q(const sdtw_kargs a)
     };
 
     unsigned *lastq = a.lastq + (int64_t)(r - a.read0) * a.lq_stride;
+    // Per read group, in LDS: the sample images of the previous and the current block (lane l
+    // needs sample t - l at step t: one ds_read with an immediate offset instead of a DPP shift
+    // chain on the vector ALU, which is the bottleneck), and the last-row values lane L-1 produces.
+    //   ybuf[0,L) even blocks | ybuf[L,2L) odd blocks | ybuf[2L,3L) copy of [0,L)
+    // so that sample t0 + q - l of an even block is ybuf[2L + q - l] and of an odd one ybuf[L + q - l].
+    __shared__ unsigned lds_all[4][5 * 64];
+    unsigned *ybuf = lds_all[threadIdx.x >> 6] + g * 5 * L;
+    unsigned *hbuf = ybuf + 3 * L;
+    unsigned *hw = (l == L - 1) ? hbuf : hbuf + L;  // every other lane writes to a dump row
+    ybuf[L + l] = QINF;                             // columns before the read
     unsigned F = toq(loadraw(l), l);
-    unsigned H = 0;                                 // last-row values of this block, one per lane
-    // one step: shift the sample and lane l-1's bottom row in, run the column old -> nw
-    auto step = [&](const unsigned (&old)[R], unsigned (&nw)[R]) {
-        yq = (unsigned)dpp_i32<SHR>((int)F, (int)yq);
-        F = (unsigned)dpp_i32<ROL>((int)F, (int)F);
+    // one step: lane l-1's bottom row comes in by DPP, run the column old -> nw
+    auto step = [&](const unsigned (&old)[R], unsigned (&nw)[R], unsigned yq, unsigned *hslot) {
         const unsigned upq = (unsigned)__builtin_amdgcn_update_dpp(0, (int)botq, SHR, 0xF, 0xF, true);
         qcolumn<R>(old, nw, xq, yq, diagq, upq);
         diagq = upq;
         if constexpr (R >= 2) botq = shortlane ? nw[R - 2] : nw[R - 1];
         else                  botq = shortlane ? upq : nw[0];
-        // lane L-1 produces one last-row value per step: shift them towards lane 0, so that after
-        // the L steps of a block lane i holds the value of step t0 + i (one coalesced store)
-        H = (unsigned)dpp_i32<SHL>((int)nw[R - 1], (int)H);
+        *hslot = nw[R - 1];                         // (only lane L-1's lands in hbuf)
     };
     for (int blk = 0; blk < nblk; blk++) {
         const auto rawnext = loadraw((blk + 1) * L + l);
@@ -192,14 +194,23 @@ void k_sdtw_q(const sdtw_kargs a)
             for (int k = 0; k < R; k++) cp[k] = Da[k];
             cp[R] = botq; cp[R + 1] = diagq;
         }
+        const unsigned *yr;
+        if (blk & 1) { ybuf[L + l] = F; yr = ybuf + L - l; }
+        else         { ybuf[l] = F; ybuf[2 * L + l] = F; yr = ybuf + 2 * L - l; }
 #pragma unroll 1
-        for (int q = 0; q < L; q += 2) {            // L is even: after two steps the roles are back
-            step(Da, Db);
-            step(Db, Da);
+        for (int qq = 0; qq < L; qq += 16) {
+            unsigned yv[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) yv[q] = yr[qq + q];
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {       // after two steps the ping-pong roles are back
+                step(Da, Db, yv[q], hw + qq + q);
+                step(Db, Da, yv[q + 1], hw + qq + q + 1);
+            }
         }
         F = toq(rawnext, (blk + 1) * L + l);
         const int j = t0 + l - (L - 1);             // lane L-1's column at step t0 + l
-        if (j >= 0 && j < n) lastq[j] = H;
+        if (j >= 0 && j < n) lastq[j] = hbuf[l];
     }
     // a sample outside the fixed-point range anywhere in the read disqualifies the screening
 #pragma unroll
