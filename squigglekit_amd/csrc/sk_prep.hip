@@ -51,13 +51,16 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+// Inclusive scan across the wavefront on the vector ALU (DPP): four shifts inside each row of 16,
+// then lane 15 of rows 0/2 into rows 1/3 and lane 31 into the upper half.  No LDS round trips.
+__device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
     return v;
 }
 
@@ -98,6 +101,59 @@ __device__ void rank_select2(const unsigned *hist, int nbins, int k1, int k2, Sc
         if (k2 >= pre && k2 < pre + local) {
             int acc = pre;
             for (int b = b0; b < b1; b++) { acc += (int)hist[b]; if (k2 < acc) { sc->sel[1] = b; break; } }
+        }
+    }
+    lds_barrier();
+}
+
+// The same for histograms of up to 1024 * NQ bins, held in registers: thread t owns bins
+// [4 NQ t, 4 NQ (t+1)) (NQ 16-byte LDS reads), so the prefix scan, the search inside the owning
+// thread and the weighted sum sum(count * bin) all run without touching LDS again.  cnt[] is
+// left to the caller (MAD histogram) and *wsum_out gets sum(count * bin) when `weighted`;
+// that sum is kept in 32 bits: the caller guarantees samples * bins < 2^31.
+// `nb4` = number of allocated bins, a multiple of 4 (bins past the real ones are zero).
+template <int NQ>
+__device__ __forceinline__ void rank_select2_regs(const unsigned *hist, int nb4, int k1, int k2, Scratch *sc, int parity,
+                                                  bool weighted, long long *wsum_out, unsigned (&cnt)[4 * NQ])
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b0 = tid * 4 * NQ;
+#pragma unroll
+    for (int j = 0; j < NQ; j++) {
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (b0 + 4 * j < nb4) q = *(const uint4 *)(hist + b0 + 4 * j);
+        cnt[4 * j] = q.x; cnt[4 * j + 1] = q.y; cnt[4 * j + 2] = q.z; cnt[4 * j + 3] = q.w;
+    }
+    int local = 0, wloc = 0;
+#pragma unroll
+    for (int i = 0; i < 4 * NQ; i++) { local += (int)cnt[i]; wloc += (int)cnt[i] * (b0 + i); }
+    const int inc = wave_incl_scan(local, lane);
+    int winc = 0;
+    if (weighted) winc = wave_incl_scan(wloc, lane);
+    if (lane == 63) { sc->wsum[parity][w] = inc; sc->wred[w] = (long long)winc; }
+    lds_barrier();
+    int base = 0;
+    long long wtot = 0;
+#pragma unroll
+    for (int i = 0; i < NWAVE; i++) {
+        const int t = sc->wsum[parity][i];
+        if (i < w) base += t;
+        wtot += sc->wred[i];
+    }
+    if (wsum_out) *wsum_out = wtot;
+    const int pre = base + inc - local;
+    if (local > 0) {
+        if (k1 >= pre && k1 < pre + local) {
+            int acc = pre, idx = b0;
+#pragma unroll
+            for (int i = 0; i < 4 * NQ; i++) { acc += (int)cnt[i]; idx += (acc <= k1) ? 1 : 0; }
+            sc->sel[0] = idx;
+        }
+        if (k2 >= pre && k2 < pre + local) {
+            int acc = pre, idx = b0;
+#pragma unroll
+            for (int i = 0; i < 4 * NQ; i++) { acc += (int)cnt[i]; idx += (acc <= k2) ? 1 : 0; }
+            sc->sel[1] = idx;
         }
     }
     lds_barrier();
@@ -242,7 +298,9 @@ __device__ __forceinline__ void put8(P *dst, const unsigned (&q)[4], int al)
 }
 
 // WINDOWED: statistics over filtered samples [t0, t1) only (dRNA_segmenter.py:109-110)
-template <bool LDSCOMP, bool WINDOWED>
+// MEDMAD: the medmad variant (its own instantiation: it shares no statistics code with the
+// mean/std variants, and one kernel carrying both runs out of registers)
+template <bool LDSCOMP, bool WINDOWED, bool MEDMAD>
 __global__ __launch_bounds__(TPB, 8) __attribute__((amdgpu_num_sgpr(80)))
 void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *__restrict__ len, int nreads,
                 int lo, int hi, int mode, double std_scale, int vec_ok, int t0, int t1,
@@ -253,13 +311,18 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     Scratch *sc = (Scratch *)lds_raw;
     unsigned *hist = (unsigned *)(lds_raw + sizeof(Scratch));
     const int nbins = max(0, hi - lo - 1);                 // values lo+1 .. hi-1
-    unsigned *dev = hist + nbins;                          // medmad: 2*nbins+1 bins of |2x - 2med|
-    const int ndev = (mode == SK_PREP_MEDMAD) ? 2 * nbins + 1 : 0;
-    int16_t *lcomp = (int16_t *)(hist + nbins + ndev + ((4 - ((nbins + ndev) & 3)) & 3));   // 16-byte aligned
+    const int nb4 = (nbins + 3) & ~3;                      // (every LDS array starts 16-byte aligned)
+    unsigned *dev = hist + nb4;                            // medmad: 2*nbins+1 bins of |2x - 2med|
+    const int ndev = MEDMAD ? 2 * nbins + 1 : 0;
+    const int ndev4 = (ndev + 3) & ~3;
+    int16_t *lcomp = (int16_t *)(dev + ndev4);
+    // histograms small enough to be ranked from registers (rank_select2_regs)
+    const bool small_hist = nbins <= 2048 && ndev <= 4096;
+    bool dirty = true;                                     // histograms need zeroing before use
     unsigned *hist_v = hist - (lo + 1);                    // hist_v[x] counts value x
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const bool to_global = !(LDSCOMP && (mode == SK_PREP_SEGMENT || mode == SK_PREP_DRNA));
+    const bool to_global = MEDMAD || !(LDSCOMP && (mode == SK_PREP_SEGMENT || mode == SK_PREP_DRNA));
     if (!WINDOWED) { t0 = 0; t1 = 0x7fffffff; }
     // bit 0: sig rows 16-byte aligned, bit 1: comp rows too
     const bool in_vec = (vec_ok & 1) != 0, out_vec = (vec_ok & 2) != 0;
@@ -296,7 +359,8 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     const int M = Mnext;
     const int16_t *row = sig + (int64_t)r * stride;
     int16_t *crow = comp + (int64_t)r * stride;
-    for (int b = tid; b < nbins + ndev; b += TPB) hist[b] = 0u;
+    if (dirty) for (int b = tid; b < nb4 + ndev4; b += TPB) hist[b] = 0u;
+    dirty = false;
     if (tid < 4) sc->sel[tid] = 0;
     lds_barrier();
 
@@ -391,19 +455,47 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     }
 
     // ---- median: ranks (ns-1)/2 and ns/2 of the value histogram -----------------------
-    rank_select2(hist, nbins, (ns - 1) / 2, ns / 2, sc, 0);
+    // (registers when the histograms are small; every thread then clears the bins it owns, so the
+    // next read starts from zeroed histograms without a separate pass)
+    const bool regs = small_hist && M < (1 << 19);         // sum(count * bin) stays below 2^31
+    long long S = 0;
+    unsigned cnt[8];
+    const int hb0 = tid * 8;                               // first bin this thread owns
+    if (regs) {
+        long long wsum;
+        rank_select2_regs<2>(hist, nb4, (ns - 1) / 2, ns / 2, sc, 0, !MEDMAD, &wsum, cnt);
+        S = wsum + (long long)ns * (lo + 1);
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            if (hb0 + 4 * j < nb4) *(uint4 *)(hist + hb0 + 4 * j) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        rank_select2(hist, nbins, (ns - 1) / 2, ns / 2, sc, 0);
+        dirty = true;
+    }
     const int med2 = (sc->sel[0] + lo + 1) + (sc->sel[1] + lo + 1);    // 2 * median, exact
     const double median = (double)med2 * 0.5;
     lds_barrier();
 
-    if (mode == SK_PREP_MEDMAD) {
+    if constexpr (MEDMAD) {
         // MAD from the value histogram: |x - med| = |2x - med2| / 2
-        for (int b = tid; b < nbins; b += TPB) {
-            const unsigned cb = hist[b];
-            if (cb) atomicAdd(&dev[abs(2 * (b + lo + 1) - med2)], cb);
+        if (regs) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (cnt[i]) atomicAdd(&dev[abs(2 * (hb0 + i + lo + 1) - med2)], cnt[i]);
+            lds_barrier();
+            unsigned dcnt[16];
+            rank_select2_regs<4>(dev, ndev4, (ns - 1) / 2, ns / 2, sc, 1, false, nullptr, dcnt);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (tid * 16 + 4 * j < ndev4) *(uint4 *)(dev + tid * 16 + 4 * j) = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            for (int b = tid; b < nbins; b += TPB) {
+                const unsigned cb = hist[b];
+                if (cb) atomicAdd(&dev[abs(2 * (b + lo + 1) - med2)], cb);
+            }
+            lds_barrier();
+            rank_select2(dev, ndev, (ns - 1) / 2, ns / 2, sc, 1);
         }
-        lds_barrier();
-        rank_select2(dev, ndev, (ns - 1) / 2, ns / 2, sc, 1);
         const double mad = (double)(sc->sel[0] + sc->sel[1]) * 0.25;   // (d1/2 + d2/2) / 2, exact
         pr.center = median;
         pr.scale = mad * 1.4826;                                       // MotifSeq.py:196
@@ -413,16 +505,18 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
         continue;
     }
 
+    if constexpr (!MEDMAD) {
     // ---- mean (exact integer sum, taken from the histogram) and numpy-order std -----------
-    long long isum = 0;
-    for (int b = tid; b < nbins; b += TPB) isum += (long long)hist[b] * (long long)(b + lo + 1);
+    if (!regs) {
+        long long isum = 0;
+        for (int b = tid; b < nbins; b += TPB) isum += (long long)hist[b] * (long long)(b + lo + 1);
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) isum += __shfl_xor(isum, d);
-    if (lane == 0) sc->wred[w] = isum;
-    lds_barrier();
-    long long S = 0;
+        for (int d = 32; d >= 1; d >>= 1) isum += __shfl_xor(isum, d);
+        if (lane == 0) sc->wred[w] = isum;
+        lds_barrier();
 #pragma unroll
-    for (int i = 0; i < NWAVE; i++) S += sc->wred[i];
+        for (int i = 0; i < NWAVE; i++) S += sc->wred[i];
+    }
     const double mean = (double)S / (double)ns;
     const int16_t *src = LDSCOMP ? (const int16_t *)lcomp : (const int16_t *)crow;
     const double ssq = numpy_sum(ns, sc, [&](int i) {
@@ -468,6 +562,7 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
         if (lane == 0) maskT[(int64_t)(i >> 6) * mask_rows + r] = bits;
     }
     lds_barrier();                                       // LDS is reused by the next read
+    }
     }
 }
 
@@ -684,8 +779,8 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
 {
     if (nreads <= 0) return SK_OK;
     const int64_t nbins = (int64_t)hi - (int64_t)lo - 1 > 0 ? (int64_t)hi - lo - 1 : 0;
-    const int64_t words = (mode == SK_PREP_MEDMAD) ? 3 * nbins + 1 : nbins;
-    size_t lds = sizeof(Scratch) + (size_t)((words + 3) & ~(int64_t)3) * 4;
+    const int64_t nb4 = (nbins + 3) & ~(int64_t)3, ndev4 = (2 * nbins + 1 + 3) & ~(int64_t)3;
+    size_t lds = sizeof(Scratch) + (size_t)(nb4 + (mode == SK_PREP_MEDMAD ? ndev4 : 0)) * 4;
     if (lds > 160 * 1024)
         return sk_fail(SK_ERR_UNSUPPORTED,
                        "outlier limits (%d, %d) span %lld integer values: the LDS histogram holds %d (%s)",
@@ -699,8 +794,9 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
     const bool ldscomp = mode != SK_PREP_MEDMAD && lds + lds_comp <= 40 * 1024;
     if (ldscomp) lds += lds_comp;
     const bool windowed = t0 > 0 || t1 < 0x7fffffff;
-    auto fn = ldscomp ? (windowed ? k_prep_i16<true, true> : k_prep_i16<true, false>)
-                      : (windowed ? k_prep_i16<false, true> : k_prep_i16<false, false>);
+    auto fn = (mode == SK_PREP_MEDMAD) ? k_prep_i16<false, false, true>
+              : ldscomp ? (windowed ? k_prep_i16<true, true, false> : k_prep_i16<true, false, false>)
+                        : (windowed ? k_prep_i16<false, true, false> : k_prep_i16<false, false, false>);
     if (lds > 64 * 1024)
         SK_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent grid: as many workgroups as the chip holds (8 x 256 threads per CU, LDS permitting)
@@ -711,6 +807,7 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
     // not have to divide the grid; SK_PREP_ROUNDS is a tuning override
     int rounds = 6;
     if (const char *e = getenv("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
+    if (const char *e = getenv("SK_PREP_PERCU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }
     long long g = (long long)c->num_cu * per_cu * rounds;
     int grid = g > nreads ? nreads : (int)g;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(TPB), lds, c->stream, d_sig, stride, d_len, nreads,
