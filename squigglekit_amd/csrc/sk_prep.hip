@@ -64,6 +64,15 @@ __device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/)
     return v;
 }
 
+// lane i <- lane i + N inside a row of 16 (lanes without a source keep their own value)
+template <int N>
+__device__ __forceinline__ double dpp_shl_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x100 + N, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x100 + N, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 // Block-wide exclusive scan of one int per thread; returns exclusive prefix, *total = block sum.
 __device__ __forceinline__ int block_excl_scan(int v, int *wsum /*[NWAVE]*/, int *total)
 {
@@ -227,9 +236,10 @@ __device__ double pairwise_chunk(int m, Scratch *sc, Term term)
         double r = term(s + j);
         const int full = len - (len % 8);
         for (int i = 8; i < full; i += 8) r += term(s + i + j);
-        r += __shfl_xor(r, 1);                      // (r0+r1) (r2+r3) (r4+r5) (r6+r7)
-        r += __shfl_xor(r, 2);                      // ((r0+r1)+(r2+r3)) ...
-        r += __shfl_xor(r, 4);
+        // lane j = 0 of the group needs ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)): three DPP shifts
+        r += dpp_shl_f64<1>(r);                     // (r0+r1) . (r2+r3) . (r4+r5) . (r6+r7) .
+        r += dpp_shl_f64<2>(r);                     // ((r0+r1)+(r2+r3)) . . . ((r4+r5)+(r6+r7)) ...
+        r += dpp_shl_f64<4>(r);
         if (j == 0) {
             for (int i = full; i < len; i++) r += term(s + i);
             sc->node_sum[id] = r;
