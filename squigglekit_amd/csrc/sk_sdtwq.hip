@@ -221,8 +221,9 @@ void k_sdtw_q(const sdtw_kargs a)
 // ---------------------------------------------------------------------------------------------
 // pass W
 // ---------------------------------------------------------------------------------------------
+// (four waves per SIMD: the two phases together want ~140 VGPRs; capping at 96 spills into the loops)
 template <int L, int R, int FEED>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R <= 13 ? 4 : 3, 8)))
 void k_sdtw_w(const sdtw_kargs a)
 {
     constexpr int G = 64 / L;
@@ -289,13 +290,85 @@ void k_sdtw_w(const sdtw_kargs a)
     const bool screened = (n > 0) && (a.qflag[r - a.read0] == 0) && (b < QSAFE) && (jhi >= jlo) &&
                           (jhi - jlo <= a.wmax);
 
-    int tbase = 0, tlast = -1, c0 = 0;
+    int tbase = 0, tlast = -1, c0 = 0, npre = 0;
     if (screened) {
-        c0 = max(0, jlo - a.span) / a.ck;
+        const int tx = max(0, jlo - a.span);        // where the exact recurrence has to start
+        c0 = tx / a.ck;
         if (c0 > a.nck) c0 = a.nck;
         tbase = c0 * a.ck;
         tlast = jhi + L - 1;
+        if (c0 > 0) npre = (tx - tbase) / L;        // whole blocks between the checkpoint and tx
     }
+    const bool shortlane = l < a.P;
+
+    // ---- pre-roll: from the checkpoint to the block that holds tx in fixed point -------------------
+    // The checkpoints are ck steps apart; running the remaining (on average ck/2) steps with the
+    // exact FP64 recurrence would cost four times what the screening recurrence does, so the
+    // systolic state is first advanced in fixed point.  Groups of one wave need different numbers of
+    // blocks: a group loads its checkpoint in the iteration in which its turn starts (what it
+    // computed before on never-initialised state is overwritten), so all groups finish together.
+    unsigned Qs[R];                                 // screening state: R cells, lane l-1's row, diagonal
+    unsigned botq = QINF, diagq = QINF;
+#pragma unroll
+    for (int k = 0; k < R; k++) Qs[k] = QINF;
+    const unsigned *cp = a.ckq + (((int64_t)(r - a.read0) * a.nck + (c0 > 0 ? c0 - 1 : 0)) * L + l) * CKW;
+    auto load_ckpt = [&]() {
+#pragma unroll
+        for (int k = 0; k < R; k++) Qs[k] = cp[k];
+        botq = cp[R]; diagq = cp[R + 1];
+    };
+    int maxpre = npre;
+#pragma unroll
+    for (int d = L; d < 64; d <<= 1) maxpre = max(maxpre, __shfl_xor(maxpre, d));
+    maxpre = __builtin_amdgcn_readfirstlane(maxpre);
+    if (maxpre > 0) {
+        const double inv_scale = 1.0 / scale;
+        const int nlast = max(n - 1, 0);
+        auto toq = [&](int idx) -> unsigned {       // the screening pass's image of sample idx
+            if (idx < 0 || idx >= n) return QINF;
+            double v;
+            if constexpr (FEED == SK_FEED_I16)           v = ((double)s16[min(idx, nlast)] - center) * inv_scale;
+            else if constexpr (FEED == SK_FEED_F64_NORM) v = (s64[min(idx, nlast)] - center) * inv_scale;
+            else                                         v = s64[min(idx, nlast)];
+            return (fabs(v) < QLIM) ? qimg(v) : QINF;
+        };
+        unsigned xq[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) xq[k] = a.xlayq[l * R + k];
+        unsigned Qn[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) Qn[k] = QINF;
+        unsigned yq = QINF, Fq = QINF;
+        const int startblk = maxpre - npre;         // my group's first block
+        auto qstep = [&](const unsigned (&old)[R], unsigned (&nw)[R]) {
+            yq = (unsigned)dpp_i32<SHR>((int)Fq, (int)yq);
+            Fq = (unsigned)dpp_i32<ROL>((int)Fq, (int)Fq);
+            const unsigned upq = (unsigned)__builtin_amdgcn_update_dpp(0, (int)botq, SHR, 0xF, 0xF, true);
+            qcolumn<R>(old, nw, xq, yq, diagq, upq);
+            diagq = upq;
+            if constexpr (R >= 2) botq = shortlane ? nw[R - 2] : nw[R - 1];
+            else                  botq = shortlane ? upq : nw[0];
+        };
+        for (int pb = 0; pb < maxpre; pb++) {
+            const int t0 = tbase + (pb - startblk) * L;
+            if (pb == startblk && npre > 0) {
+                load_ckpt();
+                yq = toq(t0 - 1 - l);               // the sample this lane held after step t0 - 1
+                Fq = toq(t0 + l);
+            }
+            const unsigned Fnext = toq(t0 + L + l);
+#pragma unroll 1
+            for (int q = 0; q < L; q += 2) {        // L is even: after two steps the roles are back
+                qstep(Qs, Qn);
+                qstep(Qn, Qs);
+            }
+            Fq = Fnext;
+        }
+    }
+    if (c0 > 0 && npre == 0) load_ckpt();
+    tbase += npre * L;
+    asm volatile("" ::: "memory");                  // keep the exact phase's loads (and registers) below
+
     int nsteps = tlast - tbase + 1;
     if (nsteps < 0) nsteps = 0;
 #pragma unroll
@@ -306,7 +379,6 @@ void k_sdtw_w(const sdtw_kargs a)
     double x[R];
 #pragma unroll
     for (int k = 0; k < R; k++) x[k] = a.xlay[l * R + k];
-    const bool shortlane = l < a.P;
 
     auto fetch = [&](int idx) -> double {
         if (idx < 0 || idx >= n) return INF;
@@ -327,11 +399,10 @@ void k_sdtw_w(const sdtw_kargs a)
     int    diagS = (l == 0) ? tbase : -1;
     double y = INF;
     if (c0 > 0) {
-        const unsigned *cp = a.ckq + (((int64_t)(r - a.read0) * a.nck + (c0 - 1)) * L + l) * CKW;
 #pragma unroll
-        for (int k = 0; k < R; k++) D[k] = lb(cp[k]);
-        botD = lb(cp[R]);
-        if (l > 0) diagD = lb(cp[R + 1]);           // lane 0's diag is the virtual row: exactly 0
+        for (int k = 0; k < R; k++) D[k] = lb(Qs[k]);
+        botD = lb(botq);
+        if (l > 0) diagD = lb(diagq);               // lane 0's diag is the virtual row: exactly 0
         if (R == 1 && l == 0 && shortlane) { botD = 0.0; botS = tbase; }   // forwards the virtual row
         y = fetch(tbase - 1 - l);                   // the sample this lane held after step tbase-1
     }
