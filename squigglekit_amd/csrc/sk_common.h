@@ -50,6 +50,9 @@ struct sk_ctx {
     sk_buf misc;
     sk_buf ckpt;      // DTW checkpoints (systolic state dumps: doubles or fixed-point units)
     sk_buf motifq;    // fixed-point motif layout
+    sk_buf motif64;   // the motif laid out for 64 lanes (retry pass of a short motif)
+    bool   motif64_valid = false;
+    std::vector<double> motif64_host;
     sk_buf lastq;     // screening pass: last-row costs per column
     sk_buf qflag;     // screening pass: per-read "left the fixed-point range" flags
     sk_buf retry;     // DTW pass-B retry counter + read list

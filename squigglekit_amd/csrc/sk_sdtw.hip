@@ -317,6 +317,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
         SK_HIP(hipMemcpyAsync(c->motif.p, c->motif_host.data(), c->motif_host.size() * sizeof(double),
                               hipMemcpyHostToDevice, c->stream));
         c->motif_src.assign(a->motif, a->motif + N);
+        c->motif64_valid = false;
     }
 
     sdtw_kargs k;
@@ -375,7 +376,27 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
         c->last_retry = nretry;
         if (nretry > 0) {                                  // exact single pass on the uncertified reads
             k.read0 = 0; k.nreads = nretry; k.ridx = cnt + 1;
-            if ((rc = launch(c, ff, k, L))) return rc;
+            // A handful of reads cannot fill the chip, so what counts is the latency of one sweep:
+            // spread each read over 64 lanes (R64 rows per lane instead of R) when the list is short.
+            const int R64 = (N + 63) / 64, P64 = 64 * R64 - N;
+            sdtw_fn f64 = (L == 16 && nretry <= 8192) ? pick_any(a->feed, 64, R64, MODE_FULL) : nullptr;
+            if (f64) {
+                if (!c->motif64_valid) {
+                    SK_HIP(hipStreamSynchronize(c->stream));      // an earlier launch may still read it
+                    c->motif64_host.assign((size_t)64 * R64, 0.0);
+                    int row = 0;
+                    for (int l = 0; l < 64; l++) {
+                        const int rows = (l < P64) ? R64 - 1 : R64;
+                        for (int kk = 0; kk < rows; kk++) c->motif64_host[(size_t)l * R64 + kk] = a->motif[row++];
+                    }
+                    if ((rc = sk_reserve(c, &c->motif64, c->motif64_host.size() * sizeof(double)))) return rc;
+                    SK_HIP(hipMemcpyAsync(c->motif64.p, c->motif64_host.data(),
+                                          c->motif64_host.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                    c->motif64_valid = true;
+                }
+                k.xlay = (const double *)c->motif64.p; k.P = P64;
+                if ((rc = launch(c, f64, k, 64))) return rc;
+            } else if ((rc = launch(c, ff, k, L))) return rc;
         }
         SK_HIP(hipEventRecord(c->ev[3], c->stream));
         return SK_OK;
