@@ -1,0 +1,76 @@
+"""GPU parity for the layout corners of the filter + statistics kernel: row strides that are not
+a multiple of 8 samples (scalar loads, 2-byte stores), reads without a single outlier (every
+wavefront takes the packed all-survive path, 16-byte stores), and outliers placed on the tile /
+wavefront / vector boundaries so that each store alignment (16, 4, 2 bytes) is exercised."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _reads(R, M, seed, clean):
+    from squigglekit_amd import synth
+    sig = synth.squiggle_batch(R, M, seed)
+    if clean:
+        sig = np.clip(sig, 350, 650).astype(np.int16)         # nothing for either filter to reject
+    return np.ascontiguousarray(sig)
+
+
+def _poke(sig):
+    """Outliers at chosen raw positions, a different pattern per read."""
+    R, M = sig.shape
+    spots = [0, 1, 7, 8, 9, 15, 16, 511, 512, 513, 1023, 1024, 2047, 2048, 2049, M - 2, M - 1]
+    for r in range(R):
+        chosen = [p for i, p in enumerate(spots) if (r >> (i % 5)) & 1 and 0 <= p < M]
+        if r % 7 == 3:
+            chosen += list(range(100, 100 + (r % 23)))          # a run of rejects: odd and even shifts
+        sig[r, chosen] = -7 if r % 2 else 2000
+    return sig
+
+
+@pytest.mark.parametrize("M", [4000, 4001, 2047, 4093, 520])
+@pytest.mark.parametrize("clean", [True, False])
+def test_segmenter_layout_corners(gpu, ora, M, clean):
+    from squigglekit_amd import api
+    sig = _reads(96, M, 4100 + M, clean)
+    if not clean:
+        sig = _poke(sig)
+    lens = np.full(96, M, dtype=np.int32)
+    lens[5] = M - 1; lens[6] = M - 7; lens[7] = 9; lens[8] = 8
+    segs, nsegs = api.segment_batch(sig, lens)
+    osegs, onsegs = ora.segment_batch_i16(sig, lens, max_segs=segs.shape[1])
+    assert np.array_equal(nsegs, onsegs), np.nonzero(nsegs != onsegs)[0][:8]
+    for r in range(96):
+        assert np.array_equal(segs[r, :nsegs[r]], osegs[r, :nsegs[r]]), r
+
+
+@pytest.mark.parametrize("M", [4000, 4001, 2047, 520])
+@pytest.mark.parametrize("clean", [True, False])
+@pytest.mark.parametrize("scale", ["medmad", "zscale"])
+def test_motifseq_layout_corners(gpu, ora, example_model, M, clean, scale):
+    from squigglekit_amd import api
+    sig = _reads(64, M, 5200 + M, clean)
+    if not clean:
+        sig = _poke(sig)
+    lens = np.full(64, M, dtype=np.int32)
+    lens[3] = M - 3; lens[4] = 300; lens[5] = 8
+    got = api.motifseq_batch(sig, lens, example_model, scale=scale)
+    want = ora.motifseq_batch_i16(sig, lens, example_model, scale_mode={"medmad": 0, "zscale": 1}[scale])
+    assert np.array_equal(got["n"], want["n"])
+    ok = (got["flags"] & 2) == 0             # MAD == 0: the reference divides by zero (flagged, not compared)
+    assert ok.sum() >= 60
+    assert np.array_equal(got["start"][ok], want["start"][ok]) and np.array_equal(got["end"][ok], want["end"][ok])
+    nan = np.isnan(got["dist"]) & np.isnan(want["dist"])
+    assert np.all(((got["dist"] == want["dist"]) | nan)[ok])
+
+
+def test_normalised_signal_matches_oracle_on_odd_stride(gpu, ora):
+    """The compacted + normalised signal itself (what -x prints), odd stride, shifted alignments."""
+    from squigglekit_amd import api
+    sig = _poke(_reads(16, 1237, 77, clean=False))
+    for r in range(16):
+        f = ora.scale_outliers(sig[r], 0, 1200)
+        for scale in ("medmad", "zscale"):
+            got = api.normalise(sig[r], scale=scale)
+            want = ora.medmad(f)[0] if scale == "medmad" else ora.zscale(f)[0]
+            assert got.shape == want.shape and np.array_equal(got, want), (r, scale)
