@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--motif", type=int, default=200, help="motif points")
     ap.add_argument("--scale", default="medmad", choices=["medmad", "zscale"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=1,
+                    help="additionally time the CPU baseline over this many host threads (reads split "
+                         "across threads; reported as cpu_baseline.threaded, the headline stays 1 core)")
     return ap.parse_args()
 
 
@@ -196,6 +199,18 @@ def main():
                          "filter+medmad+mlpy dtw_subsequence (full matrix malloc per call), gcc -O2, 1 thread, %.1f s"
                          % (done, M, N, dt),
                "host_cores_total": os.cpu_count()}
+        if a.cpu_threads > 1 and a.cpu_seconds > 0:
+            from concurrent.futures import ThreadPoolExecutor
+            T = a.cpu_threads
+            per = max(1, min(S // T, int(a.cpu_seconds * cpu["value"])))      # about cpu_seconds per thread
+            parts = [(i * per, (i + 1) * per) for i in range(T)]
+            with ThreadPoolExecutor(T) as ex:                                 # ctypes calls release the GIL
+                t1 = time.perf_counter()
+                list(ex.map(lambda ab: ora.motifseq_batch_i16(sample[ab[0]:ab[1]], lens[ab[0]:ab[1]], motif,
+                                                              scale_mode=mode), parts))
+                dtt = time.perf_counter() - t1
+            cpu["threaded"] = {"value": T * per / dtt, "unit": "reads/s", "cores": T,
+                               "sample": "%d reads on each of %d threads, %.1f s" % (per, T, dtt)}
         cells = float(N) * float(np.mean(got["n"]))
         # whole DTW stage expressed in the reference's arithmetic: 4 FP64 ops per cell
         valu = {"bound": "valu_f64_equivalent", "achieved": R * cells * 4 / (main_ms * 1e-3) / 1e12,
