@@ -83,6 +83,10 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
                        int32_t nreads, int32_t lo, int32_t hi, int mode, double std_scale,
                        int16_t *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_stride,
                        int32_t t0 = 0, int32_t t1 = 0x7fffffff);   // statistics window (filtered index)
+// wavefront-per-read medmad variant (sk_prepw.hip): same results; returns 1 (nothing launched) when
+// the configuration is outside its range and the caller has to use the workgroup-per-read kernel
+int sk_launch_prepw_medmad(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len,
+                           int32_t nreads, int32_t lo, int32_t hi, int16_t *d_comp, sk_prep *d_prep);
 // f64 ragged: read r is sig[off[r]..off[r+1]); comp uses the same offsets.
 int sk_launch_prep_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads,
                        double lo, double hi, int mode, double std_scale,

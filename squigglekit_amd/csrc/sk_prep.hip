@@ -788,6 +788,10 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
                        int32_t t0, int32_t t1)
 {
     if (nreads <= 0) return SK_OK;
+    if (mode == SK_PREP_MEDMAD && t0 <= 0 && t1 == 0x7fffffff) {      // medmad: one wavefront per read
+        const int rc = sk_launch_prepw_medmad(c, d_sig, stride, d_len, nreads, lo, hi, d_comp, d_prep);
+        if (rc != 1) return rc;
+    }
     const int64_t nbins = (int64_t)hi - (int64_t)lo - 1 > 0 ? (int64_t)hi - lo - 1 : 0;
     const int64_t nb4 = (nbins + 3) & ~(int64_t)3, ndev4 = (2 * nbins + 1 + 3) & ~(int64_t)3;
     size_t lds = sizeof(Scratch) + (size_t)(nb4 + (mode == SK_PREP_MEDMAD ? ndev4 : 0)) * 4;
