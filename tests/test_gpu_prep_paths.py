@@ -46,9 +46,12 @@ def test_segmenter_layout_corners(gpu, ora, M, clean):
 
 @pytest.mark.parametrize("M", [4000, 4001, 2047, 520])
 @pytest.mark.parametrize("clean", [True, False])
-@pytest.mark.parametrize("scale", ["medmad", "zscale"])
-def test_motifseq_layout_corners(gpu, ora, example_model, M, clean, scale):
+@pytest.mark.parametrize("scale", ["medmad", "zscale", "medmad-workgroup"])
+def test_motifseq_layout_corners(gpu, ora, example_model, M, clean, scale, monkeypatch):
     from squigglekit_amd import api
+    if scale == "medmad-workgroup":         # medmad on the workgroup-per-read kernel instead of the wave-per-read one
+        monkeypatch.setenv("SK_PREP_BLOCK", "1")
+        scale = "medmad"
     sig = _reads(64, M, 5200 + M, clean)
     if not clean:
         sig = _poke(sig)
