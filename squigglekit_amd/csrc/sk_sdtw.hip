@@ -120,6 +120,22 @@ void k_sdtw(const sdtw_kargs a)
     int    botS = (R == 1 && l == 0 && shortlane) ? 0 : -1;
     double diagD = (l == 0) ? 0.0 : INF;            // lane l-1's bottom one column back
     int    diagS = (l == 0) ? tbase : -1;           // virtual row -1 at column tbase-1: S = column + 1
+    // MODE_CHAIN, chunks below the first: the row above lane 0 is the last row of the previous chunk
+    // (per column, from memory) instead of the virtual row; it does not exist at column -1
+    bool chained = false;
+    const double *pD = nullptr;  const int32_t *pS = nullptr;
+    double PFD = 0.0;  int PFS = 0;
+    if constexpr (MODE == MODE_CHAIN) {
+        chained = a.prevD != nullptr;
+        if (chained) {
+            pD = a.prevD + (int64_t)(r - a.read0) * a.row_stride;
+            pS = a.prevS + (int64_t)(r - a.read0) * a.row_stride;
+            if (l == 0) { diagD = INF; diagS = -1; }
+            if (R == 1 && l == 0 && shortlane) { botD = INF; botS = -1; }
+            PFD = (l < n) ? pD[l] : INF;
+            PFS = (l < n) ? pS[l] : -1;
+        }
+    }
     double y = INF;                                 // columns < 0: cost +inf keeps D at +inf
     double best = INF;  int bestS = -1, bestJ = -1;
 
@@ -149,6 +165,14 @@ void k_sdtw(const sdtw_kargs a)
     double F = fetch(tbase + l);
     for (int blk = 0; blk < nblk; blk++) {
         const double Fnext = fetch(tbase + (blk + 1) * L + l);   // in flight during the L steps below
+        double PFDn = 0.0;  int PFSn = 0;
+        if constexpr (MODE == MODE_CHAIN) {
+            if (chained) {
+                const int idx = tbase + (blk + 1) * L + l;
+                PFDn = (idx < n) ? pD[idx] : INF;
+                PFSn = (idx < n) ? pS[idx] : -1;
+            }
+        }
         if constexpr (MODE == MODE_DIST) {
             // checkpoint c (>= 1) = state at the beginning of step c*ck (ck is a multiple of L)
             const int t0 = blk * L;
@@ -165,9 +189,15 @@ void k_sdtw(const sdtw_kargs a)
             // ---- systolic shift: sample and lane l-1's bottom row arrive -------
             y = dpp_f64<SHR>(F, y);                         // lane 0 takes sample t from the feed
             F = dpp_f64<ROL>(F, F);
-            const double upD = dpp_f64<SHR>(0.0, botD);     // lane 0: virtual row -1 (D = 0)
+            double topD = 0.0;  int topS = t + 1;           // lane 0: virtual row -1 (D = 0, S = column + 1)
+            if constexpr (MODE == MODE_CHAIN) {
+                if (chained) { topD = PFD; topS = PFS; }    //   or the previous chunk's last row at column t
+                PFD = dpp_f64<ROL>(PFD, PFD);
+                PFS = dpp_i32<ROL>(PFS, PFS);
+            }
+            const double upD = dpp_f64<SHR>(topD, botD);
             int upS = 0;
-            if constexpr (TRACK) upS = dpp_i32<SHR>(t + 1, botS);   //   whose S is column + 1
+            if constexpr (TRACK) upS = dpp_i32<SHR>(topS, botS);
             // ---- R cells of column j = t - l ---------------------------------
             double dgD = diagD;  int dgS = diagS;           // (i-1, j-1)
             double uD = upD;     int uS = upS;              // (i-1, j)
@@ -210,14 +240,21 @@ void k_sdtw(const sdtw_kargs a)
                     best = D[R - 1]; bestJ = j;
                     if constexpr (TRACK) bestS = S[R - 1];
                 }
-                if constexpr (MODE == MODE_FULL) {
+                if constexpr (MODE == MODE_FULL || MODE == MODE_CHAIN) {
                     if (a.last_row != nullptr) {
                         if (l == L - 1 && slot == 0 && j >= 0 && j < n) a.last_row[j] = D[R - 1];
+                    }
+                }
+                if constexpr (MODE == MODE_CHAIN) {
+                    if (a.rowD != nullptr && live && l == L - 1 && j >= 0 && j < n) {
+                        a.rowD[(int64_t)(r - a.read0) * a.row_stride + j] = D[R - 1];
+                        a.rowS[(int64_t)(r - a.read0) * a.row_stride + j] = S[R - 1];
                     }
                 }
             }
         }
         F = Fnext;
+        if constexpr (MODE == MODE_CHAIN) { PFD = PFDn; PFS = PFSn; }
     }
 
     if (live && l == L - 1) {
@@ -261,6 +298,7 @@ sdtw_fn pick(int L, int R, int mode)
     }
     if (mode == MODE_FULL) return pick_r<64, FEED, MODE_FULL>(R);
     if (mode == MODE_DIST) return pick_r<64, FEED, MODE_DIST>(R);
+    if (mode == MODE_CHAIN) return pick_r<64, FEED, MODE_CHAIN>(R);
     return pick_r<64, FEED, MODE_START>(R);
 }
 
@@ -286,6 +324,83 @@ int launch(sk_ctx *c, sdtw_fn fn, const sdtw_kargs &k, int L)
 
 } // namespace
 
+// Motifs of more than 1024 points: chunks of 1024 rows (64 lanes x 16) are swept one after the other
+// with the exact single pass; the last row of a chunk (cost and start column, per read column) goes
+// through memory and enters the next chunk where the virtual row -1 enters the first.  Reads are
+// processed in batches so that the two row buffers stay within a fixed budget.
+static int launch_chained(sk_ctx *c, const sk_sdtw_args *a)
+{
+    const int N = a->nmotif;
+    const int CH = 64 * 16;
+    const int nchunks = (N + CH - 1) / CH;
+    // layouts of all chunks back to back; chunk i at lay_off[i]
+    std::vector<size_t> lay_off(nchunks);
+    std::vector<int> Rc(nchunks), Pc(nchunks);
+    size_t total = 0;
+    for (int i = 0; i < nchunks; i++) {
+        const int rows = (i + 1 < nchunks) ? CH : N - i * CH;
+        Rc[i] = (rows + 63) / 64;
+        Pc[i] = 64 * Rc[i] - rows;
+        lay_off[i] = total;
+        total += (size_t)64 * Rc[i];
+    }
+    const bool same = c->motif.p && c->motif_src.size() == (size_t)N &&
+                      memcmp(c->motif_src.data(), a->motif, (size_t)N * sizeof(double)) == 0;
+    if (!same) {
+        SK_HIP(hipStreamSynchronize(c->stream));
+        c->motif_host.assign(total, 0.0);
+        int row = 0;
+        for (int i = 0; i < nchunks; i++)
+            for (int l = 0; l < 64; l++) {
+                const int cnt = (l < Pc[i]) ? Rc[i] - 1 : Rc[i];
+                for (int k = 0; k < cnt; k++) c->motif_host[lay_off[i] + (size_t)l * Rc[i] + k] = a->motif[row++];
+            }
+        if (row != N) return sk_fail(SK_ERR_INVALID, "internal: motif layout mismatch");
+        int rc = sk_reserve(c, &c->motif, total * sizeof(double));
+        if (rc) return rc;
+        SK_HIP(hipMemcpyAsync(c->motif.p, c->motif_host.data(), total * sizeof(double), hipMemcpyHostToDevice,
+                              c->stream));
+        c->motif_src.assign(a->motif, a->motif + N);
+        c->motif64_valid = false;
+    }
+    // row buffers: two (ping-pong) of [batch][row_stride] doubles + ints
+    const int64_t row_stride = (a->max_len > 0 ? a->max_len : 1);
+    const size_t per_read = (size_t)row_stride * 12 * 2;
+    int64_t batch = (int64_t)(((size_t)6 << 30) / per_read);
+    if (batch > a->nreads) batch = a->nreads;
+    if (batch < 1) batch = 1;
+    int rc = sk_reserve(c, &c->ckpt, (size_t)batch * per_read);
+    if (rc) return rc;
+    double  *bufD[2] = {(double *)c->ckpt.p, (double *)c->ckpt.p + (size_t)batch * row_stride};
+    int32_t *bufS[2] = {(int32_t *)(bufD[1] + (size_t)batch * row_stride),
+                        (int32_t *)(bufD[1] + (size_t)batch * row_stride) + (size_t)batch * row_stride};
+    sdtw_kargs k;
+    memset(&k, 0, sizeof k);
+    k.samples = a->samples; k.stride = a->stride; k.off = a->off; k.prep = a->prep;
+    k.out = a->out; k.last_row = nullptr; k.row_stride = row_stride;
+    c->last_retry = 0;
+    c->prof_chunks = 0;
+    SK_HIP(hipEventRecord(c->ev[2], c->stream));
+    for (int64_t r0 = 0; r0 < a->nreads; r0 += batch) {
+        k.read0 = (int)r0;
+        k.nreads = (int)((a->nreads - r0 < batch) ? a->nreads - r0 : batch);
+        for (int i = 0; i < nchunks; i++) {
+            sdtw_fn fn = pick_any(a->feed, 64, Rc[i], MODE_CHAIN);
+            if (!fn) return sk_fail(SK_ERR_UNSUPPORTED, "no chained kernel for R=%d", Rc[i]);
+            k.xlay = (const double *)c->motif.p + lay_off[i];
+            k.P = Pc[i];
+            k.prevD = (i > 0) ? bufD[(i - 1) & 1] : nullptr;
+            k.prevS = (i > 0) ? bufS[(i - 1) & 1] : nullptr;
+            k.rowD = (i + 1 < nchunks) ? bufD[i & 1] : nullptr;
+            k.rowS = (i + 1 < nchunks) ? bufS[i & 1] : nullptr;
+            k.last_row = (i + 1 == nchunks && r0 == 0) ? a->last_row : nullptr;
+            if ((rc = launch(c, fn, k, 64))) return rc;
+        }
+    }
+    SK_HIP(hipEventRecord(c->ev[3], c->stream));
+    return SK_OK;
+}
+
 // Host side: lay the motif out per lane, pick (L, R), choose one or two passes, launch.
 int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
 {
@@ -295,8 +410,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     int L, R;
     if (N <= 16 * 16)      { L = 16; R = (N + 15) / 16; }
     else if (N <= 64 * 16) { L = 64; R = (N + 63) / 64; }
-    else return sk_fail(SK_ERR_UNSUPPORTED, "motif of %d points exceeds the %d this build keeps in registers",
-                        N, 64 * 16);
+    else return launch_chained(c, a);               // more rows than a wavefront keeps in registers
     const int P = L * R - N;                 // short lanes (own R-1 rows), always < L
 
     // The laid-out motif stays resident between calls; re-upload only when it changes.

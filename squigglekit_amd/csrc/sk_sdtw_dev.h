@@ -12,7 +12,7 @@ constexpr int DPP_ROW_SHL1  = 0x101;   // lane i <- lane i+1 inside a row of 16;
 constexpr int DPP_WAVE_SHL1 = 0x130;   // lane i <- lane i+1 across the wave; lane 63 keeps `old`
 constexpr int DPP_WAVE_ROL1 = 0x134;   // lane i <- lane i+1 across the wave (rotate)
 
-enum { MODE_FULL = 0, MODE_DIST = 1, MODE_START = 2 };
+enum { MODE_FULL = 0, MODE_DIST = 1, MODE_START = 2, MODE_CHAIN = 3 };   // CHAIN: FULL on one row chunk of a long motif
 
 // Fixed-point screening (sk_sdtwq.hip): one unit = 2^-22 of a normalised signal unit.
 constexpr int      QS     = 22;
@@ -70,6 +70,12 @@ struct sdtw_kargs {
     int32_t       *qflag;       // [slot]: 1 = a sample left the fixed-point range (|y| >= QLIM)
     unsigned       qerr;        // E: bound (in units) on |screening cost - exact cost| of any cell
     int            wmax;        // widest candidate-column range the window pass accepts
+    // row-chunked motifs (MODE_CHAIN): the last row of the chunk above / of this chunk, per column
+    const double  *prevD;       // [slot][row_stride] or nullptr (first chunk: virtual row -1)
+    const int32_t *prevS;
+    double        *rowD;        // [slot][row_stride] or nullptr (last chunk)
+    int32_t       *rowS;
+    int64_t        row_stride;
 };
 
 } // namespace

@@ -24,7 +24,8 @@ def _assert_hits(got, want, label=""):
         "%s distances within tol but not bit-identical (max dev %g)" % (label, dev.max())
 
 
-@pytest.mark.parametrize("nx", [1, 2, 5, 15, 16, 17, 31, 64, 100, 163, 200, 255, 256, 257, 320, 500, 777, 1024])
+@pytest.mark.parametrize("nx", [1, 2, 5, 15, 16, 17, 31, 64, 100, 163, 200, 255, 256, 257, 320, 500, 777, 1024,
+                                1025, 1100, 2048, 2049, 3333])   # > 1024: row-chunked sweeps
 def test_dtw_raw_vs_oracle(gpu, ora, nx):
     """mlpy boundary: dtw_subsequence(x, y) on pre-normalised float64 signals."""
     from squigglekit_amd import api
@@ -137,12 +138,10 @@ def test_long_reads_and_long_motif(gpu, ora):
     _assert_hits(got, want, "C5")
 
 
-def test_unsupported_and_invalid_are_loud(gpu):
+def test_invalid_is_loud(gpu):
     from squigglekit_amd import api
     from squigglekit_amd._lib import SquiggleKitError
     sig = np.full((1, 64), 500, dtype=np.int16)
-    with pytest.raises(SquiggleKitError):
-        api.motifseq_batch(sig, None, np.zeros(2000))          # motif too long for this build
     with pytest.raises(SquiggleKitError):
         api.motifseq_batch(sig, None, np.zeros(0))
 
@@ -269,3 +268,20 @@ def test_exact_two_pass_scheme_still_exact(gpu, ora, monkeypatch):
     got = api.dtw_subsequence_batch(motif, ys)
     for r in range(0, 264, 7):
         assert (got["dist"][r], got["start"][r], got["end"][r]) == ora.dtw_subsequence(motif, ys[r])
+
+
+def test_long_motif_int16_batch(gpu, ora):
+    """A 1 500-point motif (two chained row chunks) through the whole MotifSeq path: filter,
+    medmad / zscale, DTW; ragged lengths, an empty read, reads shorter than the motif."""
+    from squigglekit_amd import api, synth
+    motif = synth.synthetic_motif(1500, seed=11)
+    sig = synth.squiggle_batch(40, 5000, 8080, motif=motif[:400])
+    lens = np.full(40, 5000, dtype=np.int32)
+    lens[:6] = [0, 1, 700, 1499, 1500, 1501]
+    sig[7, :] = 0
+    for scale in ("medmad", "zscale"):
+        got = api.motifseq_batch(sig, lens, motif, scale=scale)
+        want = ora.motifseq_batch_i16(sig, lens, motif, scale_mode={"medmad": 0, "zscale": 1}[scale])
+        ok = (got["flags"] & 2) == 0             # MAD == 0 (the one-sample read): flagged, not compared
+        assert ok.sum() >= 38 and np.array_equal(got["n"], want["n"])
+        _assert_hits(got[ok], want[ok], "long motif %s" % scale)
