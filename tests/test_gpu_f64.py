@@ -73,6 +73,17 @@ def test_f64_and_i16_paths_agree(gpu, example_model):
     assert sa == sb
 
 
+def test_f64_and_i16_paths_agree_long_motif(gpu):
+    """Same through the chained row chunks of a 1 300-point motif (both sample feeds)."""
+    from squigglekit_amd import api, synth
+    motif = synth.synthetic_motif(1300, seed=5)
+    sig = synth.squiggle_batch(12, 3000, 4321, motif=motif[:300])
+    for scale in ("medmad", "zscale"):
+        a = api.motifseq_batch(sig, None, motif, scale=scale)
+        b = api.motifseq_reads_f64([sig[r].astype(float) for r in range(12)], motif, scale=scale)
+        assert np.array_equal(a, b), scale
+
+
 def test_normalise_f64_matches_reference_pA_row(gpu, ora, example_read):
     """The real read in pA: normalised signal equals the numpy/sklearn result the reference fed to DTW."""
     from squigglekit_amd import api
