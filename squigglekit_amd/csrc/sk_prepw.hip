@@ -11,9 +11,10 @@
 //   median   rank select on the histogram from registers (lane l owns bins [l*B, (l+1)*B)), DPP scan
 //   MAD      rank select on the histogram folded around the median -- no second histogram
 //
-// 6.7 -> 4.2 ms per 1 M reads x 4 000 samples.  (A mean/std + mask variant of this shape was built and
-// measured too: without an LDS copy its per-lane 2-byte global loads made it 2-3x slower than the
-// workgroup kernel, so zscale and the segmenter stay on k_prep_i16.)
+// 6.7 -> 3.9 ms per 1 M reads x 4 000 samples.  (Mean/std + mask variants of this shape were built and
+// measured too, bit-exact but slower than the workgroup kernel's 7.5 ms: 13-22 ms when the std / mask
+// passes re-read the samples from global memory with per-lane 2-byte loads, 10.4 ms with the compacted
+// read in LDS -- 12 KB per wave leave 13 waves per CU.  zscale and the segmenter stay on k_prep_i16.)
 //
 // Reference: scale_outliers MotifSeq.py:317-324, medmad MotifSeq.py:192-200.
 #include "sk_common.h"
