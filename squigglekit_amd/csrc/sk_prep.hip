@@ -93,26 +93,32 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wsum /*[NWAVE]*/, int
 
 // Find the bins holding ranks k1 <= k2 of a histogram (counts sum to n).  Result in sc->sel[0..1].
 // Every thread scans a contiguous slice of bins.
-__device__ void rank_select2(const unsigned *hist, int nbins, int k1, int k2, Scratch *sc, int parity)
+template <typename Count>
+__device__ __forceinline__ void rank_select2_fn(Count count, int nbins, int k1, int k2, Scratch *sc, int parity)
 {
     const int per = (nbins + TPB - 1) / TPB;
     const int b0 = threadIdx.x * per;
     const int b1 = min(nbins, b0 + per);
     int local = 0;
-    for (int b = b0; b < b1; b++) local += (int)hist[b];
+    for (int b = b0; b < b1; b++) local += (int)count(b);
     int total;
     int pre = block_excl_scan(local, sc->wsum[parity], &total);
     if (local > 0) {
         if (k1 >= pre && k1 < pre + local) {
             int acc = pre;
-            for (int b = b0; b < b1; b++) { acc += (int)hist[b]; if (k1 < acc) { sc->sel[0] = b; break; } }
+            for (int b = b0; b < b1; b++) { acc += (int)count(b); if (k1 < acc) { sc->sel[0] = b; break; } }
         }
         if (k2 >= pre && k2 < pre + local) {
             int acc = pre;
-            for (int b = b0; b < b1; b++) { acc += (int)hist[b]; if (k2 < acc) { sc->sel[1] = b; break; } }
+            for (int b = b0; b < b1; b++) { acc += (int)count(b); if (k2 < acc) { sc->sel[1] = b; break; } }
         }
     }
     lds_barrier();
+}
+
+__device__ void rank_select2(const unsigned *hist, int nbins, int k1, int k2, Scratch *sc, int parity)
+{
+    rank_select2_fn([&](int b) { return hist[b]; }, nbins, k1, k2, sc, parity);
 }
 
 // The same for histograms of up to 1024 * NQ bins, held in registers: thread t owns bins
@@ -322,12 +328,9 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     unsigned *hist = (unsigned *)(lds_raw + sizeof(Scratch));
     const int nbins = max(0, hi - lo - 1);                 // values lo+1 .. hi-1
     const int nb4 = (nbins + 3) & ~3;                      // (every LDS array starts 16-byte aligned)
-    unsigned *dev = hist + nb4;                            // medmad: 2*nbins+1 bins of |2x - 2med|
-    const int ndev = MEDMAD ? 2 * nbins + 1 : 0;
-    const int ndev4 = (ndev + 3) & ~3;
-    int16_t *lcomp = (int16_t *)(dev + ndev4);
+    int16_t *lcomp = (int16_t *)(hist + nb4);
     // histograms small enough to be ranked from registers (rank_select2_regs)
-    const bool small_hist = nbins <= 2048 && ndev <= 4096;
+    const bool small_hist = nbins <= 2048;
     bool dirty = true;                                     // histograms need zeroing before use
     unsigned *hist_v = hist - (lo + 1);                    // hist_v[x] counts value x
 
@@ -369,7 +372,7 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     const int M = Mnext;
     const int16_t *row = sig + (int64_t)r * stride;
     int16_t *crow = comp + (int64_t)r * stride;
-    if (dirty) for (int b = tid; b < nb4 + ndev4; b += TPB) hist[b] = 0u;
+    if (dirty) for (int b = tid; b < nb4; b += TPB) hist[b] = 0u;
     dirty = false;
     if (tid < 4) sc->sel[tid] = 0;
     lds_barrier();
@@ -475,9 +478,11 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
         long long wsum;
         rank_select2_regs<2>(hist, nb4, (ns - 1) / 2, ns / 2, sc, 0, !MEDMAD, &wsum, cnt);
         S = wsum + (long long)ns * (lo + 1);
+        if (!MEDMAD) {                                     // (medmad reads the histogram once more)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-            if (hb0 + 4 * j < nb4) *(uint4 *)(hist + hb0 + 4 * j) = make_uint4(0u, 0u, 0u, 0u);
+            for (int j = 0; j < 2; j++)
+                if (hb0 + 4 * j < nb4) *(uint4 *)(hist + hb0 + 4 * j) = make_uint4(0u, 0u, 0u, 0u);
+        }
     } else {
         rank_select2(hist, nbins, (ns - 1) / 2, ns / 2, sc, 0);
         dirty = true;
@@ -487,26 +492,24 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     lds_barrier();
 
     if constexpr (MEDMAD) {
-        // MAD from the value histogram: |x - med| = |2x - med2| / 2
-        if (regs) {
+        // MAD = median of |x - med|: rank select on the value histogram folded around the median.
+        // |2x - med2| takes the values 2t (med2 even) or 2t + 1 (odd); f(t) = count(left) + count(right).
+        const int odd = med2 & 1;
+        const int cl = ((med2 - odd) >> 1) - (lo + 1);                 // bin just below / at the median
+        const int cr = cl + odd;
+        rank_select2_fn([&](int t) -> unsigned {
+            const int bl = cl - t, br = cr + t;
+            unsigned c = 0u;
+            if (bl >= 0 && bl < nbins) c += hist[bl];
+            if (br >= 0 && br < nbins && (odd || t > 0)) c += hist[br];
+            return c;
+        }, nbins, (ns - 1) / 2, ns / 2, sc, 1);
+        if (regs) {                                                    // all reads done (barrier above)
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (cnt[i]) atomicAdd(&dev[abs(2 * (hb0 + i + lo + 1) - med2)], cnt[i]);
-            lds_barrier();
-            unsigned dcnt[16];
-            rank_select2_regs<4>(dev, ndev4, (ns - 1) / 2, ns / 2, sc, 1, false, nullptr, dcnt);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (tid * 16 + 4 * j < ndev4) *(uint4 *)(dev + tid * 16 + 4 * j) = make_uint4(0u, 0u, 0u, 0u);
-        } else {
-            for (int b = tid; b < nbins; b += TPB) {
-                const unsigned cb = hist[b];
-                if (cb) atomicAdd(&dev[abs(2 * (b + lo + 1) - med2)], cb);
-            }
-            lds_barrier();
-            rank_select2(dev, ndev, (ns - 1) / 2, ns / 2, sc, 1);
+            for (int j = 0; j < 2; j++)
+                if (hb0 + 4 * j < nb4) *(uint4 *)(hist + hb0 + 4 * j) = make_uint4(0u, 0u, 0u, 0u);
         }
-        const double mad = (double)(sc->sel[0] + sc->sel[1]) * 0.25;   // (d1/2 + d2/2) / 2, exact
+        const double mad = (double)((2 * sc->sel[0] + odd) + (2 * sc->sel[1] + odd)) * 0.25;   // (d1/2 + d2/2) / 2
         pr.center = median;
         pr.scale = mad * 1.4826;                                       // MotifSeq.py:196
         if (mad == 0.0) pr.flags |= SK_FLAG_DEGENERATE;
@@ -793,12 +796,12 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
         if (rc != 1) return rc;
     }
     const int64_t nbins = (int64_t)hi - (int64_t)lo - 1 > 0 ? (int64_t)hi - lo - 1 : 0;
-    const int64_t nb4 = (nbins + 3) & ~(int64_t)3, ndev4 = (2 * nbins + 1 + 3) & ~(int64_t)3;
-    size_t lds = sizeof(Scratch) + (size_t)(nb4 + (mode == SK_PREP_MEDMAD ? ndev4 : 0)) * 4;
+    const int64_t nb4 = (nbins + 3) & ~(int64_t)3;
+    size_t lds = sizeof(Scratch) + (size_t)nb4 * 4;
     if (lds > 160 * 1024)
         return sk_fail(SK_ERR_UNSUPPORTED,
                        "outlier limits (%d, %d) span %lld integer values: the LDS histogram holds %d (%s)",
-                       lo, hi, (long long)nbins, (mode == SK_PREP_MEDMAD) ? 12900 : 38900,
+                       lo, hi, (long long)nbins, 38900,
                        "narrow -scale_low/-scale_hi / -lim_low/-lim_hi");
     const int vec_ok = ((((uintptr_t)d_sig & 15) == 0 && (stride % 8) == 0) ? 1 : 0) |
                        ((((uintptr_t)d_comp & 15) == 0 && (stride % 8) == 0) ? 2 : 0);
