@@ -41,6 +41,12 @@ def is_int16_exact(a):
                 and a.min() >= -32768 and a.max() <= 32767)
 
 
+def _too_wide_for_i16(lo, hi):
+    """The int16 kernels keep a histogram of the values between the outlier limits in LDS (up to
+    ~38 900 values); wider limits go through the float64 kernels (radix select, same results)."""
+    return min(int(hi), 32768) - max(int(lo), -32769) - 1 > 38000
+
+
 # ----------------------------------------------------------------------------
 # segmenter path
 # ----------------------------------------------------------------------------
@@ -58,6 +64,14 @@ def segment_batch(sig, lens=None, params=None, max_segs=64):
     lens = (np.full(R, stride, dtype=np.int32) if lens is None
             else np.ascontiguousarray(lens, dtype=np.int32))
     params = params or SegParams()
+    if _too_wide_for_i16(params.lim_low, params.lim_hi):
+        per_read = segment_reads_f64([sig[r, :lens[r]].astype(np.float64) for r in range(R)], params)
+        nsegs = np.array([len(x) if x else 0 for x in per_read], dtype=np.int32)
+        segs = np.zeros((R, max(max_segs, int(nsegs.max()) if R else 0), 2), dtype=np.int32)
+        for r, x in enumerate(per_read):
+            if x:
+                segs[r, :len(x)] = x
+        return segs, nsegs
     while True:
         segs = np.zeros((R, max_segs, 2), dtype=np.int32)
         nsegs = np.zeros(R, dtype=np.int32)
@@ -196,6 +210,9 @@ def motifseq_batch(sig, lens, motif, scale="medmad", scale_low=0, scale_hi=1200)
     lens = (np.full(R, stride, dtype=np.int32) if lens is None
             else np.ascontiguousarray(lens, dtype=np.int32))
     motif = np.ascontiguousarray(motif, dtype=np.float64)
+    if _too_wide_for_i16(scale_low, scale_hi):
+        return motifseq_reads_f64([sig[r, :lens[r]].astype(np.float64) for r in range(R)], motif, scale,
+                                  scale_low, scale_hi)
     out = np.zeros(R, dtype=HIT_DTYPE)
     check(L.sk_motifseq_batch_i16(ptr(sig), stride, ptr(lens), R, ptr(motif), motif.size,
                                   _lib.SK_SCALE[scale], int(scale_low), int(scale_hi), ptr(out)))

@@ -82,20 +82,29 @@ def test_normalised_signal_matches_oracle_on_odd_stride(gpu, ora):
 @pytest.mark.parametrize("lo,hi", [(0, 900), (300, 700), (-100, 1900), (0, 5000), (-2000, 30000), (-32768, 32767), (499, 501)])
 def test_motifseq_outlier_limits(gpu, ora, example_model, lo, hi):
     """-scale_low / -scale_hi choose the histogram size, hence the kernel variant (16, 20 or 32 bins per
-    lane on the wave-per-read kernel; the workgroup kernel beyond 2 048 values)."""
+    lane on the wave-per-read kernel; the workgroup kernel beyond 2 048 values; the float64 kernels when
+    the limits span more values than an LDS histogram holds)."""
     from squigglekit_amd import api
-    from squigglekit_amd._lib import SquiggleKitError
     sig = _poke(_reads(48, 3000, 909, clean=False))
     lens = np.full(48, 3000, dtype=np.int32)
     lens[1] = 17
-    try:
-        got = api.motifseq_batch(sig, lens, example_model, scale_low=lo, scale_hi=hi)
-    except SquiggleKitError as e:                       # limits wider than the LDS histograms hold: loud, not wrong
-        assert hi - lo > 38000 and "narrow" in str(e)
-        return
+    got = api.motifseq_batch(sig, lens, example_model, scale_low=lo, scale_hi=hi)   # (widest: float64 kernels)
     want = ora.motifseq_batch_i16(sig, lens, example_model, scale_mode=0, lo=lo, hi=hi)
     assert np.array_equal(got["n"], want["n"])
     ok = (got["flags"] & 2) == 0
     assert np.array_equal(got["start"][ok], want["start"][ok]) and np.array_equal(got["end"][ok], want["end"][ok])
     nan = np.isnan(got["dist"]) & np.isnan(want["dist"])
     assert np.all(((got["dist"] == want["dist"]) | nan)[ok])
+
+
+def test_segmenter_wide_limits_route_to_f64(gpu, ora):
+    from squigglekit_amd import api
+    from squigglekit_amd._lib import SegParams
+    sig = _poke(_reads(24, 2000, 31, clean=False))
+    lens = np.full(24, 2000, dtype=np.int32)
+    p = SegParams(lim_low=-32768, lim_hi=32767)
+    segs, nsegs = api.segment_batch(sig, lens, p)
+    osegs, onsegs = ora.segment_batch_i16(sig, lens, lo=p.lim_low, hi=p.lim_hi, max_segs=segs.shape[1])
+    assert np.array_equal(nsegs, onsegs)
+    for r in range(24):
+        assert np.array_equal(segs[r, :nsegs[r]], osegs[r, :nsegs[r]]), r
