@@ -3,7 +3,7 @@
 // Covers, per read (one 256-thread workgroup per read):
 //   scale_outliers      segmenter.py:311-318 / MotifSeq.py:317-324   strict lo < x < hi, order kept
 //   np.median           segmenter.py:410, MotifSeq.py:194            LDS counting histogram + rank select
-//   MAD                 MotifSeq.py:195-196                          derived from the value histogram
+//   MAD                 MotifSeq.py:195-196                          rank select on the histogram folded around the median
 //   np.mean / np.std    segmenter.py:412, sklearn.scale (MotifSeq.py:187)
 //                       summed in numpy's exact order: 8192-element chunks accumulated serially,
 //                       each chunk by the pairwise tree (leaves <= 128: eight strided accumulators,
