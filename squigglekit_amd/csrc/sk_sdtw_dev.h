@@ -67,7 +67,7 @@ struct sdtw_kargs {
     unsigned      *ckq;         // [slot][nck][L][R+2] unsigned
     unsigned      *lastq;       // [slot][lq_stride]: screening cost of the last row per column
     int64_t        lq_stride;
-    int32_t       *qflag;       // [slot]: 1 = a sample left the fixed-point range (|y| >= QLIM)
+    int32_t       *qflag;       // [slot]: screening minimum of the read; QINF = a sample left the fixed-point range
     unsigned       qerr;        // E: bound (in units) on |screening cost - exact cost| of any cell
     int            wmax;        // widest candidate-column range the window pass accepts
     // row-chunked motifs (MODE_CHAIN): the last row of the chunk above / of this chunk, per column

@@ -142,6 +142,7 @@ void k_sdtw_q(const sdtw_kargs a)
     unsigned botq = (R == 1 && l == 0 && shortlane) ? 0u : QINF;
     unsigned diagq = (l == 0) ? 0u : QINF;
     int bad = 0;
+    unsigned qmin = QINF;                           // minimum of the last row so far
 
     // the sample feed in two halves, so that the load for the next block is in flight during this
     // block's L steps and only converted afterwards
@@ -210,12 +211,16 @@ void k_sdtw_q(const sdtw_kargs a)
         }
         F = toq(rawnext, (blk + 1) * L + l);
         const int j = t0 + l - (L - 1);             // lane L-1's column at step t0 + l
-        if (j >= 0 && j < n) lastq[j] = hbuf[l];
+        if (j >= 0 && j < n) { const unsigned hv = hbuf[l]; lastq[j] = hv; qmin = min(qmin, hv); }
     }
-    // a sample outside the fixed-point range anywhere in the read disqualifies the screening
+    // the read's screening minimum for pass W; a sample outside the fixed-point range anywhere in the
+    // read disqualifies the screening (reported as an infinite minimum)
 #pragma unroll
-    for (int d = 1; d < L; d <<= 1) bad |= __shfl_xor(bad, d);
-    if (live && l == 0) a.qflag[r - a.read0] = bad;
+    for (int d = 1; d < L; d <<= 1) {
+        bad |= __shfl_xor(bad, d);
+        qmin = min(qmin, (unsigned)__shfl_xor((int)qmin, d));
+    }
+    if (live && l == 0) a.qflag[r - a.read0] = (int32_t)(bad ? QINF : qmin);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -264,17 +269,7 @@ void k_sdtw_w(const sdtw_kargs a)
     // (rows are 16-byte aligned and padded to a multiple of 4 columns: four columns per load)
     const uint4 *lq4 = (const uint4 *)lastq;
     const int n4 = (n + 3) >> 2;
-    unsigned b = QINF;
-    for (int q4 = l; q4 < n4; q4 += L) {
-        const uint4 v = lq4[q4];
-        const int j = q4 * 4;
-        b = min(b, v.x);
-        if (j + 1 < n) b = min(b, v.y);
-        if (j + 2 < n) b = min(b, v.z);
-        if (j + 3 < n) b = min(b, v.w);
-    }
-#pragma unroll
-    for (int d = 1; d < L; d <<= 1) b = min(b, (unsigned)__shfl_xor((int)b, d));
+    const unsigned b = (unsigned)a.qflag[r - a.read0];   // the screening minimum (pass Q), QINF: not usable
     const unsigned thr = (b > QINF - 2u * a.qerr) ? QINF : b + 2u * a.qerr;
     int jlo = 0x7fffffff, jhi = -1;
     for (int q4 = l; q4 < n4; q4 += L) {
@@ -287,7 +282,7 @@ void k_sdtw_w(const sdtw_kargs a)
     }
 #pragma unroll
     for (int d = 1; d < L; d <<= 1) { jlo = min(jlo, __shfl_xor(jlo, d)); jhi = max(jhi, __shfl_xor(jhi, d)); }
-    const bool screened = (n > 0) && (a.qflag[r - a.read0] == 0) && (b < QSAFE) && (jhi >= jlo) &&
+    const bool screened = (n > 0) && (b < QSAFE) && (jhi >= jlo) &&
                           (jhi - jlo <= a.wmax);
 
     int tbase = 0, tlast = -1, c0 = 0, npre = 0;
