@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle sweep over shapes the unit tests do not pin: random read counts, ragged
+lengths, strides, motif lengths, outlier limits, both scalings, segmenter parameters.
+
+    python tools/fuzz_gpu.py [seconds=120] [seed=1]
+
+Prints one line per mismatch and exits non-zero if there was any.  (Test infrastructure.)"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from squigglekit_amd import api, synth               # noqa: E402
+from squigglekit_amd._lib import SegParams           # noqa: E402
+from oracle import oracle as ora                      # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    t_end = time.time() + budget
+    bad = rounds = 0
+    while time.time() < t_end:
+        rounds += 1
+        R = int(rng.choice([1, 3, 64, 255, 256, 300, 700]))
+        M = int(rng.choice([8, 63, 512, 1000, 2047, 4000, 4001, 6000]))
+        sig = synth.squiggle_batch(R, M, int(rng.integers(1 << 30)))
+        if rng.random() < 0.3:
+            sig = np.clip(sig, 300, 700).astype(np.int16)
+        k = int(rng.integers(0, 40))
+        sig[rng.integers(0, R, k), rng.integers(0, M, k)] = rng.choice([-9, 0, 899, 900, 1199, 1200, 3000], k)
+        lens = rng.integers(0, M + 1, R).astype(np.int32)
+        lens[rng.integers(0, R)] = M
+        # ---- MotifSeq ----
+        N = int(rng.choice([1, 7, 16, 17, 100, 163, 200, 256, 257, 400, 1030]))
+        motif = synth.synthetic_motif(N, seed=int(rng.integers(1000)))
+        lo, hi = [(0, 1200), (0, 900), (-50, 2500), (400, 650)][int(rng.integers(4))]
+        scale = ["medmad", "zscale"][int(rng.integers(2))]
+        got = api.motifseq_batch(sig, lens, motif, scale=scale, scale_low=lo, scale_hi=hi)
+        want = ora.motifseq_batch_i16(sig, lens, motif, scale_mode=0 if scale == "medmad" else 1, lo=lo, hi=hi)
+        ok = ((got["flags"] & 2) == 0) & np.isfinite(want["dist"]) | (want["n"] == 0)   # MAD == 0 / std == 0 rows aside
+        nan = np.isnan(got["dist"]) & np.isnan(want["dist"])
+        same = (got["start"] == want["start"]) & (got["end"] == want["end"]) & (got["n"] == want["n"]) & \
+               ((got["dist"] == want["dist"]) | nan)
+        if not np.all(same[ok]):
+            bad += 1
+            r = int(np.nonzero(~same & ok)[0][0])
+            print("MOTIFSEQ mismatch R=%d M=%d N=%d %s lo=%d hi=%d read %d: got %s want %s"
+                  % (R, M, N, scale, lo, hi, r, got[r], want[r]))
+        # ---- segmenter ----
+        kw = [dict(), dict(error=10, corrector=3), dict(window=20, seg_dist=5), dict(std_scale=1.5, stall_len=0.9),
+              dict(lim_low=300, lim_hi=800)][int(rng.integers(5))]
+        p = SegParams(**kw)
+        segs, nsegs = api.segment_batch(sig, lens, p, max_segs=64)
+        okw = {a: b for a, b in kw.items() if a not in ("lim_low", "lim_hi")}
+        osegs, onsegs = ora.segment_batch_i16(sig, lens, ora.SegParams(**okw), lo=p.lim_low, hi=p.lim_hi,
+                                              max_segs=segs.shape[1])
+        if not np.array_equal(nsegs, onsegs) or any(
+                not np.array_equal(segs[r, :nsegs[r]], osegs[r, :nsegs[r]]) for r in range(R)):
+            bad += 1
+            print("SEGMENTER mismatch R=%d M=%d %s" % (R, M, kw))
+    print("fuzz: %d rounds, %d mismatching configurations" % (rounds, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
