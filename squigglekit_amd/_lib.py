@@ -22,7 +22,7 @@ class SquiggleKitError(RuntimeError):
 
 SK_ERR_OVERFLOW = -6
 SK_SCALE = {"medmad": 0, "zscale": 1}
-SK_FLAG_EMPTY, SK_FLAG_DEGENERATE = 1, 2
+SK_FLAG_EMPTY, SK_FLAG_DEGENERATE, SK_FLAG_RECENTRE = 1, 2, 4
 
 
 class SegParams(C.Structure):

@@ -618,10 +618,15 @@ __device__ void block_minmax_u64(unsigned long long &mn, unsigned long long &mx,
     lds_barrier();
 }
 
+constexpr int SEL_LIST = 1024;        // candidates kept in LDS once the selected bin is this small
+
 // Key of rank k (0-based) among key(0..n-1).  kmin/kmax: block-uniform extremes of the keys.
+// MSD radix select with 8-bit digits.  As soon as the bin that holds rank k has at most SEL_LIST
+// members they are gathered into LDS (one more sweep over the data) and the remaining digits are
+// resolved on that list, so a select costs two or three sweeps over the read instead of seven.
 template <typename KeyFn>
-__device__ unsigned long long radix_select(int n, int k, Scratch *sc, unsigned *hist256, KeyFn key,
-                                           unsigned long long kmin, unsigned long long kmax)
+__device__ unsigned long long radix_select(int n, int k, Scratch *sc, unsigned *hist256, unsigned long long *list,
+                                           KeyFn key, unsigned long long kmin, unsigned long long kmax)
 {
     if (kmin == kmax) return kmin;
     const int tid = threadIdx.x;
@@ -629,36 +634,68 @@ __device__ unsigned long long radix_select(int n, int k, Scratch *sc, unsigned *
     int shift = (top / 8) * 8;
     unsigned long long pmask = (shift + 8 >= 64) ? 0ull : ~((1ull << (shift + 8)) - 1ull);
     unsigned long long prefix = kmin & pmask;
+    int m = -1;                                     // members of `list` (-1: still sweeping the data)
     for (; shift >= 0; shift -= 8) {
         hist256[tid] = 0u;
         lds_barrier();
-        for (int i = tid; i < n; i += TPB) {
-            const unsigned long long kk = key(i);
-            if ((kk & pmask) == prefix) atomicAdd(&hist256[(unsigned)(kk >> shift) & 255u], 1u);
+        if (m < 0) {
+            for (int i = tid; i < n; i += TPB) {
+                const unsigned long long kk = key(i);
+                if ((kk & pmask) == prefix) atomicAdd(&hist256[(unsigned)(kk >> shift) & 255u], 1u);
+            }
+        } else {
+            for (int i = tid; i < m; i += TPB) {
+                const unsigned long long kk = list[i];
+                if ((kk & pmask) == prefix) atomicAdd(&hist256[(unsigned)(kk >> shift) & 255u], 1u);
+            }
         }
         lds_barrier();
         const int c = (int)hist256[tid];
         int total;
         const int excl = block_excl_scan(c, sc->wsum[0], &total);
-        if (c > 0 && k >= excl && k < excl + c) { sc->sel[0] = tid; sc->sel[1] = k - excl; }
+        if (c > 0 && k >= excl && k < excl + c) { sc->sel[0] = tid; sc->sel[1] = k - excl; sc->sel[2] = c; }
         lds_barrier();
         prefix |= (unsigned long long)(unsigned)sc->sel[0] << shift;
         pmask |= 0xffull << shift;
         k = sc->sel[1];
+        const int members = sc->sel[2];
         lds_barrier();
+        if (m < 0 && shift > 0 && members <= SEL_LIST) {        // gather the bin's members once
+            if (tid == 0) sc->sel[3] = 0;
+            lds_barrier();
+            for (int i = tid; i < n; i += TPB) {
+                const unsigned long long kk = key(i);
+                if ((kk & pmask) == prefix) list[atomicAdd(&sc->sel[3], 1)] = kk;
+            }
+            lds_barrier();
+            m = members;
+        }
     }
     return prefix;
 }
 
-// Median of n values val(i) given as keys; returns (a+b)/2 for even n like np.median.
+// Median of n values given as keys; returns (a+b)/2 for even n like np.median.  The upper middle
+// element is the lower one again if enough values are <= it, else the smallest value above it:
+// one sweep (count, min) instead of a second select.
 template <typename KeyFn>
-__device__ double median_select(int n, Scratch *sc, unsigned *hist256, KeyFn key,
-                                unsigned long long kmin, unsigned long long kmax)
+__device__ double median_select(int n, Scratch *sc, unsigned *hist256, unsigned long long *list,
+                                unsigned long long *mm, KeyFn key, unsigned long long kmin, unsigned long long kmax)
 {
     const int k1 = (n - 1) / 2, k2 = n / 2;
-    const double a = key_f64(radix_select(n, k1, sc, hist256, key, kmin, kmax));
+    const unsigned long long ka = radix_select(n, k1, sc, hist256, list, key, kmin, kmax);
+    const double a = key_f64(ka);
     if (k2 == k1) return a;
-    const double b = key_f64(radix_select(n, k2, sc, hist256, key, kmin, kmax));
+    int le = 0;
+    unsigned long long above = ~0ull, dummy = 0ull;
+    for (int i = threadIdx.x; i < n; i += TPB) {
+        const unsigned long long kk = key(i);
+        if (kk <= ka) le++;
+        else above = kk < above ? kk : above;
+    }
+    int total;
+    (void)block_excl_scan(le, sc->wsum[1], &total);
+    block_minmax_u64(above, dummy, mm);
+    const double b = (total > k2) ? a : key_f64(above);
     return (a + b) / 2.0;
 }
 
@@ -671,6 +708,7 @@ void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off,
     __shared__ Scratch sc_;
     __shared__ unsigned hist256[256];
     __shared__ unsigned long long mm[2 * NWAVE];
+    __shared__ unsigned long long sel_list[SEL_LIST];
     Scratch *sc = &sc_;
 
     const int r = blockIdx.x;
@@ -733,7 +771,7 @@ void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off,
 
     double median = 0.0;
     if (mode != SK_PREP_ZSCALE)
-        median = median_select(n, sc, hist256, [&](int i) { return f64_key(crow[i]); }, kmin, kmax);
+        median = median_select(n, sc, hist256, sel_list, mm, [&](int i) { return f64_key(crow[i]); }, kmin, kmax);
 
     if (mode == SK_PREP_MEDMAD) {
         // MAD = median(|x - med|)   MotifSeq.py:195
@@ -744,7 +782,7 @@ void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off,
             dmax = kk > dmax ? kk : dmax;
         }
         block_minmax_u64(dmin, dmax, mm);
-        const double mad = median_select(n, sc, hist256,
+        const double mad = median_select(n, sc, hist256, sel_list, mm,
                                          [&](int i) { return f64_key(fabs(crow[i] - median)); }, dmin, dmax);
         pr.center = median;
         pr.scale = mad * 1.4826;
@@ -763,6 +801,10 @@ void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off,
     if (mode == SK_PREP_ZSCALE) {
         pr.center = mean;
         pr.scale = (sd == 0.0) ? 1.0 : sd;
+        // sklearn's scale() re-centres when the mean of the centred / scaled data is not within 1e-8
+        // of zero; that needs |x| >= ~1e4 or a relative spread below ~1e-8.  Not replicated: flag it.
+        const double maxabs = fmax(fabs(key_f64(kmin)), fabs(key_f64(kmax)));
+        if (sd != 0.0 && (!(maxabs < 1e4) || !(sd > 1e-6 * maxabs))) pr.flags |= SK_FLAG_RECENTRE;
         if (tid == 0) prep[r] = pr;
         return;
     }

@@ -99,3 +99,36 @@ def test_normalise_f64_matches_reference_pA_row(gpu, ora, example_read):
         g = run["dtw_inputs"][0]
         assert y.size == g["n"]
         assert hashlib.sha256(y.tobytes()).hexdigest() == g["sha256"], run["flags"]
+
+
+def test_f64_selection_corners(gpu, ora):
+    """Median / MAD selection on doubles: heavy duplicates, values that differ only in their lowest
+    mantissa bits (every radix digit is needed), wide dynamic range, tiny reads, even and odd sizes."""
+    from squigglekit_amd import api
+    rng = np.random.default_rng(2024)
+    reads = []
+    for n in (1, 2, 3, 4, 9, 10, 255, 256, 257, 1025, 3000, 5001):
+        reads.append(rng.choice([1.5, 2.5, 3.5, 700.25], n))                        # few distinct values
+        reads.append(1.0 + rng.integers(0, 5000, n) * 2.0 ** -50)                   # differ in the last bits
+        reads.append(np.exp(rng.normal(3.0, 1.5, n)).clip(1e-3, 1100.0))            # wide range
+        reads.append(np.round(rng.normal(90.0, 12.0, n), 1))                        # pA-like, 0.1 steps (ties)
+    for i, sig in enumerate(reads):
+        f = ora.scale_outliers(sig, 0, 1200)
+        for scale in ("medmad", "zscale"):
+            want = ora.medmad(f)[0] if scale == "medmad" else ora.zscale(f)[0]
+            got = api.normalise(sig, scale=scale)
+            assert got.shape == want.shape, (i, scale)
+            if scale == "zscale" and i % 4 == 1 and ora.zscale(f)[3]:
+                # near-constant data: sklearn's "mean not close to zero" re-centring fired in the oracle;
+                # the library does not replicate it and says so (SK_FLAG_RECENTRE on the hit record)
+                hit = api.motifseq_reads_f64([sig], np.zeros(4), scale="zscale")
+                assert hit["flags"][0] & 4
+                assert np.allclose(got, want, atol=1e-3)
+                continue
+            assert np.array_equal(got, want, equal_nan=True), (i, scale, len(sig))
+    # the same reads as one ragged batch through the segmenter statistics (median + std)
+    segs = api.segment_reads_f64(reads)
+    for sig, got in zip(reads, segs):
+        f = ora.scale_outliers(sig, 0, 900)
+        want = ora.get_segs(f) if f.size else False
+        assert got == want
