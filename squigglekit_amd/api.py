@@ -30,6 +30,30 @@ def pack_i16(reads):
     return buf, lens
 
 
+def as_int16_exact(a):
+    """The read as an int16 array if every value is an integer that fits int16, else None.
+    (One cast and one comparison: a wrapped, rounded or NaN value fails the comparison.)"""
+    a = np.asarray(a)
+    if a.dtype == np.int16:
+        return a
+    with np.errstate(invalid="ignore", over="ignore"):
+        b = a.astype(np.int16)
+    return b if (a.size == 0 or np.array_equal(b, a)) else None
+
+
+def _split_int16(reads):
+    """indices + int16 arrays of the integer-valued reads, indices of the rest"""
+    ints, arrs, flts = [], [], []
+    for i, r in enumerate(reads):
+        b = as_int16_exact(r)
+        if b is None:
+            flts.append(i)
+        else:
+            ints.append(i)
+            arrs.append(b)
+    return ints, arrs, flts
+
+
 def is_int16_exact(a):
     """True if every value of the float/int array is an integer that fits int16."""
     a = np.asarray(a)
@@ -148,12 +172,10 @@ def drna_segment_reads(reads, params=None, max_segs=32):
 def segment_any(reads, params=None):
     """Route each read to the int16 kernels when it is integer valued and fits,
     else to the float64 kernels; results come back in input order."""
-    ints = [i for i, r in enumerate(reads) if is_int16_exact(r)]
-    iset = set(ints)
-    flts = [i for i in range(len(reads)) if i not in iset]
+    ints, arrs, flts = _split_int16(reads)
     out = [None] * len(reads)
     if ints:
-        for i, res in zip(ints, segment_reads([np.asarray(reads[i]).astype(np.int16) for i in ints], params)):
+        for i, res in zip(ints, segment_reads(arrs, params)):
             out[i] = res
     if flts:
         for i, res in zip(flts, segment_reads_f64([reads[i] for i in flts], params)):
@@ -234,11 +256,9 @@ def motifseq_any(reads, motif, scale="medmad", scale_low=0, scale_hi=1200):
     """Integer-valued reads go through the int16 kernels, the rest through the
     float64 kernels (bit-identical results either way); input order is kept."""
     out = np.zeros(len(reads), dtype=HIT_DTYPE)
-    ints = [i for i, r in enumerate(reads) if is_int16_exact(r)]
-    iset = set(ints)
-    flts = [i for i in range(len(reads)) if i not in iset]
+    ints, arrs, flts = _split_int16(reads)
     if ints:
-        buf, lens = pack_i16([np.asarray(reads[i]).astype(np.int16) for i in ints])
+        buf, lens = pack_i16(arrs)
         out[ints] = motifseq_batch(buf, lens, motif, scale, scale_low, scale_hi)
     if flts:
         out[flts] = motifseq_reads_f64([reads[i] for i in flts], motif, scale, scale_low, scale_hi)
@@ -252,11 +272,9 @@ def motifseq_multi(reads, motifs, scale="medmad", scale_low=0, scale_hi=1200):
     L = _lib.ensure_init()
     motifs = [np.ascontiguousarray(m, dtype=np.float64) for m in motifs]
     outs = [np.zeros(len(reads), dtype=HIT_DTYPE) for _ in motifs]
-    ints = [i for i, r in enumerate(reads) if is_int16_exact(r)]
-    iset = set(ints)
-    flts = [i for i in range(len(reads)) if i not in iset]
+    ints, arrs, flts = _split_int16(reads)
     if ints and motifs:
-        buf, lens = pack_i16([np.asarray(reads[i]).astype(np.int16) for i in ints])
+        buf, lens = pack_i16(arrs)
         moff = np.zeros(len(motifs) + 1, dtype=np.int32)
         moff[1:] = np.cumsum([m.size for m in motifs])
         flat = np.ascontiguousarray(np.concatenate(motifs))

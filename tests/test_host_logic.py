@@ -16,6 +16,11 @@ def test_pack_and_int16_detection():
     assert not api.is_int16_exact(np.array([1.5]))
     assert not api.is_int16_exact(np.array([40000.0]))
     assert api.is_int16_exact(np.array([], dtype=float))
+    for good in ([1.0, 2.0, -3.0], [], [32767, -32768], np.array([5, 6], dtype=np.int64)):
+        got = api.as_int16_exact(np.array(good))
+        assert got is not None and got.dtype == np.int16 and np.array_equal(got, np.array(good))
+    for bad in ([1.5], [40000.0], [np.nan, 1.0], [np.inf], [-32769], [65536 + 7]):
+        assert api.as_int16_exact(np.array(bad)) is None
 
 
 def test_blow5_reader_matches_survey_facts(example_read):
