@@ -50,10 +50,9 @@ enum { SK_SCALE_MEDMAD = 0, SK_SCALE_ZSCALE = 1 };
 enum {
     SK_FLAG_EMPTY      = 1,    /* no sample survived scale_outliers: dist = NaN, start=end=-1 */
     SK_FLAG_DEGENERATE = 2,    /* medmad with MAD == 0 (reference divides by zero)            */
-    SK_FLAG_RECENTRE   = 4     /* float64 zscale on near-constant (std < 1e-6 max|x|) or huge (|x| >= 1e4)
-                                  data: sklearn.preprocessing.scale may subtract the residual mean a
-                                  second time ("mean not close to zero" guards, MotifSeq.py:187-191);
-                                  that re-centring is not replicated, results can differ by ~1e-4     */
+    SK_FLAG_RECENTRE   = 4     /* float64 zscale: sklearn.preprocessing.scale subtracted the residual mean a
+                                  second time ("mean not close to zero", near-constant or huge-valued
+                                  data, MotifSeq.py:187-191); applied here too -- informational        */
 };
 
 /* get_segs parameters: the argparse flags of segmenter.py:65-96 that reach

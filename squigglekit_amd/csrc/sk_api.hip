@@ -44,7 +44,7 @@ __global__ void k_normalise_f64(const double *__restrict__ comp, const sk_prep *
 {
     const sk_prep pr = prep[0];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pr.n; i += gridDim.x * blockDim.x)
-        out[i] = (comp[i] - pr.center) / pr.scale;
+        out[i] = ((comp[i] - pr.center) - pr.top) / pr.scale - pr.bot;   // top / bot: sklearn's re-centring, 0 unless applied
 }
 
 } // namespace

@@ -801,10 +801,20 @@ void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off,
     if (mode == SK_PREP_ZSCALE) {
         pr.center = mean;
         pr.scale = (sd == 0.0) ? 1.0 : sd;
-        // sklearn's scale() re-centres when the mean of the centred / scaled data is not within 1e-8
-        // of zero; that needs |x| >= ~1e4 or a relative spread below ~1e-8.  Not replicated: flag it.
+        // sklearn's scale() subtracts the residual mean again when the mean of the centred (and, later,
+        // of the scaled) data is not within 1e-8 of zero (np.allclose).  With |mean error| <= ~60 eps
+        // max|x| that needs max|x| >~ 7e5, or a scale below ~1.4e-6 max|x|: only such reads pay for the
+        // two extra numpy-order sums.  pr.top / pr.bot carry the two corrections (0.0 when not applied)
+        // to the sample feed: v = ((x - mean) - top) / scale - bot.
         const double maxabs = fmax(fabs(key_f64(kmin)), fabs(key_f64(kmax)));
-        if (sd != 0.0 && (!(maxabs < 1e4) || !(sd > 1e-6 * maxabs))) pr.flags |= SK_FLAG_RECENTRE;
+        if (sd != 0.0 && (!(maxabs < 1e4) || !(sd > 1e-4 * maxabs))) {
+            const double m1 = numpy_sum(n, sc, [&](int i) { return crow[i] - mean; }) / (double)n;
+            const double c1 = (fabs(m1) <= 1e-8) ? 0.0 : m1;           // np.allclose(mean_1, 0)
+            const double m2 = numpy_sum(n, sc, [&](int i) { return ((crow[i] - mean) - c1) / pr.scale; }) / (double)n;
+            const double c2 = (fabs(m2) <= 1e-8) ? 0.0 : m2;
+            pr.top = c1; pr.bot = c2;
+            if (c1 != 0.0 || c2 != 0.0) pr.flags |= SK_FLAG_RECENTRE;
+        }
         if (tid == 0) prep[r] = pr;
         return;
     }

@@ -65,7 +65,7 @@ void k_sdtw(const sdtw_kargs a)
 
     // ---- per-read parameters -------------------------------------------------
     int n, flags = 0;
-    double center = 0.0, scale = 1.0;
+    double center = 0.0, scale = 1.0, rc1 = 0.0, rc2 = 0.0;
     const int16_t *s16 = nullptr;
     const double  *s64 = nullptr;
     if constexpr (FEED == SK_FEED_I16) {
@@ -75,6 +75,7 @@ void k_sdtw(const sdtw_kargs a)
     } else if constexpr (FEED == SK_FEED_F64_NORM) {
         const sk_prep pr = a.prep[r];
         n = pr.n; flags = pr.flags; center = pr.center; scale = pr.scale;
+        rc1 = pr.top; rc2 = pr.bot;                 // zscale re-centring terms (0.0 unless sklearn applied them)
         s64 = (const double *)a.samples + a.off[r];
     } else {
         n = (int)(a.off[r + 1] - a.off[r]);
@@ -155,7 +156,7 @@ void k_sdtw(const sdtw_kargs a)
             return (idx < n) ? v : INF;
         } else if constexpr (FEED == SK_FEED_F64_NORM) {
             double raw = (idx < n) ? s64[idx] : 0.0;
-            double v = (raw - center) / scale;
+            double v = ((raw - center) - rc1) / scale - rc2;
             return (idx < n) ? v : INF;
         } else {
             return (idx < n) ? s64[idx] : INF;

@@ -142,6 +142,9 @@ void k_sdtw_q(const sdtw_kargs a)
     unsigned botq = (R == 1 && l == 0 && shortlane) ? 0u : QINF;
     unsigned diagq = (l == 0) ? 0u : QINF;
     int bad = 0;
+    if constexpr (FEED == SK_FEED_F64_NORM) {       // re-centred zscale reads: exact feed only (retry pass)
+        if (live && (a.prep[r].flags & SK_FLAG_RECENTRE)) bad = 1;
+    }
     unsigned qmin = QINF;                           // minimum of the last row so far
 
     // the sample feed in two halves, so that the load for the next block is in flight during this

@@ -118,14 +118,20 @@ def test_f64_selection_corners(gpu, ora):
             want = ora.medmad(f)[0] if scale == "medmad" else ora.zscale(f)[0]
             got = api.normalise(sig, scale=scale)
             assert got.shape == want.shape, (i, scale)
-            if scale == "zscale" and i % 4 == 1 and ora.zscale(f)[3]:
-                # near-constant data: sklearn's "mean not close to zero" re-centring fired in the oracle;
-                # the library does not replicate it and says so (SK_FLAG_RECENTRE on the hit record)
-                hit = api.motifseq_reads_f64([sig], np.zeros(4), scale="zscale")
-                assert hit["flags"][0] & 4
-                assert np.allclose(got, want, atol=1e-3)
-                continue
             assert np.array_equal(got, want, equal_nan=True), (i, scale, len(sig))
+    # sklearn's "mean not close to zero" re-centring fires on the near-constant reads (the oracle
+    # reports it); the library applies the same correction and flags the read
+    fired = [bool(ora.zscale(ora.scale_outliers(sig, 0, 1200))[3]) for sig in reads]
+    assert any(fired)
+    motif = np.array([0.5, -0.25, 1.0, 0.0, -1.5])
+    hits = api.motifseq_reads_f64(reads, motif, scale="zscale")
+    for i, sig in enumerate(reads):
+        y = ora.zscale(ora.scale_outliers(sig, 0, 1200))[0]
+        if y.size == 0 or not np.all(np.isfinite(y)):
+            continue
+        d, s0, e0 = ora.dtw_subsequence(motif, y)
+        assert (hits["dist"][i], hits["start"][i], hits["end"][i]) == (d, s0, e0), i
+        assert bool(hits["flags"][i] & 4) == fired[i], i
     # the same reads as one ragged batch through the segmenter statistics (median + std)
     segs = api.segment_reads_f64(reads)
     for sig, got in zip(reads, segs):
