@@ -366,8 +366,8 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
 
     if (tid == 0) sc->tree_m = -1;                         // no pairwise tree cached yet
     unsigned v[4], vn[4];
-    int Mnext = (blockIdx.x < nreads) ? len[blockIdx.x] : 0;
-    if (blockIdx.x < nreads) load8(sig + (int64_t)blockIdx.x * stride, Mnext, tid * 8, v);
+    int Mnext = ((int)blockIdx.x < nreads) ? len[blockIdx.x] : 0;
+    if ((int)blockIdx.x < nreads) load8(sig + (int64_t)blockIdx.x * stride, Mnext, tid * 8, v);
     for (int r = blockIdx.x; r < nreads; r += gridDim.x) {
     const int M = Mnext;
     const int16_t *row = sig + (int64_t)r * stride;

@@ -30,20 +30,6 @@
 
 namespace {
 
-__device__ __forceinline__ unsigned sad_clamp(unsigned a, unsigned b, unsigned c)
-{
-    unsigned r;                                   // min(|a - b| + c, 2^32 - 1)
-    asm("v_sad_u32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-__device__ __forceinline__ unsigned min3u(unsigned a, unsigned b, unsigned c)
-{
-    unsigned r;
-    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 // One column of R cells: nw[k] = min(|xq[k] - yq| + min3(old[k-1], old[k], nw[k-1]), 2^32-1), with
 // dg standing in for old[-1] and up for nw[-1].  Written as asm blocks of four cells because the
 // compiler has no v_sad_u32 pattern, and because it pads every asm statement boundary with a
