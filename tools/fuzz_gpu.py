@@ -60,6 +60,41 @@ def main():
                 not np.array_equal(segs[r, :nsegs[r]], osegs[r, :nsegs[r]]) for r in range(R)):
             bad += 1
             print("SEGMENTER mismatch R=%d M=%d %s" % (R, M, kw))
+        # ---- float64 reads (pA-like), per-read oracle composition, a few reads per round ----
+        kinds = int(rng.integers(4))
+        freads = []
+        for _ in range(int(rng.integers(1, 12))):
+            n = int(rng.choice([1, 2, 5, 64, 257, 1500, 4000]))
+            if kinds == 0:
+                x = np.round(rng.normal(90.0, 14.0, n), 1)                      # 0.1 pA steps: many ties
+            elif kinds == 1:
+                x = rng.normal(90.0, 14.0, n)
+            elif kinds == 2:
+                x = 500.0 + rng.integers(0, 3, n) * 2.0 ** -40                  # near constant
+            else:
+                x = np.exp(rng.normal(4.0, 1.0, n))
+            freads.append(x)
+        fm = synth.synthetic_motif(int(rng.choice([3, 50, 163])), seed=int(rng.integers(1000)))
+        fscale = ["medmad", "zscale"][int(rng.integers(2))]
+        fgot = api.motifseq_reads_f64(freads, fm, scale=fscale)
+        for i, x in enumerate(freads):
+            f = ora.scale_outliers(x, 0, 1200)
+            if f.size == 0:
+                continue
+            y = ora.medmad(f)[0] if fscale == "medmad" else ora.zscale(f)[0]
+            if not np.all(np.isfinite(y)):
+                continue                                                         # MAD == 0: flagged, not compared
+            d, s0, e0 = ora.dtw_subsequence(fm, y)
+            if (fgot["dist"][i], fgot["start"][i], fgot["end"][i], fgot["n"][i]) != (d, s0, e0, f.size):
+                bad += 1
+                print("F64 mismatch kind %d %s n=%d: got %s want %s" % (kinds, fscale, len(x), fgot[i], (d, s0, e0)))
+        fsegs = api.segment_reads_f64(freads)
+        for x, gsegs in zip(freads, fsegs):
+            f = ora.scale_outliers(x, 0, 900)
+            wsegs = ora.get_segs(f) if f.size else False
+            if gsegs != wsegs:
+                bad += 1
+                print("F64 SEGMENTER mismatch kind %d n=%d" % (kinds, len(x)))
     print("fuzz: %d rounds, %d mismatching configurations" % (rounds, bad))
     sys.exit(1 if bad else 0)
 
