@@ -213,16 +213,17 @@ __device__ void build_tree(int m, Scratch *sc)
 // Leaves (<= 128 elements) are summed by 8-lane groups -- lane j owns numpy's accumulator
 // r[j], the butterfly shfl_xor 1,2,4 reproduces ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) -- then
 // wave 0 folds the partial sums bottom-up (parent = left + right), wave-synchronously.
-template <typename Term>
+// BCAST = false: only wavefront 0 gets the result (the caller continues in thread 0), which saves the
+// two barriers of the broadcast.
+template <bool BCAST, typename Term>
 __device__ double pairwise_chunk(int m, Scratch *sc, Term term)
 {
     const int tid = threadIdx.x;
     if (m < 8) {                                   // numpy: plain serial loop from 0.0
-        if (tid == 0) {
-            double res = 0.0;
-            for (int i = 0; i < m; i++) res += term(i);
-            sc->bcast[0] = res;
-        }
+        double res = 0.0;
+        if (tid < 64) for (int i = 0; i < m; i++) res += term(i);
+        if (!BCAST) return res;
+        if (tid == 0) sc->bcast[0] = res;
         lds_barrier();
         double r = sc->bcast[0];
         lds_barrier();
@@ -260,6 +261,7 @@ __device__ double pairwise_chunk(int m, Scratch *sc, Term term)
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if (!BCAST) return (tid < 64) ? ((volatile double *)sc->node_sum)[1] : 0.0;
     lds_barrier();
     double res = sc->node_sum[1];
     lds_barrier();
@@ -267,13 +269,14 @@ __device__ double pairwise_chunk(int m, Scratch *sc, Term term)
 }
 
 // np.add.reduce order over n terms: serial over 8192-chunks of pairwise sums.
-template <typename Term>
+template <bool BCAST = true, typename Term>
 __device__ double numpy_sum(int n, Scratch *sc, Term term)
 {
     double res = 0.0;
     for (int base = 0; base < n; base += NPY_BUFSIZE) {
         const int m = min(NPY_BUFSIZE, n - base);
-        res += pairwise_chunk(m, sc, [&](int i) { return term(base + i); });
+        if (!BCAST && base > 0) lds_barrier();     // wave 0 is done with the previous chunk's partial sums
+        res += pairwise_chunk<BCAST>(m, sc, [&](int i) { return term(base + i); });
     }
     return res;
 }
@@ -489,7 +492,7 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     }
     const int med2 = (sc->sel[0] + lo + 1) + (sc->sel[1] + lo + 1);    // 2 * median, exact
     const double median = (double)med2 * 0.5;
-    lds_barrier();
+    if (MEDMAD) lds_barrier();                             // (the MAD select below rewrites sc->sel)
 
     if constexpr (MEDMAD) {
         // MAD = median of |x - med|: rank select on the value histogram folded around the median.
@@ -532,7 +535,7 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     }
     const double mean = (double)S / (double)ns;
     const int16_t *src = LDSCOMP ? (const int16_t *)lcomp : (const int16_t *)crow;
-    const double ssq = numpy_sum(ns, sc, [&](int i) {
+    const double ssq = numpy_sum<false>(ns, sc, [&](int i) {      // (result in wavefront 0 only)
         const double d = (double)src[w0 + i] - mean;
         return d * d;
     });
