@@ -61,7 +61,8 @@ struct sk_ctx {
     int    prof_chunks = 0;  // chunks of the last two-pass DTW call (0: single pass)
     int    prof_reads[64] = {0};
     std::vector<double> motif_host;   // last laid-out motif (kept alive for async H2D)
-    std::vector<double> motif_src;    // the motif it was built from (upload cache key)
+    std::vector<double> motif_src;    // the motif it was built from (upload cache key, with motif_L)
+    int    motif_L = 0;               // lanes per read of the layout in `motif`
 };
 
 // ---- runtime (sk_runtime.hip) ----
