@@ -285,3 +285,25 @@ def test_long_motif_int16_batch(gpu, ora):
         ok = (got["flags"] & 2) == 0             # MAD == 0 (the one-sample read): flagged, not compared
         assert ok.sum() >= 38 and np.array_equal(got["n"], want["n"])
         _assert_hits(got[ok], want[ok], "long motif %s" % scale)
+
+
+@pytest.mark.parametrize("nx", [17, 100, 163, 200, 256])
+def test_small_batches_on_the_16_lane_layout(gpu, ora, monkeypatch, nx):
+    """Few reads normally take the 64-lanes-per-read layout; SK_DTW_NO_SMALL keeps the 16-lane one
+    (what large batches use), so that both layouts see the tie-heavy and ragged small cases."""
+    from squigglekit_amd import api, synth
+    monkeypatch.setenv("SK_DTW_NO_SMALL", "1")
+    rng = np.random.default_rng(77 + nx)
+    xi = rng.integers(-2, 3, nx).astype(float)
+    yt = [rng.integers(-2, 3, ny).astype(float) for ny in [1, 5, 40, 333, 1200, 2500]]
+    got = api.dtw_subsequence_batch(xi, yt)
+    for i, y in enumerate(yt):
+        d, s, e = ora.dtw_subsequence(xi, y)
+        assert (got["dist"][i], got["start"][i], got["end"][i]) == (d, s, e), (nx, len(y))
+    motif = synth.synthetic_motif(nx, seed=nx)
+    sig = synth.squiggle_batch(300, 3000, 9000 + nx, motif=motif)       # >= 256 reads: screening scheme
+    lens = rng.integers(1, 3001, 300).astype(np.int32)
+    want = ora.motifseq_batch_i16(sig, lens, motif)
+    got = api.motifseq_batch(sig, lens, motif)
+    ok = (got["flags"] & 2) == 0
+    _assert_hits(got[ok], want[ok], "16-lane layout, %d points" % nx)
