@@ -37,6 +37,16 @@ class SegParams(C.Structure):
         super().__init__(error, corrector, window, seg_dist, std_scale, stall_len)
 
 
+class RollParams(C.Structure):
+    """Mirror of ora_roll_params: the constants of dRNA_segmenter.py:291-295,322 and the window `w`
+    the script forgot to define (its commented default, :81, is 2000)."""
+    _fields_ = [("w", C.c_int32), ("seg_dist", C.c_int32), ("hi_thresh", C.c_int32), ("lo_thresh", C.c_int32),
+                ("shift", C.c_int32), ("std_scale", C.c_double)]
+
+    def __init__(self, w=2000, seg_dist=1500, hi_thresh=200000, lo_thresh=2000, shift=1000, std_scale=0.5):
+        super().__init__(w, seg_dist, hi_thresh, lo_thresh, shift, std_scale)
+
+
 class DrnaParams(C.Structure):
     """Mirror of ora_drna_params; defaults are dRNA_segmenter.py:80-104's constants."""
     _fields_ = [("error", C.c_int32), ("no_err_thresh", C.c_int32), ("w", C.c_int32),
@@ -76,6 +86,9 @@ def lib():
         L.ora_scale_outliers.argtypes = [dp, C.c_int64, C.c_double, C.c_double, dp]
         L.ora_get_segs.restype = C.c_int32
         L.ora_get_segs.argtypes = [dp, C.c_int64, C.POINTER(SegParams), ip, C.c_int32, dp, dp]
+        L.ora_drna_roll.restype = C.c_int
+        L.ora_drna_roll.argtypes = [dp, C.c_int64, C.POINTER(RollParams), C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_int64), dp, dp]
         L.ora_drna_segs.restype = C.c_int32
         L.ora_drna_segs.argtypes = [dp, C.c_int64, C.POINTER(DrnaParams), ip, C.c_int32, dp]
         L.ora_medmad.restype = None
@@ -168,6 +181,22 @@ def drna_segs(sig, params=None, max_segs=256):
     if k < 0:
         raise ValueError("invalid dRNA parameters")
     return segs[:2 * min(k, max_segs)].reshape(-1, 2).tolist(), top.value
+
+
+def drna_roll(sig, params=None, want_t=False):
+    """dRNA_segmenter's --signal branch on an already filtered signal: (x, y) or None; with
+    want_t also the rolling mean and (mn, std, bot)."""
+    a, p = _d(sig)
+    params = params or RollParams()
+    x, y = C.c_int64(), C.c_int64()
+    t = np.empty(max(1, a.size), dtype=np.float64)
+    stats = np.zeros(3, dtype=np.float64)
+    found = lib().ora_drna_roll(p, a.size, C.byref(params), C.byref(x), C.byref(y),
+                                t.ctypes.data_as(C.POINTER(C.c_double)), stats.ctypes.data_as(C.POINTER(C.c_double)))
+    if found < 0:
+        raise ValueError("invalid rolling parameters")
+    res = (x.value, y.value) if found else None
+    return (res, t[:a.size], tuple(stats)) if want_t else res
 
 
 def medmad(x):

@@ -469,3 +469,114 @@ int32_t ora_drna_segs(const double *sig, int64_t n, const ora_drna_params *p,
     }
     return nseg;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * dRNA_segmenter.py:272-326 -- the --signal branch (rolling mean)
+ * ------------------------------------------------------------------------------------------------ */
+/* pandas/_libs/window/aggregations.pyx: add_mean / remove_mean / calc_mean */
+typedef struct { int64_t nobs, neg_ct, same; double sum_x, comp_add, comp_rem, prev; } roll_state;
+static void roll_add(roll_state *s, double val)
+{
+    if (val == val) {
+        s->nobs += 1;
+        double y = val - s->comp_add;
+        double t = s->sum_x + y;
+        s->comp_add = t - s->sum_x - y;
+        s->sum_x = t;
+        if (signbit(val)) s->neg_ct += 1;
+        if (val == s->prev) s->same += 1; else s->same = 1;
+        s->prev = val;
+    }
+}
+static void roll_remove(roll_state *s, double val)
+{
+    if (val == val) {
+        s->nobs -= 1;
+        double y = -val - s->comp_rem;
+        double t = s->sum_x + y;
+        s->comp_rem = t - s->sum_x - y;
+        s->sum_x = t;
+        if (signbit(val)) s->neg_ct -= 1;
+    }
+}
+static double roll_calc(const roll_state *s, int64_t minp)
+{
+    if (s->nobs >= minp && s->nobs > 0) {
+        double r = s->sum_x / (double)s->nobs;
+        if (s->same >= s->nobs) r = s->prev;
+        else if (s->neg_ct == 0 && r < 0) r = 0;
+        else if (s->neg_ct == s->nobs && r > 0) r = 0;
+        return r;
+    }
+    return NAN;
+}
+
+int ora_drna_roll(const double *sig, int64_t n, const ora_roll_params *p, int64_t *x_out, int64_t *y_out,
+                  double *t_out, double *stats_out)
+{
+    if (!p || p->w <= 0) return -1;
+    const int64_t w = p->w;
+    double *t = t_out ? t_out : (double *)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+    /* fixed window, closed on the right: start = max(0, i - w + 1), end = i + 1 (monotonic bounds) */
+    roll_state st;
+    memset(&st, 0, sizeof st);
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t s0 = (i - w + 1 > 0) ? i - w + 1 : 0;
+        if (i == 0) {
+            memset(&st, 0, sizeof st);
+            st.prev = sig[s0];
+            st.same = 0;
+            roll_add(&st, sig[0]);
+        } else {
+            const int64_t sp = (i - w > 0) ? i - w : 0;          /* start[i-1] */
+            for (int64_t j = sp; j < s0; j++) roll_remove(&st, sig[j]);
+            roll_add(&st, sig[i]);                                /* end[i-1] = i .. end[i] = i + 1 */
+        }
+        t[i] = roll_calc(&st, w);
+    }
+    /* t.mean(), t.std(): pandas.core.nanops (no bottleneck): NaN -> 0 copies, numpy sums */
+    double *v = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; i++) { if (t[i] == t[i]) { v[i] = t[i]; cnt++; } else v[i] = 0.0; }
+    const double mn = ora_np_sum(v, n) / (double)cnt;             /* count 0 -> NaN like pandas */
+    for (int64_t i = 0; i < n; i++) {
+        if (t[i] == t[i]) { const double d = mn - t[i]; v[i] = d * d; } else v[i] = 0.0;
+    }
+    const double var = ora_np_sum(v, n) / (double)(cnt - 1);      /* ddof = 1 */
+    const double sd = sqrt(var);
+    const double bot = mn - (sd * p->std_scale);
+    free(v);
+    if (stats_out) { stats_out[0] = mn; stats_out[1] = sd; stats_out[2] = bot; }
+
+    /* the scan (dRNA_segmenter.py:296-316) */
+    int begin = 0, found = 0;
+    int64_t start = 0, end = 0, last_end = 0, nseg = 0;
+    int64_t cap = 64, *segs = (int64_t *)malloc((size_t)cap * 2 * sizeof(int64_t));
+    for (int64_t c = 0; c < n; c++) {
+        const double i = t[c];
+        if (i < bot && !begin) { start = c; begin = 1; }
+        else if (i < bot) { end = c; }
+        else if (i > bot && begin) {
+            if (nseg > 0 && start - last_end < p->seg_dist) segs[2 * (nseg - 1) + 1] = end;
+            else {
+                if (nseg == cap) { cap *= 2; segs = (int64_t *)realloc(segs, (size_t)cap * 2 * sizeof(int64_t)); }
+                segs[2 * nseg] = start; segs[2 * nseg + 1] = end; nseg++;
+            }
+            last_end = end;
+            start = 0; end = 0; begin = 0;
+        }
+    }
+    for (int64_t k = 0; k < nseg; k++) {                          /* :318-326 */
+        const int64_t a = segs[2 * k], b = segs[2 * k + 1];
+        if (b - a > p->hi_thresh) continue;
+        if (b - a < p->lo_thresh) continue;
+        if (x_out) *x_out = a - p->shift;
+        if (y_out) *y_out = b - p->shift;
+        found = 1;
+        break;
+    }
+    free(segs);
+    if (!t_out) free(t);
+    return found;
+}

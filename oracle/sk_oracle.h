@@ -89,6 +89,25 @@ typedef struct {
 int32_t ora_drna_segs(const double *sig, int64_t n, const ora_drna_params *p,
                       int32_t *segs, int32_t max_segs, double *top);
 
+/* dRNA_segmenter.py:272-326, the --signal branch: rolling mean of the filtered signal
+ * (pandas Series.rolling(window=w).mean(), restated from pandas/_libs/window/aggregations.pyx
+ * roll_mean: Kahan-compensated add / remove, "consecutive same value" shortcut, min_periods = w),
+ * mn = t.mean(), std = t.std() (pandas nanops: NaN -> 0, numpy sums, ddof = 1), bot = mn - 0.5 std,
+ * the begin/end scan and the first segment whose length lies in [lo_thresh, hi_thresh].
+ * `w` is undefined in the reference (the branch stops with NameError); the caller supplies it.
+ * Returns 1 and (x, y) = (a - 1000, b - 1000) when a segment is printed, else 0.
+ * t_out (n doubles, optional) receives the rolling mean; stats_out[3] = mn, std, bot. */
+typedef struct {
+    int32_t w;              /* rolling window: the script's commented default is 2000 */
+    int32_t seg_dist;       /* 1500   */
+    int32_t hi_thresh;      /* 200000 */
+    int32_t lo_thresh;      /* 2000   */
+    int32_t shift;          /* 1000: subtracted from both ends when printing */
+    double  std_scale;      /* 0.5    */
+} ora_roll_params;
+int ora_drna_roll(const double *sig, int64_t n, const ora_roll_params *p, int64_t *x, int64_t *y,
+                  double *t_out, double *stats_out);
+
 /* 24-byte hit record shared with the product ABI. */
 typedef struct { double dist; int32_t start, end, n, flags; } ora_hit;
 

@@ -70,3 +70,43 @@ def test_drna_cli_gpu(gpu, example_read, capsys):
     main(["-f", os.path.join(GOLD, "example_0.blow5")])
     out = capsys.readouterr().out
     assert out == load_golden("drna_cli.json")["stdout"].split("\n")[0] + "\n"
+
+
+# ---- the --signal branch (rolling mean); goldens: the reference's own code with its commented-out
+# ---- `# w = 2000` enabled in memory (tools/gen_golden.py), plus pandas' own statistics per read
+def _roll_reads():
+    from squigglekit_amd import synth
+    gold = load_golden("drna_roll.json")
+    reads = synth.drna_reads(20, 4242, min_len=9000, max_len=30000)
+    reads.append(np.full(9000, 500, dtype=np.int16))
+    reads.append(np.concatenate([np.full(4000, 300), np.full(9000, 600)]).astype(np.int16))
+    assert hashlib.sha256(np.concatenate(reads).tobytes()).hexdigest() == gold["sha256"], "generator drifted"
+    return reads, gold
+
+
+def _roll_lines(results):
+    return "".join("roll%02d.fast5\trid%02d\t%d\t%d\n" % (i, i, r[0], r[1]) for i, r in enumerate(results) if r)
+
+
+def test_oracle_rolling_branch_matches_reference_and_pandas(ora):
+    reads, gold = _roll_reads()
+    for run in gold["runs"]:
+        p = ora.RollParams(w=run["w"])
+        out = []
+        for r, st in zip(reads, run["stats"]):
+            f = ora.scale_outliers(r.astype(float), 0, 1200)
+            res, t, (mn, sd, bot) = ora.drna_roll(f, p, want_t=True)
+            assert f.size == st["n"]
+            assert hashlib.sha256(t.tobytes()).hexdigest() == st["t_sha256"]          # pandas rolling mean
+            assert (mn == st["mn"] or (np.isnan(mn) and np.isnan(st["mn"])))          # pandas t.mean()
+            assert (sd == st["std"] or (np.isnan(sd) and np.isnan(st["std"])))        # pandas t.std()
+            out.append(res)
+        assert _roll_lines(out) == run["stdout"]
+
+
+def test_oracle_rolling_edge_cases(ora):
+    assert ora.drna_roll(np.zeros(0)) is None
+    assert ora.drna_roll(np.full(100, 400.0)) is None                   # shorter than the window: all NaN
+    assert ora.drna_roll(np.full(9000, 400.0)) is None                  # constant: nothing below mn - 0 
+    res = ora.drna_roll(np.r_[np.full(6000, 300.0), np.full(20000, 600.0)])
+    assert res is not None and res[0] < res[1]

@@ -331,6 +331,47 @@ def main():
         "seed": 777, "n": 24, "sha256": digest(np.concatenate(dreads)),
         "stdout": so, "stderr": se, "exit": code})
 
+    # ---------------- dRNA_segmenter.py main() on its --signal branch (rolling mean) ----------------
+    # The branch reads the local `w` before it is assigned (dRNA_segmenter.py:282, UnboundLocalError); the
+    # script's own commented-out default is `# w = 2000` (:81).  To let the reference's code run (pandas
+    # rolling / mean / std, the scan, the print), that one line is un-commented IN MEMORY: the module source
+    # is read, patched and exec'd here; nothing of it is written anywhere.
+    import tempfile
+    import types
+    import pandas as pd
+    src = open(os.path.join(REF, "dRNA_segmenter.py")).read()
+    assert src.count("    # w = 2000\n") == 1
+
+    def patched_drna(w):
+        mod = types.ModuleType("dRNA_segmenter_w%d" % w)
+        exec(compile(src.replace("    # w = 2000\n", "    w = %d\n" % w), "dRNA_segmenter.py", "exec"), mod.__dict__)
+        return mod
+    rreads = synth.drna_reads(20, 4242, min_len=9000, max_len=30000)
+    rreads.append(np.full(9000, 500, dtype=np.int16))                       # constant: std 0, nothing below
+    rreads.append(np.concatenate([np.full(4000, 300), np.full(9000, 600)]).astype(np.int16))
+    roll_runs = []
+    for w in (2000, 1000):
+        with tempfile.NamedTemporaryFile("w", suffix=".tsv", delete=False) as fh:
+            for i, r in enumerate(rreads):
+                fh.write(tsv_line("roll%02d.fast5" % i, "rid%02d" % i, r.tolist(), extra=[0, 0]))
+            path = fh.name
+        so, se, code = run_main(patched_drna(w), ["dRNA_segmenter.py", "-s", path])
+        os.unlink(path)
+        stats = []
+        for r in rreads:                                                    # the dependency's own arithmetic
+            f = r.astype(np.int64)
+            f = f[(f > 0) & (f < 1200)]
+            t = pd.Series(f).rolling(window=w).mean()
+            stats.append({"n": int(f.size), "mn": float(t.mean()), "std": float(t.std()),
+                          "t_sha256": digest(t.values)})
+        roll_runs.append({"w": w, "stdout": so, "stderr": se, "exit": code, "stats": stats})
+    dump("drna_roll.json", {
+        "generator": "tools/gen_golden.py running /root/reference/dRNA_segmenter.py main() (-s branch) with its "
+                     "commented-out `# w = 2000` (line 81) enabled in memory (w = 2000 / 1000); pandas %s"
+                     % pd.__version__,
+        "reads": "synth.drna_reads(20, 4242, min_len=9000, max_len=30000) + constant 500 x 9000 + step 300 x 4000 | 600 x 9000",
+        "sha256": digest(np.concatenate(rreads)), "runs": roll_runs})
+
     # ---------------- numpy reductions the oracle must match bit-for-bit -----
     rng = np.random.default_rng(123)
     red = []
