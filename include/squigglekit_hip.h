@@ -131,6 +131,25 @@ typedef struct sk_drna_params {
 int sk_drna_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
                               const sk_drna_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs);
 
+/* ---- dRNA adapter segmenter, --signal branch (dRNA_segmenter.py:272-326): rolling mean -------- */
+/* t = pandas.Series(filtered).rolling(window=w).mean(); mn = t.mean(); std = t.std();
+ * bot = mn - std * std_scale; runs of t < bot, closed by t > bot, merged when closer than seg_dist;
+ * the first segment with lo_thresh <= length <= hi_thresh is reported as (start - shift, end - shift).
+ * The script reads `w` before assigning it (:282) -- its commented-out default (:81) is 2000. */
+typedef struct sk_roll_params {
+    int32_t w;              /* 2000    rolling window (min_periods = w)            */
+    int32_t seg_dist;       /* 1500                                                */
+    int32_t hi_thresh;      /* 200000                                              */
+    int32_t lo_thresh;      /* 2000                                                */
+    int32_t shift;          /* 1000    subtracted from both ends when reporting    */
+    double  std_scale;      /* 0.5                                                 */
+    int32_t lim_low;        /* 0       scale_outliers limits (:329-332)            */
+    int32_t lim_hi;         /* 1200                                                */
+} sk_roll_params;
+/* xy[2r], xy[2r+1] = the reported pair of read r when found[r] != 0. */
+int sk_drna_roll_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
+                           const sk_roll_params *p, int32_t *xy, int32_t *found);
+
 /* ---- MotifSeq path ---------------------------------------------------- */
 /* Replaces, per read r: scale_outliers (MotifSeq.py:274,317-324), medmad
  * (:192-200) or zscale (:186-191), then mlpy.dtw_subsequence(motif, sig)

@@ -55,6 +55,17 @@ class DrnaParams(C.Structure):
                          lim_low, lim_hi)
 
 
+class RollParams(C.Structure):
+    """sk_roll_params: the constants of dRNA_segmenter.py:288-295,322 and the rolling window `w` the
+    script reads before assigning (its commented-out default, :81, is 2000)."""
+    _fields_ = [("w", C.c_int32), ("seg_dist", C.c_int32), ("hi_thresh", C.c_int32), ("lo_thresh", C.c_int32),
+                ("shift", C.c_int32), ("std_scale", C.c_double), ("lim_low", C.c_int32), ("lim_hi", C.c_int32)]
+
+    def __init__(self, w=2000, seg_dist=1500, hi_thresh=200000, lo_thresh=2000, shift=1000, std_scale=0.5,
+                 lim_low=0, lim_hi=1200):
+        super().__init__(w, seg_dist, hi_thresh, lo_thresh, shift, std_scale, lim_low, lim_hi)
+
+
 class Hit(C.Structure):
     _fields_ = [("dist", C.c_double), ("start", C.c_int32), ("end", C.c_int32),
                 ("n", C.c_int32), ("flags", C.c_int32)]
@@ -84,6 +95,7 @@ ABI = {
     "sk_segment_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, C.POINTER(SegParams),
                                      _vp, _vp, C.c_int32]),
     "sk_drna_segment_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32]),
+    "sk_drna_roll_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, _vp]),
     "sk_motifseq_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, _vp]),
     "sk_motifseq_multi_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,

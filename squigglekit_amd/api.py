@@ -219,6 +219,22 @@ def test_segs(segs, args, err=None):
     return segs
 
 
+def drna_roll_reads(reads, params=None):
+    """dRNA_segmenter.py's --signal branch (:272-326) on raw integer reads: per read (x, y) -- the first
+    low rolling-mean segment of acceptable length, both ends shifted as the script prints them -- or None."""
+    if not len(reads):
+        return []
+    from ._lib import RollParams
+    L = _lib.ensure_init()
+    params = params or RollParams()
+    buf, lens = pack_i16(reads)
+    R = len(reads)
+    xy = np.zeros((R, 2), dtype=np.int32)
+    found = np.zeros(R, dtype=np.int32)
+    check(L.sk_drna_roll_batch_i16(ptr(buf), buf.shape[1], ptr(lens), R, C.byref(params), ptr(xy), ptr(found)))
+    return [(int(xy[i, 0]), int(xy[i, 1])) if found[i] else None for i in range(R)]
+
+
 # ----------------------------------------------------------------------------
 # MotifSeq path
 # ----------------------------------------------------------------------------

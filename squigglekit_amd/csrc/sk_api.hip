@@ -461,6 +461,52 @@ int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads, 
 }
 
 // ------------------------------------------------------------------ dRNA adapter segmenter
+// ------------------------------------------------------------------ dRNA --signal branch (rolling mean)
+int sk_drna_roll_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
+                           const sk_roll_params *p, int32_t *xy, int32_t *found)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    int rc = check_i16(sig, stride, len, nreads);
+    if (rc) return rc;
+    if (!p) return sk_fail(SK_ERR_INVALID, "NULL sk_roll_params");
+    if (p->w <= 0) return sk_fail(SK_ERR_INVALID, "the rolling window w must be positive");
+    if (nreads == 0) return SK_OK;
+    if (!xy || !found) return sk_fail(SK_ERR_INVALID, "NULL xy/found");
+    int32_t lo = p->lim_low, hi = p->lim_hi;
+    clamp_limits(&lo, &hi);
+    const int64_t words = (stride + 63) / 64;
+    const size_t sb = (size_t)nreads * (size_t)stride * sizeof(int16_t);
+    if ((rc = sk_reserve(c, &c->sig, sb))) return rc;
+    if ((rc = sk_reserve(c, &c->len, (size_t)nreads * sizeof(int32_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->comp, sb))) return rc;
+    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
+    if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * 2 * sizeof(uint64_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->misc, (size_t)nreads * (size_t)(stride + 1) * sizeof(int64_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->out, (size_t)nreads * 2 * sizeof(int32_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->out2, (size_t)nreads * sizeof(int32_t)))) return rc;
+    SK_HIP(hipMemcpyAsync(c->sig.p, sig, sb, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipMemcpyAsync(c->len.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    // filter + order-preserving compaction (the medmad kernel: its statistics are not used here)
+    rc = sk_launch_prep_i16(c, (const int16_t *)c->sig.p, stride, (const int32_t *)c->len.p, nreads, lo, hi,
+                            SK_PREP_MEDMAD, 0.0, (int16_t *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
+    if (rc) return rc;
+    uint64_t *below = (uint64_t *)c->mask.p, *above = below + (size_t)nreads * (size_t)words;
+    rc = sk_launch_roll_stats(c, (const int16_t *)c->comp.p, stride, (sk_prep *)c->prep.p, nreads, p->w,
+                              p->std_scale, (int64_t *)c->misc.p, below, above);
+    if (rc) return rc;
+    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+    rc = sk_launch_roll_walk(c, below, above, (const sk_prep *)c->prep.p, nreads, p, (int32_t *)c->out.p,
+                             (int32_t *)c->out2.p);
+    if (rc) return rc;
+    c->ev_valid = true;
+    SK_HIP(hipMemcpyAsync(xy, c->out.p, (size_t)nreads * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipMemcpyAsync(found, c->out2.p, (size_t)nreads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
+
 int sk_drna_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
                               const sk_drna_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs)
 {

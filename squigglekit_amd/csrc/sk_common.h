@@ -117,6 +117,15 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a);
 int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P, int ck, int span,
                           int32_t *d_retry_cnt, int32_t *d_retry);
 
+// ---- dRNA --signal branch (rolling mean): statistics + masks (sk_prep.hip), scan (sk_segment.hip) ----
+struct sk_roll_params;
+// comp / prep as left by sk_launch_prep_i16; psum: nreads * (stride + 1) int64 scratch; masks: two
+// transposed bit masks (t < bot, t > bot), `words` words per read each, word wi of read r at [wi * nreads + r]
+int sk_launch_roll_stats(sk_ctx *c, const int16_t *d_comp, int64_t stride, sk_prep *d_prep, int32_t nreads,
+                         int32_t w, double std_scale, int64_t *d_psum, uint64_t *d_below, uint64_t *d_above);
+int sk_launch_roll_walk(sk_ctx *c, const uint64_t *d_below, const uint64_t *d_above, const sk_prep *d_prep,
+                        int32_t nreads, const sk_roll_params *p, int32_t *d_xy, int32_t *d_found);
+
 // ---- segment walk (sk_segment.hip) ----
 struct sk_drna_params;
 int sk_launch_drna_walk(sk_ctx *c, const uint64_t *d_mask, int64_t mask_rows, const sk_prep *d_prep,

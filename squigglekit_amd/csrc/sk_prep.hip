@@ -838,7 +838,92 @@ void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// dRNA_segmenter.py --signal branch (:272-326): rolling mean of the filtered signal
+// ------------------------------------------------------------------------------------------
+// t = Series(filtered).rolling(window=w).mean(): pandas' roll_mean keeps a Kahan-compensated running
+// sum (add the entering sample, remove the leaving one) and divides by the count.  The samples are
+// integers and every window sum is far below 2^53, so all of those additions are exact and
+// t[i] = (double)(window sum) / w with ONE rounding -- whatever the order.  The kernel therefore takes
+// the window sums from an exact int64 prefix sum.  mn = t.mean() and std = t.std() are pandas nanops:
+// NaN (the first w - 1 entries) replaced by 0, numpy sums, ddof = 1 -- the numpy-order summation
+// above.  Output: mn / std / bot in the read's record and the two bit masks t < bot, t > bot.
+__global__ __launch_bounds__(TPB)
+void k_roll_stats(const int16_t *__restrict__ comp, int64_t stride, sk_prep *__restrict__ prep, int nreads,
+                  int w, double std_scale, int64_t *__restrict__ psum,
+                  uint64_t *__restrict__ below, uint64_t *__restrict__ above, int64_t mask_rows)
+{
+    __shared__ Scratch sc_;
+    Scratch *sc = &sc_;
+    const int r = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n = prep[r].n;
+    const int16_t *crow = comp + (int64_t)r * stride;
+    int64_t *P = psum + (int64_t)r * (stride + 1);           // P[i] = sum of the first i filtered samples
+    if (tid == 0) { sc->tree_m = -1; P[0] = 0; }
+
+    long long carry = 0;
+    int parity = 0;
+    for (int base = 0; base < n; base += TPB * 8, parity ^= 1) {
+        const int i0 = base + tid * 8;
+        int v[8], tsum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { v[k] = (i0 + k < n) ? (int)crow[i0 + k] : 0; tsum += v[k]; }
+        int total;
+        const int excl = block_excl_scan(tsum, sc->wsum[parity], &total);     // < 2^31: 2048 * 32767
+        long long run = carry + excl;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            run += v[k];
+            if (i0 + k < n) P[i0 + k + 1] = run;
+        }
+        carry += total;
+    }
+    __syncthreads();                                         // the prefix sums are read by everybody
+
+    const long long cnt = (n >= w) ? (long long)n - w + 1 : 0;               // entries of t that are not NaN
+    const double dw = (double)w;
+    auto tval = [&](int i) -> double { return (double)(P[i + 1] - P[i + 1 - w]) / dw; };   // i >= w - 1
+    const double mn = numpy_sum(n, sc, [&](int i) { return (i >= w - 1) ? tval(i) : 0.0; }) / (double)cnt;
+    const double ss = numpy_sum(n, sc, [&](int i) {
+        if (i < w - 1) return 0.0;
+        const double d = mn - tval(i);
+        return d * d;
+    });
+    const double sd = sqrt(ss / (double)(cnt - 1));          // ddof = 1 (NaN for a single entry, like pandas)
+    const double bot = mn - (sd * std_scale);                // dRNA_segmenter.py:288
+    if (tid == 0) {
+        sk_prep pr = prep[r];
+        pr.center = mn; pr.scale = sd; pr.top = bot; pr.bot = bot;
+        prep[r] = pr;
+    }
+    for (int base = 0; base < n; base += TPB) {
+        const int i = base + tid;
+        bool lt = false, gt = false;
+        if (i < n && i >= w - 1) {
+            const double t = tval(i);
+            lt = t < bot;                                    // :297 / :300
+            gt = t > bot;                                    // :302
+        }
+        const unsigned long long bl = __ballot(lt), ba = __ballot(gt);
+        if (lane == 0) {
+            below[(int64_t)(i >> 6) * mask_rows + r] = bl;
+            above[(int64_t)(i >> 6) * mask_rows + r] = ba;
+        }
+    }
+}
+
 } // namespace
+
+int sk_launch_roll_stats(sk_ctx *c, const int16_t *d_comp, int64_t stride, sk_prep *d_prep, int32_t nreads,
+                         int32_t w, double std_scale, int64_t *d_psum, uint64_t *d_below, uint64_t *d_above)
+{
+    if (nreads <= 0) return SK_OK;
+    hipLaunchKernelGGL(k_roll_stats, dim3(nreads), dim3(TPB), 0, c->stream, d_comp, stride, d_prep, nreads, w,
+                       std_scale, d_psum, d_below, d_above, (int64_t)nreads);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
+}
 
 int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len,
                        int32_t nreads, int32_t lo, int32_t hi, int mode, double std_scale,

@@ -216,7 +216,67 @@ void k_drna_walk(const uint64_t *__restrict__ maskT, int64_t mask_rows,
     nsegs[r] = nseg;
 }
 
+// dRNA_segmenter.py --signal branch, the scan over the rolling mean (:296-326): runs of t < bot
+// (mask `below`), closed by the first t > bot (mask `above`; NaN or t == bot change nothing), merged into
+// the previous segment when they start less than seg_dist after its end, and the first segment whose
+// length lies in [lo_thresh, hi_thresh] is reported, both ends shifted.  One lane per read; a segment
+// can only be judged once the next one has been appended (or the read ends), because merges extend it.
+struct RollWalk { int seg_dist, hi_thresh, lo_thresh, shift; };
+
+__global__ __launch_bounds__(64)
+void k_roll_walk(const uint64_t *__restrict__ below, const uint64_t *__restrict__ above, int64_t mask_rows,
+                 const sk_prep *__restrict__ prep, int nreads, RollWalk p,
+                 int32_t *__restrict__ xy, int32_t *__restrict__ found)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nreads) return;
+    const int n = prep[r].n;
+    bool begin = false, done = false;
+    int start = 0, end = 0, nseg = 0, sa = 0, sb = 0, fx = 0, fy = 0;
+    auto judge = [&]() {                                      // :318-326 on the segment (sa, sb)
+        const int len = sb - sa;
+        if (!done && len <= p.hi_thresh && len >= p.lo_thresh) { fx = sa - p.shift; fy = sb - p.shift; done = true; }
+    };
+    for (int wi = 0; wi * 64 < n; wi++) {
+        const uint64_t B = below[(int64_t)wi * mask_rows + r], A = above[(int64_t)wi * mask_rows + r];
+        if (!begin && B == 0ull) continue;                    // nothing opens in this word
+        const int lim = min(64, n - wi * 64);
+        for (int b = 0; b < lim; b++) {
+            const int i = wi * 64 + b;
+            if ((B >> b) & 1) {
+                if (!begin) { start = i; begin = true; }      // :297-299
+                else end = i;                                 // :300-301
+            } else if (begin && ((A >> b) & 1)) {             // :302-309
+                if (nseg > 0 && start - sb < p.seg_dist) sb = end;
+                else {
+                    if (nseg > 0) judge();                    // the previous segment is final now
+                    sa = start; sb = end; nseg++;
+                }
+                start = 0; end = 0; begin = false;
+            }
+        }
+    }
+    if (nseg > 0) judge();
+    found[r] = done ? 1 : 0;
+    xy[2 * r] = fx; xy[2 * r + 1] = fy;
+}
+
 } // namespace
+
+int sk_launch_roll_walk(sk_ctx *c, const uint64_t *d_below, const uint64_t *d_above, const sk_prep *d_prep,
+                        int32_t nreads, const sk_roll_params *p, int32_t *d_xy, int32_t *d_found)
+{
+    if (nreads <= 0) return SK_OK;
+    RollWalk wp;
+    wp.seg_dist = p->seg_dist; wp.hi_thresh = p->hi_thresh; wp.lo_thresh = p->lo_thresh; wp.shift = p->shift;
+    const int grid = (nreads + 63) / 64;
+    SK_HIP(hipEventRecord(c->ev[2], c->stream));
+    hipLaunchKernelGGL(k_roll_walk, dim3(grid), dim3(64), 0, c->stream, d_below, d_above, (int64_t)nreads, d_prep,
+                       nreads, wp, d_xy, d_found);
+    SK_HIP(hipGetLastError());
+    SK_HIP(hipEventRecord(c->ev[3], c->stream));
+    return SK_OK;
+}
 
 int sk_launch_drna_walk(sk_ctx *c, const uint64_t *d_mask, int64_t mask_rows, const sk_prep *d_prep,
                         int32_t nreads, const sk_drna_params *p, int32_t *d_segs, int32_t *d_nsegs,

@@ -110,3 +110,27 @@ def test_oracle_rolling_edge_cases(ora):
     assert ora.drna_roll(np.full(9000, 400.0)) is None                  # constant: nothing below mn - 0 
     res = ora.drna_roll(np.r_[np.full(6000, 300.0), np.full(20000, 600.0)])
     assert res is not None and res[0] < res[1]
+
+
+@pytest.mark.gpu
+def test_gpu_rolling_branch(gpu, ora):
+    """HIP path of the --signal branch vs the reference's stdout (both windows) and vs the oracle over
+    parameter corners, short reads and reads with outliers."""
+    from squigglekit_amd import api
+    from squigglekit_amd._lib import RollParams
+    reads, gold = _roll_reads()
+    for run in gold["runs"]:
+        got = api.drna_roll_reads(reads, RollParams(w=run["w"]))
+        assert _roll_lines(got) == run["stdout"]
+    extra = reads + [np.zeros(0, dtype=np.int16), np.full(100, 400, dtype=np.int16),
+                     np.full(2000, 400, dtype=np.int16), np.full(2001, 400, dtype=np.int16),
+                     np.r_[np.full(6000, 300), np.full(20000, 600)].astype(np.int16)]
+    extra[3][::97] = 2000                                   # outliers: the filter shifts every coordinate
+    for kw in (dict(), dict(w=7, lo_thresh=3, seg_dist=2, shift=0), dict(w=1200, std_scale=0.1, lo_thresh=100),
+               dict(w=500, seg_dist=100000), dict(lim_low=300, lim_hi=700, w=300, lo_thresh=50)):
+        p = RollParams(**kw)
+        got = api.drna_roll_reads(extra, p)
+        okw = {k: v for k, v in kw.items() if not k.startswith("lim")}
+        for r, g in zip(extra, got):
+            f = ora.scale_outliers(r.astype(float), p.lim_low, p.lim_hi)
+            assert g == ora.drna_roll(f, ora.RollParams(**okw)), (kw, len(r))
