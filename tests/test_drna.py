@@ -134,3 +134,23 @@ def test_gpu_rolling_branch(gpu, ora):
         for r, g in zip(extra, got):
             f = ora.scale_outliers(r.astype(float), p.lim_low, p.lim_hi)
             assert g == ora.drna_roll(f, ora.RollParams(**okw)), (kw, len(r))
+
+
+@pytest.mark.gpu
+def test_cli_signal_branch(gpu, tmp_path, capsys):
+    """`dRNA_segmenter.py -s file.tsv [-w N]` prints what the reference's branch prints once its window is
+    defined; --strict-compat keeps the reference's failure."""
+    from squigglekit_amd import drna_cli
+    reads, gold = _roll_reads()
+    tsv = tmp_path / "roll.tsv"
+    with open(tsv, "w") as fh:
+        for i, r in enumerate(reads):
+            fh.write("\t".join(["roll%02d.fast5" % i, "rid%02d" % i, "0", "0"] + [str(v) for v in r.tolist()]) + "\n")
+    for run in gold["runs"]:
+        drna_cli.main(["-s", str(tsv), "-w", str(run["w"]), "--batch", "7"])
+        assert capsys.readouterr().out == run["stdout"]
+    drna_cli.main(["-s", str(tsv)])                              # default window = the commented-out 2000
+    assert capsys.readouterr().out == gold["runs"][0]["stdout"]
+    with pytest.raises(SystemExit) as e:
+        drna_cli.main(["-s", str(tsv), "--strict-compat"])
+    assert e.value.code == 1 and "UnboundLocalError" in capsys.readouterr().err
