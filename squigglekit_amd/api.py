@@ -281,6 +281,28 @@ def motifseq_any(reads, motif, scale="medmad", scale_low=0, scale_hi=1200):
     return out
 
 
+def stall_cuts(reads, seg_params=None):
+    """[extension -- the author's TODO "integration with MotifSeq", segmenter.py:35]  Per read, the raw
+    index right after the first segment the segmenter finds (the stall at the start of a read), 0 when it
+    finds none: the filtered coordinate get_segs reports is mapped back through scale_outliers' mask."""
+    params = seg_params or SegParams()
+    cuts = np.zeros(len(reads), dtype=np.int64)
+    for i, (r, s) in enumerate(zip(reads, segment_any(reads, params))):
+        if s:
+            a = np.asarray(r)
+            kept = np.flatnonzero((a > params.lim_low) & (a < params.lim_hi))      # segmenter.py:311-318
+            e = s[0][1]
+            cuts[i] = int(kept[e]) if e < kept.size else int(a.size)
+    return cuts
+
+
+def motifseq_after_stall(reads, motif, scale="medmad", scale_low=0, scale_hi=1200, seg_params=None):
+    """[extension]  MotifSeq on what follows the stall: reads[i][cut:] goes through the usual filter,
+    normalisation and subsequence DTW.  Returns (hits, cuts); hit coordinates index the filtered slice."""
+    cuts = stall_cuts(reads, seg_params)
+    return motifseq_any([np.asarray(r)[c:] for r, c in zip(reads, cuts)], motif, scale, scale_low, scale_hi), cuts
+
+
 def motifseq_multi(reads, motifs, scale="medmad", scale_low=0, scale_hi=1200):
     """Every motif of `motifs` (list of float vectors) against every read: list (one per motif,
     in order) of HIT_DTYPE arrays in read order -- the double loop of MotifSeq.py:261-298,436.

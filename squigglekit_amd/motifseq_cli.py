@@ -45,6 +45,10 @@ def build_parser():
                    help="scrappie squiggle model used for -i")
     mod.add_argument("-m", "--model", help="pre-computed motif signal: scrappie squiggle text or name/len/x/values TSV")
     p.add_argument("-x", "--sig_extract", action="store_true", help="append the matched normalised signal")
+    p.add_argument("--after_stall", action="store_true",
+                   help="[extension] run the segmenter first and search only the signal after its first segment "
+                        "(the stall); coordinates then index that slice and a last column `search_from` gives "
+                        "the raw sample index where it starts")
     p.add_argument("--slope", type=float, default=2.90, help="[experimental] distance model slope")
     p.add_argument("--intercept", type=float, default=-9.6, help="[experimental] distance model intercept")
     p.add_argument("--std_const", type=float, default=0.08468, help="[experimental] distance model stdev factor")
@@ -115,6 +119,12 @@ class _Batcher:
         a = self.args
         live = [i for i, s in enumerate(self.sigs) if s is not None]
         sigs = [self.sigs[i] for i in live]
+        cuts = None
+        if a.after_stall and sigs:                    # [extension] search only after the segmenter's first segment
+            cuts = api.stall_cuts(sigs)
+            sigs = [np.asarray(s)[c:] for s, c in zip(sigs, cuts)]
+            for i, s in zip(live, sigs):
+                self.sigs[i] = s
         hits = (api.motifseq_multi(sigs, [np.asarray(self.models[name], dtype=np.float64) for name in self.order],
                                    a.scale, a.scale_low, a.scale_hi) if sigs else [[] for _ in self.order])
         slot = {i: k for k, i in enumerate(live)}
@@ -140,6 +150,8 @@ class _Batcher:
                     if norm is None:
                         norm = api.normalise(self.sigs[i], a.scale, a.scale_low, a.scale_hi)
                     row.append("\t".join(str(v) for v in norm[start:end]))
+                if cuts is not None:
+                    row.append(int(cuts[r]))
                 print("\t".join("{}".format(v) for v in row))
         self.meta, self.sigs = [], []
 
@@ -163,7 +175,8 @@ def main(argv=None):
         sys.stderr.write("MotifSeq: -v/--save plotting is not part of this build; ignoring\n")
 
     models, order, lens = load_models(args)
-    print("\t".join(HEADER + (["normalised_signal"] if args.sig_extract else [])))    # MotifSeq.py:160-163
+    print("\t".join(HEADER + (["normalised_signal"] if args.sig_extract else [])
+                    + (["search_from"] if args.after_stall else [])))                  # MotifSeq.py:160-163
 
     if not (args.f5f or args.f5_path or args.signal):
         sys.stderr.write("Unknown file or path input")

@@ -307,3 +307,27 @@ def test_small_batches_on_the_16_lane_layout(gpu, ora, monkeypatch, nx):
     got = api.motifseq_batch(sig, lens, motif)
     ok = (got["flags"] & 2) == 0
     _assert_hits(got[ok], want[ok], "16-lane layout, %d points" % nx)
+
+
+def test_motifseq_after_stall_extension(gpu, ora, example_model):
+    """[extension] search only after the stall the segmenter finds: equals the composition of the two
+    reference stages -- get_segs on the filtered read, then MotifSeq on raw[cut:]."""
+    from squigglekit_amd import api, synth
+    sig = synth.squiggle_batch(48, 4000, 60606, motif=example_model)
+    reads = [sig[r] for r in range(48)]
+    hits, cuts = api.motifseq_after_stall(reads, example_model)
+    ncut = 0
+    for r, x in enumerate(reads):
+        f = ora.scale_outliers(x.astype(float), 0, 900)
+        segs = ora.get_segs(f)
+        cut = 0
+        if segs:
+            kept = np.flatnonzero((x > 0) & (x < 900))
+            e = segs[0][1]
+            cut = int(kept[e]) if e < kept.size else x.size
+            ncut += 1
+        assert cuts[r] == cut
+        y = ora.medmad(ora.scale_outliers(x[cut:].astype(float), 0, 1200))[0]
+        d, s0, e0 = ora.dtw_subsequence(example_model, y)
+        assert (hits["dist"][r], hits["start"][r], hits["end"][r]) == (d, s0, e0), r
+    assert ncut >= 40                                  # the synthetic reads start with a stall
