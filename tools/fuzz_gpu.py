@@ -95,6 +95,23 @@ def main():
             if gsegs != wsegs:
                 bad += 1
                 print("F64 SEGMENTER mismatch kind %d n=%d" % (kinds, len(x)))
+        # ---- dRNA_segmenter: both branches on a few long ragged reads ----
+        if rounds % 4 == 0:
+            from squigglekit_amd._lib import DrnaParams, RollParams
+            dreads = synth.drna_reads(int(rng.integers(1, 9)), int(rng.integers(1 << 30)),
+                                      min_len=int(rng.choice([300, 3000, 9000])), max_len=26000)
+            dkw = [dict(), dict(error=2, no_err_thresh=0, w=50, window=30, seg_dist=100),
+                   dict(t_start=0, t_end=2000, std_scale=0.2)][int(rng.integers(3))]
+            for x, g in zip(dreads, api.drna_segment_reads(dreads, DrnaParams(**dkw))):
+                if g != ora.drna_segs(ora.scale_outliers(x.astype(float), 0, 1200), ora.DrnaParams(**dkw))[0]:
+                    bad += 1
+                    print("DRNA mismatch n=%d %s" % (len(x), dkw))
+            rkw = [dict(), dict(w=int(rng.choice([3, 64, 999, 2000, 5000]))),
+                   dict(w=800, lo_thresh=200, seg_dist=int(rng.choice([1, 300, 5000])), std_scale=0.25)][int(rng.integers(3))]
+            for x, g in zip(dreads, api.drna_roll_reads(dreads, RollParams(**rkw))):
+                if g != ora.drna_roll(ora.scale_outliers(x.astype(float), 0, 1200), ora.RollParams(**rkw)):
+                    bad += 1
+                    print("DRNA ROLL mismatch n=%d %s" % (len(x), rkw))
     print("fuzz: %d rounds, %d mismatching configurations" % (rounds, bad))
     sys.exit(1 if bad else 0)
 
