@@ -169,51 +169,74 @@ void k_segment_walk(const uint64_t *__restrict__ maskT, int64_t mask_rows,
 // band for more than seg_dist samples after the last segment.
 struct DrnaWalk { int error, no_err_thresh, w, window, seg_dist; };
 
+// Straight-line per-sample update (the 64 lanes are 64 reads in different states): flags are 0/1
+// integers, `cm` tracks c mod w so that the corrector test `c % w == 0` (:121 / :133) needs no division,
+// and only "close a segment that is long enough" branches.  A lane whose scan has stopped ("adapter
+// found", :152) or whose read has ended just stops changing; the wave skips words in which no lane
+// can change state.
 __global__ __launch_bounds__(64)
 void k_drna_walk(const uint64_t *__restrict__ maskT, int64_t mask_rows,
                  const sk_prep *__restrict__ prep, int nreads, DrnaWalk p,
                  int32_t *__restrict__ segs, int32_t *__restrict__ nsegs, int max_segs)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nreads) return;
-    const int n = prep[r].n;
-    int32_t *my = segs + (int64_t)r * 2 * max_segs;
-    bool prev = false, done = false;
-    int err = 0, prev_err = 0, c = 0, start = 0, nseg = 0, last_end = 0;
-    for (int wi = 0; wi * 64 < n && !done; wi++) {
-        const uint64_t word = maskT[(int64_t)wi * mask_rows + r];
-        const int lim = min(64, n - wi * 64);
-        for (int b = 0; b < lim; b++) {
-            const int i = wi * 64 + b;
-            if ((word >> b) & 1) {                                         // a < top  (:114)
-                if (!prev) { start = i; prev = true; err = 0; }
-                c++; prev_err = 0;
-                if (c >= p.window && c >= p.w && (c % p.w) == 0) err--;
-            } else if (prev) {
-                if (err < p.error) {                                       // :129
-                    c++;
-                    if (i >= p.no_err_thresh) { err++; prev_err++; }
-                    if (c >= p.window && c >= p.w && (c % p.w) == 0) err--;
-                } else {
-                    if (c >= p.window) {                                   // :137 close
-                        const int end = i - prev_err;
-                        if (nseg > 0 && start - last_end < p.seg_dist) {
-                            if (nseg <= max_segs) my[2 * (nseg - 1) + 1] = end;
-                        } else {
-                            if (nseg < max_segs) { my[2 * nseg] = start; my[2 * nseg + 1] = end; }
-                            nseg++;
-                        }
-                        last_end = end;
-                    }
-                    prev = false; c = 0; err = 0; prev_err = 0;
-                }
-            } else if (nseg > 0 && i - last_end > p.seg_dist) {            // :152 adapter found
-                done = true;
-                break;
-            }
+    const bool live = r < nreads;
+    const int n = live ? prep[r].n : 0;
+    int32_t *my = segs + (int64_t)(live ? r : 0) * 2 * max_segs;
+    int prev = 0, done = 0;
+    int err = 0, prev_err = 0, c = 0, cm = 0, start = 0, nseg = 0, last_end = 0;
+    int nmax = n;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+    for (int wi = 0; wi * 64 < nmax; wi++) {
+        const bool mine = !done && wi * 64 < n;
+        const uint64_t word = mine ? maskT[(int64_t)wi * mask_rows + r] : 0ull;
+        if (__all(!mine || (!prev && word == 0ull))) {
+            // no lane can open or continue a segment in these 64 samples: only the "adapter found" test
+            // (:152) can fire, and it fires somewhere in the word iff it fires at its last sample
+            const int last = min(wi * 64 + 63, n - 1);
+            if (mine && nseg > 0 && last - last_end > p.seg_dist) done = 1;
+            if (__all(done || (wi + 1) * 64 >= n)) break;
+            continue;
         }
+        for (int h = 0; h < 2; h++) {
+        const unsigned bits = h ? (unsigned)(word >> 32) : (unsigned)word;
+#pragma unroll 8
+        for (int b = 0; b < 32; b++) {
+            const int i = wi * 64 + h * 32 + b;
+            const int valid = (int)(i < n) & (done ^ 1);
+            const int inb = valid & (int)((bits >> b) & 1u);                    // a < top (:114)
+            const int opening = inb & (prev ^ 1);
+            start = opening ? i : start;
+            err = opening ? 0 : err;                                            // :117 re-arms the budget
+            const int tol = valid & (inb ^ 1) & prev & (int)(err < p.error);    // :129
+            const int act = inb | tol;
+            const int closing = valid & prev & (act ^ 1);
+            if (closing && c >= p.window) {                                     // :137 close
+                const int end = i - prev_err;
+                if (nseg > 0 && start - last_end < p.seg_dist) {
+                    if (nseg <= max_segs) my[2 * (nseg - 1) + 1] = end;
+                } else {
+                    if (nseg < max_segs) { my[2 * nseg] = start; my[2 * nseg + 1] = end; }
+                    nseg++;
+                }
+                last_end = end;
+            }
+            const int adapter = valid & (inb ^ 1) & (prev ^ 1) & (int)(nseg > 0) &
+                                (int)(i - last_end > p.seg_dist);               // :152
+            const int e1 = tol & (int)(i >= p.no_err_thresh);                   // :131
+            c = act ? c + 1 : (closing ? 0 : c);
+            cm = act ? ((cm + 1 == p.w) ? 0 : cm + 1) : (closing ? 0 : cm);
+            err = closing ? 0 : err + e1;
+            prev_err = (inb | closing) ? 0 : prev_err + e1;
+            err -= act & (int)(cm == 0) & (int)(c >= p.window);                 // c % w == 0 (then c >= w too)
+            prev = closing ? 0 : (prev | opening);
+            done |= adapter;
+        }
+        }
+        if (__all(done || (wi + 1) * 64 >= n)) break;
     }
-    nsegs[r] = nseg;
+    if (live) nsegs[r] = nseg;
 }
 
 // dRNA_segmenter.py --signal branch, the scan over the rolling mean (:296-326): runs of t < bot
