@@ -1,23 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- whole-job throughput of the SquiggleKit hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload motifseq|segmenter]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload motifseq|segmenter] [--scaling weak|strong]
 
-Headline (BASELINE.json `metric`): reads/s of the MotifSeq path -- scale_outliers ->
-medmad -> subsequence DTW -- for 4 000-sample int16 reads against a 200-point motif
-(config C4: 1 000 000 reads per GPU, seed 20260929 + rank, synthetic squiggles generated
-on the device).  One "step" = one pass of the hot path (prep kernel + DTW kernel) over the
-whole HBM-resident batch; inputs are already in HBM when the timed region starts.
+Headline (BASELINE.json `metric`): reads/s of the MotifSeq path -- scale_outliers -> medmad -> subsequence
+DTW -- for 4 000-sample int16 reads against a 200-point motif (config C4: 1 000 000 reads, seed 20260929 +
+rank, synthetic squiggles generated on the device).  One "step" = one pass of the hot path (prep kernel + DTW
+kernels) over the whole HBM-resident batch; inputs are already in HBM when the timed region starts.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): reads are sharded, no data-path
-collective; torch.distributed (backend nccl == RCCL) provides the barrier, the MAX over
-ranks of the elapsed time and the final all-gather of the 24-byte hit records.  torch is
-plumbing only -- the kernels, memory and stream are the library's own (ctypes C ABI).
+N > 1: reads are block-sharded over the GPUs, no data-path collective; each step ends with the one exchange
+the path has, an RCCL all-gather of the 24-byte hit records (`sk_comm_allgather_dev`, csrc/sk_comm.hip).
+Two launch shapes give the same line (squigglekit_amd/multigpu.py):
+    python bench.py --gpus N                                     one process, one host thread per GPU
+    python -m torch.distributed.run --nproc-per-node N bench.py --gpus N      one process per GPU; only the
+                     launcher's environment is read (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT) -- torch is
+                     never imported; rank 0's ncclUniqueId travels through a file store under $TMPDIR.
+`--scaling weak` (default): --reads per GPU (C4 on every GPU); `--scaling strong`: --reads in total (C4 as
+BASELINE.json words it: 1 M reads sharded 1/2/4/8).  With N > 1 the weak run also reports a short strong run.
 
-Rank 0 prints ONE JSON line with the driver's contract plus `roofline` (HIP-event kernel
-time vs algorithmic bytes; the VALU view is inside it because this kernel is FP64-VALU bound,
-see DESIGN.md) and `cpu_baseline` (the oracle's mlpy-style C restatement timed on one host
-core over a bounded sample of the same reads -- the only place the oracle is timed).
+Rank 0 prints ONE JSON line with the driver's contract plus `roofline` (HIP-event kernel time vs algorithmic
+bytes, and the VALU-issue view that actually binds this kernel -- DESIGN.md 4.3), `cpu_baseline` (the oracle
+timed on the host: the only place it is timed), `parity` (a sample strided over the whole batch, checked
+against the oracle) and, at N = 1, `secondary` (segmenter line), `exact_only_reads_per_s` and `end_to_end`.
 """
 import argparse
 import ctypes as C
@@ -33,269 +37,514 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_F64_LANEOPS = 256 * 4 * 16 * 2.4e9   # 3.93e13 f64 add/min/cmp lane-ops per second
+WAVE_ISSUE_SLOTS = 256 * 4 * 64 * 2.4e9   # lane-results per second if every SIMD issued a wave64 VALU op per cycle
 HIT_BYTES = 24
+MAX_SEGS = 16
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="motifseq", choices=["motifseq", "segmenter"])
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --reads per GPU; strong: --reads in total, sharded over the GPUs")
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (weak) or in total (strong)")
     ap.add_argument("--samples", type=int, default=4000)
     ap.add_argument("--motif", type=int, default=200, help="motif points")
     ap.add_argument("--scale", default="medmad", choices=["medmad", "zscale"])
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=1,
-                    help="additionally time the CPU baseline over this many host threads (reads split "
-                         "across threads; reported as cpu_baseline.threaded, the headline stays 1 core)")
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="1-core CPU baseline budget (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=-1,
+                    help="threads of the all-cores CPU baseline (-1 = every host core, 0 = skip)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the N = 1 extras (secondary segmenter line, exact-only schemes, end-to-end ingest)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="N = 1: still create the RCCL communicator and gather every step (exercises the N > 1 path)")
+    return ap.parse_args(argv)
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (a.gpus, a.gpus))
-        a.gpus = world
+# ----------------------------------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------------------------------
+def strided_rows(total, want, run=8):
+    """About `want` row indices spread over the whole batch: runs of `run` consecutive rows at evenly spaced
+    positions, first and last rows included."""
+    nruns = max(2, want // run)
+    starts = np.unique(np.linspace(0, max(0, total - run), nruns).astype(np.int64))
+    idx = (starts[:, None] + np.arange(run)[None, :]).ravel()
+    return np.unique(idx[(idx >= 0) & (idx < total)])
 
-    from squigglekit_amd import _lib, synth
-    from squigglekit_amd._lib import SegParams, check, ptr, HIT_DTYPE
 
-    dist = None
-    torch = None
-    use_dist = world > 1 or os.environ.get("SK_BENCH_FORCE_DIST") == "1"   # force: exercise the RCCL path on 1 GPU
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    L = _lib.load()
-    _lib.init(local)
+def download_rows(L, d_base, row_bytes, rows, dtype, row_items, run=8):
+    """Rows `rows` (sorted) of a device array -> numpy; consecutive rows travel in one copy."""
+    from squigglekit_amd._lib import check
+    base = C.cast(d_base, C.c_void_p).value
+    out = np.empty((len(rows), row_items), dtype=dtype)
+    k = 0
+    while k < len(rows):
+        j = k
+        while j + 1 < len(rows) and rows[j + 1] == rows[j] + 1 and j + 1 - k < 4096:
+            j += 1
+        view = out[k:j + 1]
+        check(L.sk_dev_download(view.ctypes.data_as(C.c_void_p), C.c_void_p(base + int(rows[k]) * row_bytes),
+                                view.nbytes))
+        k = j + 1
+    return out
 
-    R, M, N = a.reads, a.samples, a.motif
-    stride = (M + 7) // 8 * 8
-    motif = synth.synthetic_motif(N)
-    seed = (synth.SEED_C4 if a.workload == "motifseq" else synth.SEED_C2) + rank
 
-    # ---- device-resident inputs -------------------------------------------------------
-    d_sig = L.sk_dev_alloc(R * stride * 2)
-    d_len = L.sk_dev_alloc(R * 4)
-    if not d_sig or not d_len:
-        check(-4)
-    lens = np.full(R, M if a.workload == "motifseq" else M - 1, dtype=np.int32)   # segmenter: Num=-1
-    check(L.sk_dev_upload(d_len, ptr(lens), lens.nbytes))
-    check(L.sk_synth_squiggles_dev(d_sig, stride, R, M, seed, ptr(motif), N))
+class Workload:
+    """Device-resident inputs and outputs of one rank, and its step()."""
 
-    max_segs = 16
-    if a.workload == "motifseq":
-        if use_dist:
-            out_t = torch.empty(R * HIT_BYTES, dtype=torch.uint8, device="cuda")
-            gath_t = torch.empty(world * R * HIT_BYTES, dtype=torch.uint8, device="cuda")
-            d_out = C.c_void_p(out_t.data_ptr())
+    def __init__(self, a, L, rank, world, R, workload=None, comm=None, gather_pad=None):
+        from squigglekit_amd import _lib, synth
+        from squigglekit_amd._lib import SegParams, check, ptr
+        self.a, self.L, self.R, self.rank, self.world, self.comm = a, L, R, rank, world, comm
+        self.kind = workload or a.workload
+        M, N = a.samples, a.motif
+        self.M, self.N = M, N
+        self.stride = (M + 7) // 8 * 8
+        self.motif = synth.synthetic_motif(N)
+        self.seed = (synth.SEED_C4 if self.kind == "motifseq" else synth.SEED_C2) + rank
+        self.mode = _lib.SK_SCALE[a.scale]
+        self.bufs = []
+        alloc = self._alloc
+        self.d_sig = alloc(max(1, R) * self.stride * 2)
+        self.d_len = alloc(max(1, R) * 4)
+        self.lens = np.full(R, M if self.kind == "motifseq" else M - 1, dtype=np.int32)   # segmenter: Num = -1
+        if R:
+            check(L.sk_dev_upload(self.d_len, ptr(self.lens), self.lens.nbytes))
+            check(L.sk_synth_squiggles_dev(self.d_sig, self.stride, R, M, self.seed, ptr(self.motif), N))
+        self.pad = gather_pad if gather_pad is not None else R
+        self.rec_bytes = HIT_BYTES if self.kind == "motifseq" else 4
+        if self.kind == "motifseq":
+            self.d_out = alloc(max(1, self.pad) * HIT_BYTES)
         else:
-            d_out = L.sk_dev_alloc(R * HIT_BYTES)
-        mode = _lib.SK_SCALE[a.scale]
+            self.d_segs = alloc(max(1, R) * MAX_SEGS * 2 * 4)
+            self.d_out = alloc(max(1, self.pad) * 4)                  # nsegs: the fixed-size record gathered
+            self.sp = SegParams()
+        self.d_all = alloc(max(1, self.pad) * self.rec_bytes * world) if comm is not None else None
 
-        def step():
-            check(L.sk_motifseq_dev_i16(d_sig, stride, d_len, R, ptr(motif), N, mode, 0, 1200, d_out))
-            check(L.sk_sync())
-            if use_dist:                       # the one exchange: gather of the hit records (RCCL)
-                dist.all_gather_into_tensor(gath_t, out_t)
-                torch.cuda.current_stream().synchronize()   # out_t is rewritten by the next step
-    else:
-        d_segs = L.sk_dev_alloc(R * max_segs * 2 * 4)
-        d_nsegs = L.sk_dev_alloc(R * 4)
-        sp = SegParams()
+    def _alloc(self, nbytes):
+        from squigglekit_amd._lib import check
+        p = self.L.sk_dev_alloc(nbytes)
+        if not p:
+            check(-4)
+        self.bufs.append(p)
+        return p
 
-        def step():
-            check(L.sk_segment_dev_i16(d_sig, stride, d_len, R, C.byref(sp), d_segs, d_nsegs, max_segs))
-            check(L.sk_sync())
+    def free(self):
+        for p in self.bufs:
+            self.L.sk_dev_free(p)
+        self.bufs = []
+
+    def step(self):
+        from squigglekit_amd._lib import check, ptr
+        L = self.L
+        if self.R:
+            if self.kind == "motifseq":
+                check(L.sk_motifseq_dev_i16(self.d_sig, self.stride, self.d_len, self.R, ptr(self.motif), self.N,
+                                            self.mode, 0, 1200, self.d_out))
+            else:
+                check(L.sk_segment_dev_i16(self.d_sig, self.stride, self.d_len, self.R, C.byref(self.sp),
+                                           self.d_segs, self.d_out, MAX_SEGS))
+        if self.comm is not None:                   # the one exchange: gather of the result records (RCCL)
+            self.comm.allgather_dev(self.d_out, self.d_all, self.pad * self.rec_bytes)
+        check(L.sk_sync())
+
+    def kernel_ms(self):
+        from squigglekit_amd._lib import check
+        p_, m_ = C.c_float(), C.c_float()
+        check(self.L.sk_last_kernel_ms(C.byref(p_), C.byref(m_)))
+        return p_.value, m_.value
+
+    def dtw_profile(self):
+        from squigglekit_amd._lib import check
+        da, sb = C.c_float(), C.c_float()
+        la, lb, rpl = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.L.sk_last_dtw_profile(C.byref(da), C.byref(la), C.byref(sb), C.byref(lb), C.byref(rpl)))
+        return da.value, sb.value, la.value, self.L.sk_last_dtw_retries()
+
+
+def timed(w, comm, steps, warmup):
+    """W warmup steps, then exactly K timed steps between barrier + device sync on both sides; returns the
+    MAX over ranks of the elapsed time plus this rank's HIP-event sums."""
+    from squigglekit_amd._lib import check
 
     def fence():
-        check(L.sk_sync())
-        if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        check(w.L.sk_sync())
+        if comm is not None:
+            comm.barrier()
+            check(w.L.sk_sync())
 
-    for _ in range(a.warmup):
-        step()
-    prep_ms = main_ms = 0.0
-    dtw_prof = {"dist_ms": 0.0, "start_ms": 0.0, "launches": 0, "retries": 0}
+    for _ in range(warmup):
+        w.step()
+    prof = {"prep_ms": 0.0, "main_ms": 0.0, "dist_ms": 0.0, "start_ms": 0.0, "launches": 0, "retries": 0}
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-        p_, m_ = C.c_float(), C.c_float()
-        check(L.sk_last_kernel_ms(C.byref(p_), C.byref(m_)))   # HIP events on the library's stream
-        prep_ms += p_.value
-        main_ms += m_.value
-        if a.workload == "motifseq":           # per-launch times of the two DTW passes
-            da, sb = C.c_float(), C.c_float()
-            la, lb, rpl = C.c_int32(), C.c_int32(), C.c_int32()
-            check(L.sk_last_dtw_profile(C.byref(da), C.byref(la), C.byref(sb), C.byref(lb), C.byref(rpl)))
-            dtw_prof["dist_ms"] += da.value
-            dtw_prof["start_ms"] += sb.value
-            dtw_prof["launches"] += la.value
-            dtw_prof["retries"] += L.sk_last_dtw_retries()
+    for _ in range(steps):
+        w.step()
+        if w.R:
+            p_, m_ = w.kernel_ms()                  # HIP events on the library's stream
+            prof["prep_ms"] += p_
+            prof["main_ms"] += m_
+            if w.kind == "motifseq":
+                da, sb, la, rt = w.dtw_profile()
+                prof["dist_ms"] += da
+                prof["start_ms"] += sb
+                prof["launches"] += la
+                prof["retries"] += rt
     fence()
     elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    prep_ms /= max(1, a.steps)
-    main_ms /= max(1, a.steps)
+    if comm is not None:
+        elapsed = float(comm.allgather_host(np.array([elapsed], dtype=np.float64)).max())
+    return elapsed, prof
 
-    if rank != 0:
-        if use_dist:
-            dist.destroy_process_group()
-        return
 
-    ms_per_step = elapsed / a.steps * 1e3
-    value = world * R * a.steps / elapsed
-    alg_bytes = R * (2 * M + HIT_BYTES)                       # 2*M in + 24 out per read
-
-    # ---- parity + CPU baseline on a bounded sample of rank 0's reads -------------------
+# ----------------------------------------------------------------------------------------------------
+# rank 0 extras: parity, CPU baselines, secondary lines
+# ----------------------------------------------------------------------------------------------------
+def parity_and_cpu(a, w, want_cpu):
+    """Oracle check on a sample strided over rank 0's whole batch (every chunk of the screening path), and the
+    CPU baselines (N = 1 only) timed on the same reads."""
     from oracle import oracle as ora
-    if world > 1:
-        a.cpu_seconds = 0.0          # the CPU baseline is timed at N = 1 only; keep the parity spot check
-    S = min(R, 8192)
-    sample = np.empty((S, stride), dtype=np.int16)
-    check(L.sk_dev_download(ptr(sample), d_sig, sample.nbytes))
-    parity, cpu = {}, None
-    if a.workload == "motifseq":
-        hits = np.empty(S, dtype=HIT_DTYPE)
-        check(L.sk_dev_download(ptr(hits), d_out, hits.nbytes))
-        n0 = min(S, 128)
+    from squigglekit_amd._lib import HIT_DTYPE, check, ptr
+    L, R = w.L, w.R
+    rows = strided_rows(R, min(R, 8192))
+    sample = download_rows(L, w.d_sig, w.stride * 2, rows, np.int16, w.stride)
+    lens = w.lens[rows]
+    cpu = None
+    if w.kind == "motifseq":
+        hits = np.empty(R, dtype=HIT_DTYPE)
+        check(L.sk_dev_download(ptr(hits), w.d_out, hits.nbytes))
+        got_all = hits[rows]
+        # the oracle goes through the sample in an order that is itself strided, so that whatever part of it the
+        # CPU budget covers still spans the whole batch
+        order = np.concatenate([np.arange(k, len(rows), 16) for k in range(16)])
+        n0 = min(len(rows), 128)
         t0 = time.perf_counter()
-        want = [ora.motifseq_batch_i16(sample[:n0], lens[:n0], motif, scale_mode=mode)]
+        want = [ora.motifseq_batch_i16(sample[order[:n0]], lens[order[:n0]], w.motif, scale_mode=w.mode)]
         dt = time.perf_counter() - t0
         done = n0
-        if a.cpu_seconds > 0 and done < S:
-            more = int(min(S - done, max(0, (a.cpu_seconds - dt) / (dt / n0))))
-            if more > 0:
-                t1 = time.perf_counter()
-                want.append(ora.motifseq_batch_i16(sample[done:done + more], lens[done:done + more], motif,
-                                                   scale_mode=mode))
-                dt += time.perf_counter() - t1
-                done += more
+        budget = a.cpu_seconds if want_cpu else 3.0
+        more = int(min(len(rows) - done, max(0, (budget - dt) / (dt / n0))))
+        if more > 0:
+            t1 = time.perf_counter()
+            want.append(ora.motifseq_batch_i16(sample[order[done:done + more]], lens[order[done:done + more]],
+                                               w.motif, scale_mode=w.mode))
+            dt += time.perf_counter() - t1
+            done += more
         want = np.concatenate(want)
-        got = hits[:done]
+        got = got_all[order[:done]]
+        covered = rows[order[:done]]
         parity = {"reads_checked": int(done),
+                  "sample": "strided over the whole batch: reads %d..%d" % (int(covered.min()), int(covered.max())),
                   "start_end_exact": bool(np.array_equal(got["start"], want["start"])
                                           and np.array_equal(got["end"], want["end"])),
                   "max_abs_ddist": float(np.nanmax(np.abs(got["dist"] - want["dist"]))),
                   "dist_bit_identical": bool(np.array_equal(got["dist"], want["dist"]))}
-        cpu = {"value": done / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-               "sample": "%d of rank 0's reads (%d x %d-pt motif): oracle C restatement of "
-                         "filter+medmad+mlpy dtw_subsequence (full matrix malloc per call), gcc -O2, 1 thread, %.1f s"
-                         % (done, M, N, dt),
-               "host_cores_total": os.cpu_count()}
-        if a.cpu_threads > 1 and a.cpu_seconds > 0:
-            from concurrent.futures import ThreadPoolExecutor
-            T = a.cpu_threads
-            per = max(1, min(S // T, int(a.cpu_seconds * cpu["value"])))      # about cpu_seconds per thread
-            parts = [(i * per, (i + 1) * per) for i in range(T)]
-            with ThreadPoolExecutor(T) as ex:                                 # ctypes calls release the GIL
-                t1 = time.perf_counter()
-                list(ex.map(lambda ab: ora.motifseq_batch_i16(sample[ab[0]:ab[1]], lens[ab[0]:ab[1]], motif,
-                                                              scale_mode=mode), parts))
-                dtt = time.perf_counter() - t1
-            cpu["threaded"] = {"value": T * per / dtt, "unit": "reads/s", "cores": T,
-                               "sample": "%d reads on each of %d threads, %.1f s" % (per, T, dtt)}
-        cells = float(N) * float(np.mean(got["n"]))
-        # whole DTW stage expressed in the reference's arithmetic: 4 FP64 ops per cell
-        valu = {"bound": "valu_f64_equivalent", "achieved": R * cells * 4 / (main_ms * 1e-3) / 1e12,
-                "peak": VALU_F64_LANEOPS / 1e12,
-                "unit": "T f64-lane-op/s the reference's 4-op-per-cell recurrence would need at this rate "
-                        "(the screening pass replaces most of them by 2 integer ops, so this may exceed 1)"}
-        valu["frac"] = valu["achieved"] / valu["peak"]
-        dominant, dom_ms = "k_sdtw (all launches of one call)", main_ms
-        if dtw_prof["launches"] > 0:
-            # dominant kernel = the fixed-point screening pass k_sdtw_q<L,R,feed>; one launch per chunk
-            per_step = dtw_prof["launches"] / a.steps
-            Lg, Rg = (16, (N + 15) // 16) if N <= 256 else (64, (N + 63) // 64)
-            dominant = "k_sdtw_q<%d,%d,0> (screening pass, %d launches per call)" % (Lg, Rg, per_step)
-            dom_ms = dtw_prof["dist_ms"] / dtw_prof["launches"]
-            alg_bytes = alg_bytes / per_step                   # algorithmic bytes one launch covers
-            # its own roof: 2 half-rate VALU instructions (v_min3_u32, v_sad_u32: 4 cycles each,
-            # tools/ubench/valu_rate.hip) per cell -> 256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 8 cycles
-            q_peak = 256 * 4 * 64 * 2.4e9 / 8.0
-            q_ach = R * cells / (dtw_prof["dist_ms"] / a.steps * 1e-3)
-            valu["screening_pass"] = {"bound": "valu_issue", "achieved": q_ach / 1e12, "peak": q_peak / 1e12,
-                                      "unit": "T cell-updates/s", "frac": q_ach / q_peak}
-            valu["passes_ms_per_call"] = {"screen": dtw_prof["dist_ms"] / a.steps,
-                                          "window": dtw_prof["start_ms"] / a.steps,
-                                          "retried_reads": dtw_prof["retries"] / a.steps}
-    else:
-        segs = np.empty((S, max_segs, 2), dtype=np.int32)
-        nsegs = np.empty(S, dtype=np.int32)
-        check(L.sk_dev_download(ptr(segs), d_segs, segs.nbytes))
-        check(L.sk_dev_download(ptr(nsegs), d_nsegs, nsegs.nbytes))
-        t0 = time.perf_counter()
-        osegs, onsegs = ora.segment_batch_i16(sample, lens[:S], max_segs=max_segs)
-        dt = time.perf_counter() - t0
-        same = bool(np.array_equal(nsegs, onsegs)) and all(
-            np.array_equal(segs[r, :nsegs[r]], osegs[r, :nsegs[r]]) for r in range(S))
-        parity = {"reads_checked": int(S), "segments_bit_exact": same}
-        cpu = {"value": S / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+        mean_n = float(np.mean(hits["n"]))
+        if want_cpu:
+            cpu = {"value": done / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+                   "sample": "%d of rank 0's reads (%d x %d-pt motif): oracle C restatement of filter+medmad+mlpy "
+                             "dtw_subsequence (full matrix malloc per call), gcc -O2, 1 thread, %.1f s"
+                             % (done, w.M, w.N, dt),
+                   "host_cores_total": os.cpu_count()}
+            T = (os.cpu_count() or 1) if a.cpu_threads < 0 else a.cpu_threads
+            if T > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                per = max(1, min(len(rows) // T, int(4.0 * cpu["value"])))       # a few seconds per thread
+                parts = [(i * per, (i + 1) * per) for i in range(T)]
+                with ThreadPoolExecutor(T) as ex:                              # ctypes calls release the GIL
+                    t1 = time.perf_counter()
+                    list(ex.map(lambda ab: ora.motifseq_batch_i16(sample[ab[0]:ab[1]], lens[ab[0]:ab[1]], w.motif,
+                                                                  scale_mode=w.mode), parts))
+                    dtt = time.perf_counter() - t1
+                cpu["all_cores"] = {"value": T * per / dtt, "unit": "reads/s", "cores": T,
+                                    "sample": "%d reads on each of %d threads (reads split over threads), %.1f s"
+                                              % (per, T, dtt)}
+            # "as shipped": the reference's own Python around the C DTW (MotifSeq.py:192-200 per-sample loop)
+            k = min(48, done)
+            t1 = time.perf_counter()
+            for r in range(k):
+                x = sample[order[r], :lens[order[r]]].astype(np.float64)
+                ora.medmad_python_loop(x[(x > 0) & (x < 1200)])
+            loop_ms = (time.perf_counter() - t1) / k * 1e3
+            dtw_ms = 1e3 / cpu["value"]
+            cpu["as_shipped"] = {"value": 1e3 / (loop_ms + dtw_ms), "unit": "reads/s", "cores": 1,
+                                 "note": "estimate: the reference's per-sample Python medmad loop (%.2f ms/read, "
+                                         "restated, %d reads) + the C DTW above (%.2f ms/read); TSV parsing not "
+                                         "included" % (loop_ms, k, dtw_ms)}
+        return parity, cpu, mean_n
+    segs = np.empty((R, MAX_SEGS, 2), dtype=np.int32)
+    nsegs = np.empty(R, dtype=np.int32)
+    check(L.sk_dev_download(ptr(segs), w.d_segs, segs.nbytes))
+    check(L.sk_dev_download(ptr(nsegs), w.d_out, nsegs.nbytes))
+    t0 = time.perf_counter()
+    osegs, onsegs = ora.segment_batch_i16(sample, lens, max_segs=MAX_SEGS)
+    dt = time.perf_counter() - t0
+    same = bool(np.array_equal(nsegs[rows], onsegs)) and all(
+        np.array_equal(segs[r, :nsegs[r]], osegs[k, :onsegs[k]]) for k, r in enumerate(rows))
+    parity = {"reads_checked": int(len(rows)), "sample": "strided over the whole batch",
+              "segments_bit_exact": same}
+    if want_cpu:
+        cpu = {"value": len(rows) / dt, "unit": "reads/s", "cores": 1, "kind": "port",
                "sample": "%d of rank 0's reads: oracle C restatement of filter+get_segs, gcc -O2, 1 thread, %.2f s"
-                         % (S, dt), "host_cores_total": os.cpu_count()}
-        alg_bytes = R * (2 * M + 4 + 8 * 2)
-        valu = None
-        dominant, dom_ms = ("k_prep_i16", prep_ms) if prep_ms >= main_ms else ("k_segment_walk", main_ms)
+                         % (len(rows), dt), "host_cores_total": os.cpu_count()}
+        k = min(64, len(rows))
+        t1 = time.perf_counter()
+        for r in range(k):
+            x = sample[r, :lens[r]].astype(np.float64)
+            ora.get_segs_python(x[(x > 0) & (x < 900)])
+        cpu["as_shipped"] = {"value": k / (time.perf_counter() - t1), "unit": "reads/s", "cores": 1,
+                             "note": "the reference's get_segs at interpreter speed (restated, %d reads)" % k}
+    return parity, cpu, float(w.M - 1)
 
-    if world > 1:
-        cpu = None
+
+def traffic_from_profiles(workload, pattern):
+    """HBM bytes per read of one kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, collected
+    separately with rocprofv3 --pmc: a bench run cannot read hardware counters itself)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    try:
+        tj = json.load(open(tpath))
+        key = [k for k in tj["kernels"] if pattern in k]
+        if key and tj.get("reads_per_call"):
+            kk = tj["kernels"][key[0]]
+            per_read = (kk["fetch_bytes_total"] + kk["write_bytes_total"]) / (
+                tj["reads_per_call"] * max(1, tj.get("calls", 1)))
+            return per_read, "profiles/traffic_%s.json: %s, %.0f B/read measured" % (workload, key[0], per_read)
+    except Exception:
+        pass
+    return None, None
+
+
+def motifseq_roofline(a, w, prof, steps, mean_n):
+    R, M, N = w.R, w.M, w.N
+    prep_ms, main_ms = prof["prep_ms"] / steps, prof["main_ms"] / steps
+    cells = float(N) * mean_n
+    alg_bytes = R * (2 * M + HIT_BYTES)                       # SURVEY.md 8(d): 2*M in + 24 out per read
+    dominant, dom_ms = "k_sdtw (all launches of one call)", main_ms
+    valu = {}
+    if prof["launches"] > 0:
+        # dominant kernel = the fixed-point screening pass k_sdtw_q<L,R,feed>; one launch per chunk
+        per_step = prof["launches"] / steps
+        Lg, Rg = (16, (N + 15) // 16) if N <= 256 else (64, (N + 63) // 64)
+        dominant = "k_sdtw_q<%d,%d,0> (screening pass, %d launches per call)" % (Lg, Rg, per_step)
+        dom_ms = prof["dist_ms"] / prof["launches"]
+        alg_bytes = alg_bytes / per_step                      # algorithmic bytes one launch covers
+        # its roof: 2 VALU instructions per cell (v_min3_u32 + v_sad_u32).  Nominal issue cost of a wave64 VALU
+        # op on a SIMD-32 is 2 cycles (MI355X_MICROARCH.md); these two measure 4.2-4.6 cycles each in isolation
+        # (profiles/r02_valu_rate.txt), which is what the "measured issue" roof uses.
+        q_ach = R * cells / (prof["dist_ms"] / steps * 1e-3)
+        valu["screening_pass"] = {
+            "bound": "valu_issue", "achieved": q_ach / 1e12, "unit": "T cell-updates/s",
+            "peak_at_measured_issue_cost": WAVE_ISSUE_SLOTS / 8.0 / 1e12,
+            "frac": q_ach / (WAVE_ISSUE_SLOTS / 8.0),
+            "peak_at_nominal_2_cycles": WAVE_ISSUE_SLOTS / 4.0 / 1e12,
+            "frac_of_nominal": q_ach / (WAVE_ISSUE_SLOTS / 4.0)}
+        step_ach = R * cells / ((prep_ms + main_ms) * 1e-3)
+        valu["whole_step"] = {"bound": "valu_issue", "achieved": step_ach / 1e12, "unit": "T cell-updates/s",
+                              "peak": WAVE_ISSUE_SLOTS / 8.0 / 1e12, "frac": step_ach / (WAVE_ISSUE_SLOTS / 8.0),
+                              "note": "prep + screening + certified window + retries, against the screening "
+                                      "pass's own roof"}
+        valu["passes_ms_per_call"] = {"prep": prep_ms, "screen": prof["dist_ms"] / steps,
+                                      "window": prof["start_ms"] / steps,
+                                      "retried_reads": prof["retries"] / steps}
+    f64_roof = VALU_F64_LANEOPS / 4.0 / cells                 # reads/s of the reference's 4-f64-op cell at full rate
+    valu["exact_f64_recurrence_roof_reads_per_s"] = f64_roof
+    valu["speed_vs_exact_f64_roof"] = (R / ((prep_ms + main_ms) * 1e-3)) / f64_roof
+    valu["note"] = ("speed_vs_exact_f64_roof is a ratio, not a fraction of peak: 98 % of the cells are evaluated "
+                    "in 32-bit fixed point (2 integer ops), only the certified window in f64")
+    per_read, src = traffic_from_profiles("motifseq", "k_sdtw_q")
+    traffic = per_read * (alg_bytes / (2 * M + HIT_BYTES)) if per_read else None
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-    # HBM bytes from the PMC passes (FETCH_SIZE, WRITE_SIZE; collected separately with rocprofv3 --pmc
-    # and committed under profiles/ -- a bench run cannot read hardware counters itself)
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = [k for k in tj["kernels"] if ("k_sdtw_q" in k if a.workload == "motifseq" else "k_prep_i16" in k)]
-            if key and tj.get("reads_per_call"):
-                kk = tj["kernels"][key[0]]
-                per_read = (kk["fetch_bytes_total"] + kk["write_bytes_total"]) / (
-                    tj["reads_per_call"] * max(1, tj.get("calls", 1)))
-                traffic = per_read * (alg_bytes / (2 * M + HIT_BYTES) if a.workload == "motifseq" else R)
-                traffic_src = "profiles/traffic_%s.json: %s, %.0f B/read measured" % (a.workload, key[0], per_read)
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": traffic_src,
-                "kernel_ms": {"prep": prep_ms, "main": main_ms, "dominant_avg_launch": dom_ms},
-                "algorithmic_bytes_per_launch": alg_bytes}
-    if valu:
-        roofline["binding"] = "valu issue rate (min-plus recurrence; HBM is not the limiter, DESIGN.md 4.3)"
-        roofline["valu"] = valu
+    return {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+            "kernel_ms": {"prep": prep_ms, "main": main_ms, "dominant_avg_launch": dom_ms},
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "dominant_kernel_dtype": "u32 fixed-point screening, f64 certified window",
+            "binding": "valu issue rate (min-plus recurrence; HBM is not the limiter, DESIGN.md 4.3)",
+            "valu": valu}
 
-    name = ("reads/sec MotifSeq DTW (4k-sample read x 200-sample motif)" if a.workload == "motifseq"
-            else "reads/sec segmenter (4k-sample read)")
+
+def segmenter_roofline(w, prof, steps):
+    R, M = w.R, w.M
+    prep_ms, main_ms = prof["prep_ms"] / steps, prof["main_ms"] / steps
+    alg_bytes = R * (2 * M + 4 + 8 * 2)
+    dominant, dom_ms = ("k_seg_stats (filter + statistics + in-band mask)", prep_ms) if prep_ms >= main_ms \
+        else ("k_segment_walk", main_ms)
+    per_read, src = traffic_from_profiles("segmenter", "k_seg" if prep_ms >= main_ms else "k_segment_walk")
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    both = alg_bytes / ((prep_ms + main_ms) * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": per_read * R if per_read else None, "traffic_source": src,
+            "kernel_ms": {"prep": prep_ms, "main": main_ms, "dominant_avg_launch": dom_ms},
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "both_kernels": {"achieved": both, "frac": both / HBM_PEAK_GBS}}
+
+
+def extras_single_gpu(a, L, main):
+    """N = 1 only, after the timed region: the secondary (segmenter) line, the exact-only DTW schemes and the
+    PCIe-inclusive host-buffer rate.  Each is a few short steps."""
+    from squigglekit_amd._lib import HIT_DTYPE, check, ptr
+    out = {}
+    # ---- secondary metric: segmenter reads/s on 1 M x 4 000 (SURVEY 8(d)) ------------------------------------
+    if a.workload == "motifseq":
+        sa = argparse.Namespace(**vars(a))
+        sa.workload = "segmenter"
+        w = Workload(sa, L, 0, 1, a.reads, workload="segmenter")
+        try:
+            el, prof = timed(w, None, 5, 1)
+            par, cpu, _ = parity_and_cpu(sa, w, True)
+            out["secondary"] = {"metric": "reads/sec segmenter (4k-sample read)", "value": w.R * 5 / el,
+                                "unit": "reads/s", "ms_per_step": el / 5 * 1e3, "steps": 5, "warmup": 1,
+                                "config": {"workload": "segmenter C2-1M: %d reads x %d int16 samples, default flags"
+                                                       % (w.R, w.M), "seed": w.seed},
+                                "roofline": segmenter_roofline(w, prof, 5), "cpu_baseline": cpu, "parity": par}
+        finally:
+            w.free()
+    # ---- what the screening buys: the exact-only schemes on 200 000 of the same reads ------------------------
+    if a.workload == "motifseq":
+        ex = {}
+        Rx = min(main.R, 200_000)
+        for name, env in (("full_single_pass", "full"), ("exact_two_pass", "exact2")):
+            os.environ["SK_DTW_SCHEME"] = env
+            try:
+                t = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    check(L.sk_motifseq_dev_i16(main.d_sig, main.stride, main.d_len, Rx, ptr(main.motif), main.N,
+                                                main.mode, 0, 1200, main.d_out))
+                    check(L.sk_sync())
+                    t.append(time.perf_counter() - t0)
+                ex[name] = Rx / min(t[1:])
+            finally:
+                del os.environ["SK_DTW_SCHEME"]
+        ex["reads"] = Rx
+        out["exact_only_reads_per_s"] = ex
+    # ---- end to end: host (pageable numpy) buffers in, host records out, PCIe included -----------------------
+    Rh = min(main.R, 400_000)
+    host = np.empty((Rh, main.stride), dtype=np.int16)
+    check(L.sk_dev_download(ptr(host), main.d_sig, host.nbytes))
+    lens = main.lens[:Rh]
+    e2e = {"reads": Rh, "note": "sk_*_batch_i16 on pageable host arrays: H2D + kernels + D2H, wall clock; "
+                                "PCIe Gen5 x16 ceiling ~63 GB/s = 7.9 M reads/s at 8 KB per read"}
+    hits = np.zeros(Rh, dtype=HIT_DTYPE)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        check(L.sk_motifseq_batch_i16(ptr(host), main.stride, ptr(lens), Rh, ptr(main.motif), main.N, main.mode,
+                                      0, 1200, ptr(hits)))
+        ts.append(time.perf_counter() - t0)
+    e2e["motifseq_reads_per_s"] = Rh / min(ts[1:])
+    from squigglekit_amd._lib import SegParams
+    segs = np.zeros((Rh, MAX_SEGS, 2), dtype=np.int32)
+    nsegs = np.zeros(Rh, dtype=np.int32)
+    sp = SegParams()
+    lens_s = (lens - 1).astype(np.int32)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        check(L.sk_segment_batch_i16(ptr(host), main.stride, ptr(lens_s), Rh, C.byref(sp), ptr(segs), ptr(nsegs),
+                                     MAX_SEGS))
+        ts.append(time.perf_counter() - t0)
+    e2e["segmenter_reads_per_s"] = Rh / min(ts[1:])
+    out["end_to_end"] = e2e
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# one rank
+# ----------------------------------------------------------------------------------------------------
+def rank_body(a, comm, rank, world, shape):
+    """Runs on the rank's own thread / process with its device bound.  Returns the JSON line on rank 0."""
+    from squigglekit_amd import _lib, sharding
+    L = _lib.load()
+    if a.scaling == "strong":
+        lo, hi = sharding.shard_bounds(a.reads, rank, world)
+        R, pad = hi - lo, max(sharding.shard_sizes(a.reads, world))
+    else:
+        R = pad = a.reads
+    use_comm = comm if (world > 1 or a.force_comm) else None
+    w = Workload(a, L, rank, world, R, comm=use_comm, gather_pad=pad)
+    elapsed, prof = timed(w, use_comm, a.steps, a.warmup)
+    ranks_seen = use_comm.ranks_seen() if use_comm is not None else 1
+
+    strong = None
+    if world > 1 and a.scaling == "weak" and a.workload == "motifseq":
+        # the same job as BASELINE.json words C4 -- a.reads in TOTAL, sharded -- on the data already resident
+        lo, hi = sharding.shard_bounds(a.reads, rank, world)
+        keepR, keeppad = w.R, w.pad
+        w.R, w.pad = hi - lo, max(sharding.shard_sizes(a.reads, world))
+        el_s, _ = timed(w, use_comm, a.steps, 1)
+        w.R, w.pad = keepR, keeppad
+        strong = {"scaling": "strong", "total_reads": a.reads, "value": a.reads * a.steps / el_s, "unit": "reads/s",
+                  "ms_per_step": el_s / a.steps * 1e3, "steps": a.steps}
+        w.step()                                                # every rank: d_out holds its full shard again
+    if rank != 0:
+        w.free()
+        return None
+
+    total_reads = a.reads * world if a.scaling == "weak" else a.reads
+    ms_per_step = elapsed / a.steps * 1e3
+    value = total_reads * a.steps / elapsed
+    want_cpu = world == 1 and a.cpu_seconds > 0          # the CPU baseline is timed at N = 1 only
+    parity, cpu, mean_n = parity_and_cpu(a, w, want_cpu)
+    if a.workload == "motifseq":
+        roofline = motifseq_roofline(a, w, prof, a.steps, mean_n)
+        name = "reads/sec MotifSeq DTW (4k-sample read x 200-sample motif)"
+        wl = "MotifSeq C4: %d reads x %d int16 samples %s, %d-pt motif, %s" % (
+            a.reads, a.samples, "per GPU" if a.scaling == "weak" else "in total", a.motif, a.scale)
+    else:
+        roofline = segmenter_roofline(w, prof, a.steps)
+        name = "reads/sec segmenter (4k-sample read)"
+        wl = "segmenter C2-1M: %d reads x %d int16 samples %s, default flags" % (
+            a.reads, a.samples, "per GPU" if a.scaling == "weak" else "in total")
     line = {"metric": name, "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "f64" if a.workload == "motifseq" else "int16/f64",
             "data": "synthetic",
-            "config": {"workload": ("MotifSeq C4" if a.workload == "motifseq" else "segmenter C2-1M")
-                       + ": %d reads x %d int16 samples per GPU" % (R, M)
-                       + (", %d-pt motif, %s" % (N, a.scale) if a.workload == "motifseq" else ", default flags"),
-                       "reads_per_gpu": R, "samples": M, "motif_points": N if a.workload == "motifseq" else None,
-                       "seed": seed, "sharding": "reads block-sharded, %d rank(s), result all-gather over RCCL" % world},
+            "config": {"workload": wl, "reads_per_gpu": w.R, "total_reads": total_reads, "samples": a.samples,
+                       "motif_points": a.motif if a.workload == "motifseq" else None, "seed": w.seed,
+                       "generator": "device generator k_synth (csrc/sk_synth.hip): the SURVEY 8(d) squiggle model, "
+                                    "counter-based RNG -- a different stream than squigglekit_amd/synth.py's "
+                                    "numpy default_rng recipe the tests use under the same seed",
+                       "sharding": "reads block-sharded over %d rank(s); every step ends with an RCCL all-gather "
+                                   "of the result records" % world if use_comm is not None else
+                                   "1 rank, no exchange",
+                       "launch": {"single": "one process, one GPU", "threads": "one process, one host thread per GPU",
+                                  "process": "one process per GPU (launcher environment), torch-free"}[shape],
+                       "gather_backend": use_comm.backend if use_comm is not None else None,
+                       "ranks_seen": ranks_seen},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity}
-    print(json.dumps(line))
-    if use_dist:
-        dist.destroy_process_group()
+    if strong:
+        line["strong_scaling"] = strong
+    if world == 1 and not a.no_extras:
+        line.update(extras_single_gpu(a, L, w))
+    w.free()
+    return line
+
+
+def main(argv=None):
+    a = parse(argv)
+    from squigglekit_amd import _lib, multigpu
+    _lib.load()
+    shape, rank, local, world = multigpu.plan(a.gpus)
+    a.gpus = world
+    if shape == "process":
+        with multigpu.ProcessGroup(rank, local, world) as comm:
+            line = rank_body(a, comm, rank, world, shape)
+    elif shape == "threads" or a.force_comm:
+        g = multigpu.ThreadGroup(list(range(world)))
+        try:
+            line = g.run(lambda comm: rank_body(a, comm, comm.rank, world, shape))[0]
+        finally:
+            g.close()
+    else:
+        _lib.init(0)
+        line = rank_body(a, None, 0, 1, shape)
+    if line is not None:
+        print(json.dumps(line))
 
 
 if __name__ == "__main__":

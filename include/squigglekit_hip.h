@@ -210,6 +210,25 @@ int sk_tsv_parse(const char *buf, size_t len, int32_t start_col, int64_t nlines,
                  double *values, int64_t *name_off, int32_t *name_len, int64_t *id_off, int32_t *id_len,
                  int32_t *flags, int32_t nthreads);
 
+/* ---- multi-GPU: the final gather of result records (RCCL over xGMI) ------ */
+/* The reference's per-read loops (segmenter.py:189-230, MotifSeq.py:261-298) carry no state from one read
+ * to the next, so N GPUs take contiguous blocks of the reads with no data-path collective; the one exchange
+ * is an all-gather of the fixed-size records at the end.  librccl.so is loaded on first use; when it (or a
+ * communicator) is not available these return SK_ERR_UNSUPPORTED and the caller concatenates the shards on
+ * the host.  One communicator per device; the calls act on the calling thread's bound device.
+ *   one process, one thread per GPU:   sk_comm_init_all(devices, n)  once, from any thread
+ *   one process per GPU:               rank 0: sk_comm_unique_id(id) -> hand the 128 bytes to every rank;
+ *                                      every rank: sk_init(dev); sk_comm_init_rank(id, nranks, rank)        */
+int sk_comm_unique_id(void *id128);
+int sk_comm_init_rank(const void *id128, int nranks, int rank);
+int sk_comm_init_all(const int *devices, int ndev);
+int sk_comm_info(int *nranks, int *rank);      /* what RCCL reports for this device's communicator */
+/* d_recv[nranks * bytes] <- every rank's d_send[bytes], rank order; enqueued on the device's stream */
+int sk_comm_allgather_dev(const void *d_send, void *d_recv, size_t bytes);
+/* the same for small host buffers (timings, a barrier); synchronous */
+int sk_comm_allgather_host(const void *send, void *recv, size_t bytes);
+int sk_comm_destroy(void);
+
 /* ---- instrumentation -------------------------------------------------- */
 /* HIP-event durations (ms) of the kernels of the most recent *_dev / batch
  * call on this thread's device: prep (filter+stats), main (DTW or segment walk). */

@@ -281,3 +281,63 @@ def segment_batch_i16(sig, lens, params=None, lo=0, hi=900, max_segs=64):
     if rc:
         raise ValueError("oracle segment batch failed")
     return segs, nsegs
+
+
+# ------------------------------------------------------------------------------------------------
+# Python-speed restatements: what the reference costs "as shipped" (BASELINE.md section 3, items 2 and 4a).
+# Test infrastructure like everything else here -- bench.py times them, tests pin them to the C oracle.
+# ------------------------------------------------------------------------------------------------
+def medmad_python_loop(sig):
+    """MotifSeq.py:192-200 at the reference's own speed: numpy medians, then one Python-level
+    (x - med) / scaled_mad and one list append per sample, then a list -> ndarray conversion."""
+    sig = np.asarray(sig)
+    centre = np.median(sig)
+    spread = np.median(np.abs(sig - centre)) * 1.4826
+    acc = []
+    for x in sig:
+        acc.append((x - centre) / spread)
+    return np.array(acc)
+
+
+def get_segs_python(sig, params=None):
+    """segmenter.py:399-470 at interpreter speed (one Python iteration per sample).  Same decisions as
+    ora_get_segs; written as an explicit in/tolerated/closing classification per sample."""
+    p = params or SegParams()
+    sig = np.asarray(sig)
+    mid = np.median(sig)
+    sd = np.std(sig)
+    hi_t = mid + sd * p.std_scale                                    # :413
+    lo_t = mid - sd * p.std_scale                                    # :414
+    inside = False
+    run = errs = tail = 0
+    period = p.corrector                                             # :424, never reset
+    first = 0
+    found = []
+    for i in range(len(sig)):
+        v = sig[i]
+        in_band = lo_t < v < hi_t                                    # :431
+        if in_band or (inside and errs < p.error):                   # :431 / :442 -- the sample extends the run
+            if in_band:
+                if not inside:
+                    inside, first = True, i
+                period += 1
+                tail = 0
+            else:
+                errs += 1
+                tail += 1
+            run += 1
+            if run >= p.window and run >= period and run % period == 0:   # :439 / :446
+                errs -= 1
+            continue
+        if not inside:
+            continue
+        long_enough = run >= p.window or (not found and run >= p.window * p.stall_len)   # :448
+        if long_enough:
+            stop = i - tail                                          # :449
+            if found and first - found[-1][1] < p.seg_dist:          # :451
+                found[-1][1] = stop
+            else:
+                found.append([first, stop])
+        inside = False
+        run = errs = tail = 0
+    return found if found else False

@@ -6,6 +6,7 @@ visible, every compute call raises.  Nothing here imports torch or the oracle.
 import ctypes as C
 import os
 import subprocess
+import threading
 
 import numpy as np
 
@@ -112,6 +113,13 @@ ABI = {
     "sk_tsv_count_tokens": (C.c_int, [_vp, C.c_size_t, C.c_int32, C.c_int64, _vp, C.c_int32]),
     "sk_tsv_parse": (C.c_int, [_vp, C.c_size_t, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                C.c_int32]),
+    "sk_comm_unique_id": (C.c_int, [_vp]),
+    "sk_comm_init_rank": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "sk_comm_init_all": (C.c_int, [_i32p, C.c_int]),
+    "sk_comm_info": (C.c_int, [_i32p, _i32p]),
+    "sk_comm_allgather_dev": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "sk_comm_allgather_host": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "sk_comm_destroy": (C.c_int, []),
     "sk_last_kernel_ms": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sk_last_dtw_retries": (C.c_int, []),
     "sk_last_dtw_profile": (C.c_int, [C.POINTER(C.c_float), _i32p, C.POINTER(C.c_float), _i32p, _i32p]),
@@ -153,22 +161,21 @@ def check(rc):
         raise SquiggleKitError(rc, load().sk_last_error().decode(errors="replace"))
 
 
-_bound = None
+_tls = threading.local()      # the library binds a device per host thread (thread_local in sk_runtime.hip)
 
 
 def init(device=None):
-    """Bind this thread to a GPU (default: $SK_DEVICE, else LOCAL_RANK, else 0)."""
-    global _bound
+    """Bind the calling thread to a GPU (default: $SK_DEVICE, else LOCAL_RANK, else 0)."""
     L = load()
     if device is None:
         device = int(os.environ.get("SK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     check(L.sk_init(int(device)))
-    _bound = int(device)
-    return _bound
+    _tls.device = int(device)
+    return _tls.device
 
 
 def ensure_init():
-    if _bound is None:
+    if getattr(_tls, "device", None) is None:
         init()
     return load()
 

@@ -17,6 +17,28 @@ from ._lib import HIT_DTYPE, SegParams, SquiggleKitError, check, ptr
 
 
 # ----------------------------------------------------------------------------
+# device selection
+# ----------------------------------------------------------------------------
+_default_devices = None
+
+
+def set_devices(devices):
+    """GPUs the batch calls shard their reads over when no `devices=` is passed (None / one entry: the
+    calling thread's bound GPU, as before).  The CLIs' --gpus N sets range(N)."""
+    global _default_devices
+    devices = None if devices is None else [int(d) for d in devices]
+    if devices is not None:
+        n = _lib.load().sk_device_count()
+        if not devices or len(set(devices)) != len(devices) or min(devices) < 0 or max(devices) >= max(n, 1):
+            raise ValueError("devices %s: need distinct indices below the %d visible GPU(s)" % (devices, n))
+    _default_devices = devices
+
+
+def _devs(devices):
+    return _default_devices if devices is None else devices
+
+
+# ----------------------------------------------------------------------------
 # packing helpers
 # ----------------------------------------------------------------------------
 def pack_i16(reads):
@@ -74,13 +96,15 @@ def _too_wide_for_i16(lo, hi):
 # ----------------------------------------------------------------------------
 # segmenter path
 # ----------------------------------------------------------------------------
-def segment_batch(sig, lens=None, params=None, max_segs=64):
+def segment_batch(sig, lens=None, params=None, max_segs=64, devices=None):
     """scale_outliers + get_segs for every row of an int16 [R, stride] batch.
 
     Returns (segs int32 [R, max_segs, 2], nsegs int32 [R]); grows max_segs and
     retries on overflow.  Coordinates are in the FILTERED signal, like the
-    reference's (segmenter.py:209-211)."""
-    L = _lib.ensure_init()
+    reference's (segmenter.py:209-211).  devices=[d0, d1, ...]: the reads are block-sharded over those
+    GPUs, one host thread each (multigpu.py); results land in the same arrays, in input order."""
+    devices = _devs(devices)
+    L = _lib.load() if devices else _lib.ensure_init()
     sig = np.ascontiguousarray(sig, dtype=np.int16)
     if sig.ndim != 2:
         raise ValueError("sig must be [reads, samples]")
@@ -96,11 +120,28 @@ def segment_batch(sig, lens=None, params=None, max_segs=64):
             if x:
                 segs[r, :len(x)] = x
         return segs, nsegs
+    sharded = devices is not None and len(devices) > 1 and R >= len(devices)
     while True:
         segs = np.zeros((R, max_segs, 2), dtype=np.int32)
         nsegs = np.zeros(R, dtype=np.int32)
-        rc = L.sk_segment_batch_i16(ptr(sig), stride, ptr(lens), R, C.byref(params),
-                                    ptr(segs), ptr(nsegs), max_segs)
+        if sharded:
+            from . import multigpu
+            rcs = []
+
+            def shard(lo, hi, comm, ms=max_segs):
+                if hi > lo:
+                    rc = L.sk_segment_batch_i16(ptr(sig[lo:hi]), stride, ptr(lens[lo:hi]), hi - lo, C.byref(params),
+                                                ptr(segs[lo:hi]), ptr(nsegs[lo:hi]), ms)
+                    if rc != _lib.SK_ERR_OVERFLOW:
+                        check(rc)
+                    rcs.append(rc)
+            multigpu.run_sharded(devices, R, shard)
+            rc = _lib.SK_ERR_OVERFLOW if _lib.SK_ERR_OVERFLOW in rcs else 0
+        else:
+            if devices:
+                _lib.init(devices[0])
+            rc = L.sk_segment_batch_i16(ptr(sig), stride, ptr(lens), R, C.byref(params),
+                                        ptr(segs), ptr(nsegs), max_segs)
         if rc == _lib.SK_ERR_OVERFLOW:
             max_segs = int(nsegs.max()) + 8
             continue
@@ -238,11 +279,15 @@ def drna_roll_reads(reads, params=None):
 # ----------------------------------------------------------------------------
 # MotifSeq path
 # ----------------------------------------------------------------------------
-def motifseq_batch(sig, lens, motif, scale="medmad", scale_low=0, scale_hi=1200):
+def motifseq_batch(sig, lens, motif, scale="medmad", scale_low=0, scale_hi=1200, devices=None, gather="host"):
     """scale_outliers + medmad/zscale + dtw_subsequence for every row of an
     int16 [R, stride] batch.  Returns a HIT_DTYPE record array (dist, start,
-    end, n, flags); start/end index the FILTERED signal (MotifSeq.py:438-439)."""
-    L = _lib.ensure_init()
+    end, n, flags); start/end index the FILTERED signal (MotifSeq.py:438-439).
+    devices=[d0, d1, ...]: reads block-sharded over those GPUs, one host thread each; gather="host" writes
+    every shard's records straight into the result, gather="rccl" all-gathers them GPU to GPU first (RCCL) and
+    downloads the complete result from the first device (multigpu.motifseq_sharded)."""
+    devices = _devs(devices)
+    L = _lib.load() if devices else _lib.ensure_init()
     sig = np.ascontiguousarray(sig, dtype=np.int16)
     R, stride = sig.shape
     lens = (np.full(R, stride, dtype=np.int32) if lens is None
@@ -252,6 +297,21 @@ def motifseq_batch(sig, lens, motif, scale="medmad", scale_low=0, scale_hi=1200)
         return motifseq_reads_f64([sig[r, :lens[r]].astype(np.float64) for r in range(R)], motif, scale,
                                   scale_low, scale_hi)
     out = np.zeros(R, dtype=HIT_DTYPE)
+    if devices is not None and len(devices) > 1 and R >= len(devices):
+        from . import multigpu
+        if gather == "rccl":
+            return multigpu.motifseq_sharded(sig, lens, motif, _lib.SK_SCALE[scale], scale_low, scale_hi,
+                                             devices, gather="rccl")[0]
+
+        def shard(lo, hi, comm):
+            if hi > lo:
+                check(L.sk_motifseq_batch_i16(ptr(sig[lo:hi]), stride, ptr(lens[lo:hi]), hi - lo, ptr(motif),
+                                              motif.size, _lib.SK_SCALE[scale], int(scale_low), int(scale_hi),
+                                              ptr(out[lo:hi])))
+        multigpu.run_sharded(devices, R, shard)
+        return out
+    if devices:
+        _lib.init(devices[0])
     check(L.sk_motifseq_batch_i16(ptr(sig), stride, ptr(lens), R, ptr(motif), motif.size,
                                   _lib.SK_SCALE[scale], int(scale_low), int(scale_hi), ptr(out)))
     return out
@@ -317,9 +377,22 @@ def motifseq_multi(reads, motifs, scale="medmad", scale_low=0, scale_hi=1200):
         moff[1:] = np.cumsum([m.size for m in motifs])
         flat = np.ascontiguousarray(np.concatenate(motifs))
         res = np.zeros((len(motifs), len(ints)), dtype=HIT_DTYPE)
-        check(L.sk_motifseq_multi_batch_i16(ptr(buf), buf.shape[1], ptr(lens), len(ints), ptr(flat), ptr(moff),
-                                            len(motifs), _lib.SK_SCALE[scale], int(scale_low), int(scale_hi),
-                                            ptr(res)))
+        devices = _devs(None)
+        if devices is not None and len(devices) > 1 and len(ints) >= len(devices):
+            from . import multigpu
+
+            def shard(lo, hi, comm):
+                if hi > lo:
+                    part = np.zeros((len(motifs), hi - lo), dtype=HIT_DTYPE)
+                    check(L.sk_motifseq_multi_batch_i16(ptr(buf[lo:hi]), buf.shape[1], ptr(lens[lo:hi]), hi - lo,
+                                                        ptr(flat), ptr(moff), len(motifs), _lib.SK_SCALE[scale],
+                                                        int(scale_low), int(scale_hi), ptr(part)))
+                    res[:, lo:hi] = part
+            multigpu.run_sharded(devices, len(ints), shard)
+        else:
+            check(L.sk_motifseq_multi_batch_i16(ptr(buf), buf.shape[1], ptr(lens), len(ints), ptr(flat), ptr(moff),
+                                                len(motifs), _lib.SK_SCALE[scale], int(scale_low), int(scale_hi),
+                                                ptr(res)))
         for k in range(len(motifs)):
             outs[k][ints] = res[k]
     if flts:

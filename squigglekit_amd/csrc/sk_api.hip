@@ -16,6 +16,16 @@ int check_i16(const void *sig, int64_t stride, const int32_t *len, int32_t nread
     return SK_OK;
 }
 
+// host-buffer entry points: every len[r] must lie in [0, stride] -- the kernels use it as a trip count
+// over the read's row (the *_dev_* entry points cannot look at device memory; the kernels clamp there)
+int check_len_host(const int32_t *len, int32_t nreads, int64_t stride)
+{
+    for (int32_t r = 0; r < nreads; r++)
+        if (len[r] < 0 || (int64_t)len[r] > stride)
+            return sk_fail(SK_ERR_INVALID, "len[%d] = %d is outside [0, stride = %lld]", r, len[r], (long long)stride);
+    return SK_OK;
+}
+
 int check_seg_params(const sk_seg_params *p)
 {
     if (!p) return sk_fail(SK_ERR_INVALID, "NULL sk_seg_params");
@@ -95,6 +105,7 @@ int sk_motifseq_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len
     if (!c) return SK_ERR_NO_DEVICE;
     int rc = check_i16(sig, stride, len, nreads);
     if (rc) return rc;
+    if ((rc = check_len_host(len, nreads, stride))) return rc;
     if (nreads == 0) return SK_OK;
     if (!out) return sk_fail(SK_ERR_INVALID, "NULL out");
     const size_t sb = (size_t)nreads * (size_t)stride * sizeof(int16_t);
@@ -121,6 +132,7 @@ int sk_motifseq_multi_batch_i16(const int16_t *sig, int64_t stride, const int32_
     if (!c) return SK_ERR_NO_DEVICE;
     int rc = check_i16(sig, stride, len, nreads);
     if (rc) return rc;
+    if ((rc = check_len_host(len, nreads, stride))) return rc;
     if (!motifs || !motif_off || nmotifs <= 0) return sk_fail(SK_ERR_INVALID, "no motifs");
     for (int32_t k = 0; k < nmotifs; k++)
         if (motif_off[k + 1] <= motif_off[k]) return sk_fail(SK_ERR_INVALID, "motif %d is empty", k);
@@ -396,6 +408,7 @@ int sk_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len,
     if (!c) return SK_ERR_NO_DEVICE;
     int rc = check_i16(sig, stride, len, nreads);
     if (rc) return rc;
+    if ((rc = check_len_host(len, nreads, stride))) return rc;
     if ((rc = check_seg_params(p))) return rc;
     if (max_segs <= 0) return sk_fail(SK_ERR_INVALID, "max_segs must be positive");
     if (nreads == 0) return SK_OK;
@@ -469,6 +482,7 @@ int sk_drna_roll_batch_i16(const int16_t *sig, int64_t stride, const int32_t *le
     if (!c) return SK_ERR_NO_DEVICE;
     int rc = check_i16(sig, stride, len, nreads);
     if (rc) return rc;
+    if ((rc = check_len_host(len, nreads, stride))) return rc;
     if (!p) return sk_fail(SK_ERR_INVALID, "NULL sk_roll_params");
     if (p->w <= 0) return sk_fail(SK_ERR_INVALID, "the rolling window w must be positive");
     if (nreads == 0) return SK_OK;
@@ -514,6 +528,7 @@ int sk_drna_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t 
     if (!c) return SK_ERR_NO_DEVICE;
     int rc = check_i16(sig, stride, len, nreads);
     if (rc) return rc;
+    if ((rc = check_len_host(len, nreads, stride))) return rc;
     if (!p) return sk_fail(SK_ERR_INVALID, "NULL sk_drna_params");
     if (p->w <= 0) return sk_fail(SK_ERR_INVALID, "w must be positive (the scan takes c %% w)");
     if (p->t_start < 0 || p->t_end < p->t_start) return sk_fail(SK_ERR_INVALID, "bad statistics window");

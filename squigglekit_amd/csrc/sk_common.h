@@ -63,12 +63,19 @@ struct sk_ctx {
     std::vector<double> motif_host;   // last laid-out motif (kept alive for async H2D)
     std::vector<double> motif_src;    // the motif it was built from (upload cache key, with motif_L)
     int    motif_L = 0;               // lanes per read of the layout in `motif`
+    void  *comm = nullptr;            // ncclComm_t of this device (sk_comm.hip), or nullptr
+    sk_buf commbuf;                   // staging for the small host-side exchanges
 };
 
 // ---- runtime (sk_runtime.hip) ----
 sk_ctx *sk_cur(void);                       // bound context or nullptr (error set)
+sk_ctx *sk_ctx_of(int device);              // context slot of a device (ready or not)
+int  sk_bound_device(void);                 // device the calling thread is bound to, or -1
 int  sk_fail(int code, const char *fmt, ...);
 int  sk_reserve(sk_ctx *c, sk_buf *b, size_t bytes);
+// Reads per chunk of a checkpointing DTW call: scratch budget (12 GB, or SK_DTW_SCRATCH_MB) / per_read, at
+// least 1024 reads (64 when the budget was set by hand, so that tests can force many small chunks).
+int64_t sk_dtw_chunk_reads(size_t per_read, int64_t nreads);
 #define SK_HIP(call)                                                                    \
     do {                                                                                \
         hipError_t e_ = (call);                                                         \

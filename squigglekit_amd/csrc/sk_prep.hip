@@ -369,7 +369,11 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
 
     if (tid == 0) sc->tree_m = -1;                         // no pairwise tree cached yet
     unsigned v[4], vn[4];
-    int Mnext = ((int)blockIdx.x < nreads) ? len[blockIdx.x] : 0;
+    // a length outside [0, stride] would walk into the neighbouring rows: clamp (the host entry points
+    // reject such input; device-resident callers get the clamp)
+    const int maxM = (int)min(stride, (int64_t)0x7fffff00);
+    auto rdlen = [&](int rr) { return min(max(len[rr], 0), maxM); };
+    int Mnext = ((int)blockIdx.x < nreads) ? rdlen(blockIdx.x) : 0;
     if ((int)blockIdx.x < nreads) load8(sig + (int64_t)blockIdx.x * stride, Mnext, tid * 8, v);
     for (int r = blockIdx.x; r < nreads; r += gridDim.x) {
     const int M = Mnext;
@@ -440,7 +444,7 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     const int n = run;
     {                                                      // first tile of my next read
         const int rn = r + gridDim.x;
-        Mnext = (rn < nreads) ? len[rn] : 0;
+        Mnext = (rn < nreads) ? rdlen(rn) : 0;
         if (rn < nreads) load8(sig + (int64_t)rn * stride, Mnext, tid * 8, v);
     }
     __syncthreads();                                       // histogram + compacted samples complete

@@ -139,7 +139,7 @@ void k_prepw_medmad(const int16_t *__restrict__ sig, int64_t stride, const int32
 
     const int nwaves = gridDim.x * WPB;
     for (int r = blockIdx.x * WPB + w; r < nreads; r += nwaves) {
-        const int M = len[r];
+        const int M = min(max(len[r], 0), (int)min(stride, (int64_t)0x7fffff00));   // never past the row
         const int16_t *row = sig + (int64_t)r * stride;
         int16_t *crow = comp + (int64_t)r * stride;
 

@@ -5,6 +5,7 @@
 #include "sk_common.h"
 #include <mutex>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char  g_err[512] = "";
@@ -34,6 +35,9 @@ sk_ctx *sk_cur(void)
     return &g_ctx[g_cur];
 }
 
+sk_ctx *sk_ctx_of(int device) { return (device >= 0 && device < SK_MAX_DEVICES) ? &g_ctx[device] : nullptr; }
+int sk_bound_device(void) { return g_cur; }
+
 int sk_reserve(sk_ctx *c, sk_buf *b, size_t bytes)
 {
     (void)c;
@@ -47,6 +51,20 @@ int sk_reserve(sk_ctx *c, sk_buf *b, size_t bytes)
     }
     b->cap = want;
     return SK_OK;
+}
+
+int64_t sk_dtw_chunk_reads(size_t per_read, int64_t nreads)
+{
+    size_t budget = (size_t)12 << 30;
+    int64_t floor_reads = 1024;
+    if (const char *e = getenv("SK_DTW_SCRATCH_MB")) {
+        const long v = atol(e);
+        if (v > 0) { budget = (size_t)v << 20; floor_reads = 64; }
+    }
+    int64_t chunk = (int64_t)(budget / (per_read ? per_read : 1));
+    if (chunk < floor_reads) chunk = floor_reads;
+    if (chunk > nreads) chunk = nreads;
+    return chunk > 0 ? chunk : 1;
 }
 
 extern "C" {
@@ -102,7 +120,7 @@ int sk_shutdown(void)
         (void)hipStreamSynchronize(c->stream);
         sk_buf *bufs[] = {&c->sig, &c->len, &c->off, &c->comp, &c->prep, &c->mask,
                           &c->motif, &c->out, &c->out2, &c->misc, &c->ckpt, &c->retry, &c->motifq, &c->lastq, &c->qflag,
-                          &c->motif64};
+                          &c->motif64, &c->commbuf};
         for (sk_buf *b : bufs) free_buf(b);
         for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev[i]);
         for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);

@@ -461,8 +461,9 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     if (const char *e = getenv("SK_DTW_CK")) { int v = atoi(e); if (v >= 64 && v % 64 == 0) ck = v; }
     if (const char *e = getenv("SK_DTW_SPAN")) { int v = atoi(e); if (v > 0) span = v; }
     const int64_t maxlen = a->max_len;
+    const char *scheme = getenv("SK_DTW_SCHEME");          // A/B switch: "full" = the exact single pass
     const bool two_pass = !a->last_row && !a->force_single && maxlen >= 4 * (int64_t)(span + ck) &&
-                          a->nreads >= 256;
+                          a->nreads >= 256 && !(scheme && strcmp(scheme, "full") == 0);
     SK_HIP(hipEventRecord(c->ev[2], c->stream));
     if (!two_pass) {
         c->last_retry = 0;
@@ -525,10 +526,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     }
     const int nck = (int)((maxlen + L - 1) / ck);          // checkpoints at steps ck, 2ck, ... <= last step
     const size_t per_read = (size_t)(nck > 0 ? nck : 1) * L * (R + 3) * sizeof(double);
-    size_t budget = (size_t)12 << 30;                      // checkpoint scratch per chunk
-    int64_t chunk = (int64_t)(budget / per_read);
-    if (chunk > a->nreads) chunk = a->nreads;
-    if (chunk < 1024) chunk = 1024 < a->nreads ? 1024 : a->nreads;
+    const int64_t chunk = sk_dtw_chunk_reads(per_read, a->nreads);   // checkpoint scratch per chunk
     int rc;
     if ((rc = sk_reserve(c, &c->ckpt, (size_t)chunk * per_read))) return rc;
     if ((rc = sk_reserve(c, &c->retry, ((size_t)a->nreads + 1) * sizeof(int32_t)))) return rc;

@@ -503,10 +503,7 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P,
     const size_t lq_stride = (size_t)((maxlen + 3) & ~(int64_t)3);
     const size_t per_read = (size_t)(nck > 0 ? nck : 1) * L * (R + 2) * sizeof(unsigned) +
                             lq_stride * sizeof(unsigned) + sizeof(int32_t);
-    const size_t budget = (size_t)12 << 30;
-    int64_t chunk = (int64_t)(budget / per_read);
-    if (chunk > a->nreads) chunk = a->nreads;
-    if (chunk < 1024) chunk = 1024 < a->nreads ? 1024 : a->nreads;
+    const int64_t chunk = sk_dtw_chunk_reads(per_read, a->nreads);
     if ((rc = sk_reserve(c, &c->ckpt, (size_t)chunk * (size_t)(nck > 0 ? nck : 1) * L * (R + 2) * sizeof(unsigned)))) return rc;
     if ((rc = sk_reserve(c, &c->lastq, (size_t)chunk * lq_stride * sizeof(unsigned)))) return rc;
     if ((rc = sk_reserve(c, &c->qflag, (size_t)chunk * sizeof(int32_t)))) return rc;

@@ -61,6 +61,8 @@ def build_parser():
     p.add_argument("--verbose", action="store_true", help="dump the parsed arguments to stderr")
     p.add_argument("--device", type=int, default=None, help="[extension] GPU index (default $SK_DEVICE or 0)")
     p.add_argument("--batch", type=int, default=2048, help="[extension] reads per GPU call")
+    p.add_argument("--gpus", type=int, default=1,
+                   help="[extension] shard every batch of reads over this many GPUs of the node")
     p.add_argument("--strict-compat", action="store_true",
                    help="[extension] keep the reference's -m defect (empty model order: header only)")
     return p
@@ -190,6 +192,8 @@ def main(argv=None):
 
     from . import _lib
     _lib.init(args.device)
+    if args.gpus > 1:
+        api.set_devices(range(args.gpus))
     out = _Batcher(args, models, order, lens)
     if args.signal:
         for fast5, read_id, vals, fl, raw in tsvio.iter_tsv_native(args.signal, 8):

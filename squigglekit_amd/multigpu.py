@@ -1,0 +1,384 @@
+"""Reads sharded over the GPUs of one node, and the one exchange the path has: the final gather of the
+fixed-size result records over RCCL (xGMI).
+
+Reads are independent in both scripts (segmenter.py:189-230, MotifSeq.py:261-298 carry no state from one
+read to the next), so N GPUs take contiguous blocks of the reads (`sharding.shard_bounds`) and never talk
+while computing.  Two launch shapes:
+
+  * one process, one host thread per GPU (`ThreadGroup`): what `api.*(devices=[...])`, the CLIs' `--gpus` and
+    a plain `python bench.py --gpus N` use.  The library binds a device per thread; ctypes releases the GIL.
+  * one process per GPU (`ProcessGroup`): what `python -m torch.distributed.run ... bench.py` gives.  Only the
+    launcher's environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_PORT) is read; rank 0's ncclUniqueId travels
+    through a small file store under $TMPDIR (one node), no torch import anywhere.
+
+The gather is `ncclAllGather` inside the library (`sk_comm_*`, csrc/sk_comm.hip).  If librccl cannot be loaded
+or a communicator cannot be created, the same interface is served by host concatenation (`backend == "host"`).
+"""
+import ctypes as C
+import os
+import shutil
+import tempfile
+import threading
+import time
+
+import numpy as np
+
+from . import _lib, sharding
+from ._lib import check, ptr
+
+UID_BYTES = 128
+
+
+# ------------------------------------------------------------------------------------------------
+# launch-shape detection
+# ------------------------------------------------------------------------------------------------
+def launch_env(environ=None):
+    """(rank, local_rank, world) when a one-process-per-GPU launcher set the usual variables, else None."""
+    e = os.environ if environ is None else environ
+    try:
+        world = int(e.get("WORLD_SIZE", "1"))
+    except ValueError:
+        return None
+    if world <= 1 or "RANK" not in e:
+        return None
+    rank = int(e["RANK"])
+    return rank, int(e.get("LOCAL_RANK", rank)), world
+
+
+def plan(gpus, environ=None):
+    """How a job asking for `gpus` GPUs runs here: ("single", 0, 0, 1), ("threads", 0, 0, N) -- this process
+    drives N devices -- or ("process", rank, local_rank, world) under a per-GPU launcher (whose WORLD_SIZE wins
+    over a conflicting --gpus)."""
+    le = launch_env(environ)
+    if le is not None:
+        return ("process",) + le
+    if gpus and int(gpus) > 1:
+        return ("threads", 0, 0, int(gpus))
+    return ("single", 0, 0, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# a tiny file store: rendezvous for the process-per-GPU shape, and the host fallback exchange
+# ------------------------------------------------------------------------------------------------
+def _proc_start(pid):
+    try:
+        with open("/proc/%d/stat" % pid) as fh:
+            return fh.read().rsplit(")", 1)[1].split()[19]          # starttime (field 22)
+    except (OSError, IndexError):
+        return "0"
+
+
+def store_dir(environ=None):
+    """One directory per launch: keyed on the launcher process (pid + start time, shared by its workers),
+    the rendezvous port and the restart count, so a stale directory of an earlier launch is never read."""
+    e = os.environ if environ is None else environ
+    if e.get("SK_RDZV_DIR"):
+        return e["SK_RDZV_DIR"]
+    ppid = os.getppid()
+    tag = "sk_rdzv_%d_%d_%s_%s_%s_%s" % (os.getuid(), ppid, _proc_start(ppid), e.get("MASTER_PORT", "0"),
+                                        e.get("TORCHELASTIC_RUN_ID", "none"), e.get("TORCHELASTIC_RESTART_COUNT", "0"))
+    return os.path.join(tempfile.gettempdir(), tag)
+
+
+class FileStore:
+    """Atomic small-file exchange between the ranks of one node."""
+
+    def __init__(self, path, rank, world, timeout=300.0):
+        self.path, self.rank, self.world, self.timeout = path, rank, world, timeout
+        os.makedirs(path, exist_ok=True)
+        self._seq = 0
+
+    def put(self, key, data):
+        tmp = os.path.join(self.path, ".%s.%d.tmp" % (key, self.rank))
+        with open(tmp, "wb") as fh:
+            fh.write(data)
+        os.replace(tmp, os.path.join(self.path, key))
+
+    def get(self, key):
+        p = os.path.join(self.path, key)
+        t0, nap = time.monotonic(), 0.0005
+        while True:
+            try:
+                with open(p, "rb") as fh:
+                    return fh.read()
+            except FileNotFoundError:
+                if time.monotonic() - t0 > self.timeout:
+                    raise TimeoutError("rank %d: nothing at %s after %.0f s" % (self.rank, p, self.timeout))
+                time.sleep(nap)
+                nap = min(nap * 2, 0.02)
+
+    def allgather(self, payload):
+        self._seq += 1
+        self.put("ag%d.%d" % (self._seq, self.rank), payload)
+        return [self.get("ag%d.%d" % (self._seq, r)) for r in range(self.world)]
+
+    def close(self):
+        """Every rank leaves a note; rank 0 waits for all of them (nobody reads the store any more), then removes
+        the directory.  The other ranks wait for nothing, so the removal cannot strand them."""
+        self.put("bye.%d" % self.rank, b"")
+        if self.rank == 0:
+            for r in range(self.world):
+                self.get("bye.%d" % r)
+            shutil.rmtree(self.path, ignore_errors=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# communicators (one per rank); both launch shapes give the same interface
+# ------------------------------------------------------------------------------------------------
+class RankComm:
+    """rank / world / backend ("rccl" or "host"), barrier(), allgather_host(array) -> [world, ...],
+    allgather_dev(d_send, d_recv, nbytes) (RCCL only), ranks_seen()."""
+
+    def __init__(self, rank, world, backend, host_exchange):
+        self.rank, self.world, self.backend = rank, world, backend
+        self._hx = host_exchange                                     # bytes -> list of bytes (rank order)
+
+    def ranks_seen(self):
+        """The communicator size as RCCL reports it (ncclCommCount); for the host fallback, the ranks that
+        actually answered an exchange."""
+        if self.backend == "rccl":
+            n, r = C.c_int32(), C.c_int32()
+            check(_lib.load().sk_comm_info(C.byref(n), C.byref(r)))
+            assert r.value == self.rank
+            return n.value
+        return len(self._hx(b"x"))
+
+    def allgather_host(self, arr):
+        a = np.ascontiguousarray(arr)
+        if self.backend == "rccl":
+            out = np.empty((self.world,) + a.shape, dtype=a.dtype)
+            check(_lib.load().sk_comm_allgather_host(ptr(a), ptr(out), a.nbytes))
+            return out
+        parts = self._hx(a.tobytes())
+        return np.stack([np.frombuffer(p, dtype=a.dtype).reshape(a.shape) for p in parts])
+
+    def barrier(self):
+        self.allgather_host(np.zeros(1, dtype=np.int64))
+
+    def allgather_dev(self, d_send, d_recv, nbytes):
+        """Every rank's `nbytes` at d_send -> d_recv[world * nbytes] on every rank, enqueued on the library's
+        stream (wait with sk_sync).  Device pointers; RCCL backend only."""
+        if self.backend != "rccl":
+            raise _lib.SquiggleKitError(-5, "device all-gather needs the RCCL backend (this group fell back to "
+                                            "host concatenation)")
+        check(_lib.load().sk_comm_allgather_dev(d_send, d_recv, nbytes))
+
+    def close(self):
+        if self.backend == "rccl":
+            check(_lib.load().sk_comm_destroy())
+
+
+def _want_rccl():
+    return os.environ.get("SK_COMM", "rccl").lower() != "host"
+
+
+class ThreadGroup:
+    """One process driving `devices`, one host thread each.  run(fn) calls fn(comm) on every rank's thread
+    (bound to its device) and returns the results in rank order."""
+
+    def __init__(self, devices, rccl=True, bind=True):
+        self.bind = bind                                             # False: host logic only (CPU tests)
+        rccl = rccl and bind
+        self.devices = [int(d) for d in devices]
+        if len(set(self.devices)) != len(self.devices) or not self.devices:
+            raise ValueError("devices must be distinct and non-empty")
+        n = len(self.devices)
+        self.world = n
+        self.backend, self.why_host = "host", None
+        if not rccl:
+            self.why_host = "not requested"
+        elif _want_rccl():
+            L = _lib.load()
+            arr = np.array(self.devices, dtype=np.int32)
+            rc = L.sk_comm_init_all(arr.ctypes.data_as(C.POINTER(C.c_int32)), n)
+            if rc == 0:
+                self.backend = "rccl"
+            elif rc == -5:                                           # SK_ERR_UNSUPPORTED: no RCCL here
+                self.why_host = L.sk_last_error().decode(errors="replace")
+            else:
+                check(rc)
+        else:
+            self.why_host = "SK_COMM=host"
+        self._bar = threading.Barrier(n)
+        self._slots = [None] * n
+
+    def _exchange(self, rank):
+        def hx(payload):
+            self._bar.wait()                                         # previous round fully read
+            self._slots[rank] = payload
+            self._bar.wait()
+            return list(self._slots)
+        return hx
+
+    def run(self, fn):
+        """fn(comm) on every rank's own thread; the communicators stay alive until close()."""
+        n = self.world
+        res, err = [None] * n, [None] * n
+
+        def body(rank):
+            try:
+                if self.bind:
+                    _lib.init(self.devices[rank])
+                res[rank] = fn(RankComm(rank, n, self.backend, self._exchange(rank)))
+            except BaseException as e:                               # noqa: BLE001 -- re-raised below
+                err[rank] = e
+                self._bar.abort()                                    # do not leave the other ranks waiting
+
+        ts = [threading.Thread(target=body, args=(r,), name="sk-gpu%d" % self.devices[r]) for r in range(n)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        first = [e for e in err if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+        if first:
+            raise first[0]
+        if any(e is not None for e in err):
+            raise [e for e in err if e is not None][0]
+        return res
+
+    def close(self):
+        """Destroy the communicators (each on a thread bound to its device)."""
+        if self.backend == "rccl":
+            self.run(lambda comm: comm.close())
+            self.backend = "host"
+
+
+class ProcessGroup:
+    """This process is one rank of a per-GPU launch.  `with ProcessGroup(rank, local, world) as comm: ...`"""
+
+    def __init__(self, rank, local_rank, world, environ=None, bind=True):
+        self.rank, self.local_rank, self.world = rank, local_rank, world
+        self.store = FileStore(store_dir(environ), rank, world)
+        self.backend, self.why_host = "host", None
+        if bind:
+            _lib.init(local_rank)
+        if _want_rccl() and bind:
+            L = _lib.load()
+            uid = C.create_string_buffer(UID_BYTES)
+            ok = 1
+            if rank == 0:
+                rc = L.sk_comm_unique_id(uid)
+                ok = 1 if rc == 0 else 0
+                if rc not in (0, -5):
+                    check(rc)
+                if not ok:
+                    self.why_host = L.sk_last_error().decode(errors="replace")
+                self.store.put("uid", bytes([ok]) + uid.raw)
+            blob = self.store.get("uid")
+            if blob[0] == 1:
+                rc = L.sk_comm_init_rank(blob[1:1 + UID_BYTES], world, rank)
+                mine = 1 if rc == 0 else 0
+                if not mine:
+                    self.why_host = L.sk_last_error().decode(errors="replace")
+                votes = self.store.allgather(bytes([mine]))           # all or nothing
+                if all(v == b"\x01" for v in votes):
+                    self.backend = "rccl"
+                elif mine:
+                    L.sk_comm_destroy()
+        elif not _want_rccl():
+            self.why_host = "SK_COMM=host"
+        self.comm = RankComm(rank, world, self.backend, self.store.allgather)
+
+    def __enter__(self):
+        return self.comm
+
+    def __exit__(self, *exc):
+        try:
+            self.comm.close()
+        finally:
+            if exc[0] is None:
+                self.store.close()
+        return False
+
+
+# ------------------------------------------------------------------------------------------------
+# product entry: a host batch over several GPUs
+# ------------------------------------------------------------------------------------------------
+_groups = {}
+_groups_mu = threading.Lock()
+
+
+def group_for(devices, rccl=False):
+    """The (cached) ThreadGroup of a device list; created with RCCL communicators when `rccl` is asked for
+    (an RCCL group also serves the host-gather calls)."""
+    key = tuple(int(d) for d in devices)
+    with _groups_mu:
+        g = _groups.get(key)
+        if g is not None and rccl and g.backend != "rccl" and g.why_host == "not requested":
+            g = None                                                 # upgrade: build the communicators now
+        if g is None:
+            g = _groups[key] = ThreadGroup(key, rccl=rccl)
+        return g
+
+
+def close_groups():
+    with _groups_mu:
+        for g in _groups.values():
+            g.close()
+        _groups.clear()
+
+
+def run_sharded(devices, total, fn, rccl=False):
+    """fn(lo, hi, comm) on one thread per device, over the block split of `total` reads.  Results are written
+    by fn into views of caller-owned host arrays (that IS the host-side gather).  Returns the group."""
+    g = group_for(devices, rccl=rccl)
+
+    def body(comm):
+        lo, hi = sharding.shard_bounds(total, comm.rank, comm.world)
+        return fn(lo, hi, comm)
+
+    g.run(body)
+    return g
+
+
+def motifseq_sharded(sig, lens, motif, scale_mode, scale_low, scale_hi, devices, gather="host"):
+    """sk_motifseq over `devices`: rank r uploads rows [lo_r, hi_r), runs the device-resident path and
+      gather == "host"  downloads its records into its slice of the result (no inter-GPU traffic at all);
+      gather == "rccl"  all-gathers the padded record blocks over RCCL so that every GPU holds the complete
+                        result, and rank 0 downloads it (the shape a device-resident pipeline uses).
+    Returns (hits, info)."""
+    L = _lib.load()
+    R, stride = sig.shape
+    out = np.zeros(R, dtype=_lib.HIT_DTYPE)
+    sizes = sharding.shard_sizes(R, len(devices))
+    pad = max(sizes) if sizes else 0
+    info = {"devices": list(devices), "shards": sizes, "gather": gather}
+
+    def body(lo, hi, comm):
+        n = hi - lo
+        use_rccl = gather == "rccl" and comm.backend == "rccl"
+        hb = _lib.HIT_DTYPE.itemsize
+        d_sig = L.sk_dev_alloc(max(1, n) * stride * 2)
+        d_len = L.sk_dev_alloc(max(1, n) * 4)
+        d_out = L.sk_dev_alloc(max(1, pad) * hb)
+        d_all = L.sk_dev_alloc(max(1, pad) * hb * comm.world) if use_rccl else None
+        try:
+            if not d_sig or not d_len or not d_out or (use_rccl and not d_all):
+                check(-4)
+            if n:
+                check(L.sk_dev_upload(d_sig, ptr(sig[lo:hi]), n * stride * 2))
+                check(L.sk_dev_upload(d_len, ptr(lens[lo:hi]), n * 4))
+                check(L.sk_motifseq_dev_i16(d_sig, stride, d_len, n, ptr(motif), motif.size, scale_mode,
+                                            int(scale_low), int(scale_hi), d_out))
+            if use_rccl:
+                comm.allgather_dev(d_out, d_all, pad * hb)
+                check(L.sk_sync())
+                if comm.rank == 0:
+                    full = np.empty(comm.world * pad, dtype=_lib.HIT_DTYPE)
+                    check(L.sk_dev_download(ptr(full), d_all, full.nbytes))
+                    for r in range(comm.world):
+                        a, b = sharding.shard_bounds(R, r, comm.world)
+                        out[a:b] = full[r * pad:r * pad + (b - a)]
+            elif n:
+                check(L.sk_sync())
+                check(L.sk_dev_download(ptr(out[lo:hi]), d_out, n * hb))
+        finally:
+            for d in (d_sig, d_len, d_out, d_all):
+                if d:
+                    L.sk_dev_free(d)
+
+    g = run_sharded(devices, R, body, rccl=(gather == "rccl"))
+    info["backend"] = g.backend
+    if gather == "rccl" and g.backend != "rccl":
+        info["gather"] = "host (RCCL unavailable: %s)" % g.why_host
+    return out, info

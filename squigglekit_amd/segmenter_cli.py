@@ -51,6 +51,8 @@ def build_parser():
     p.add_argument("--raw_signal", action="store_true", help="fast5 input: keep raw ADC values (no pA conversion)")
     p.add_argument("--device", type=int, default=None, help="[extension] GPU index (default $SK_DEVICE or 0)")
     p.add_argument("--batch", type=int, default=4096, help="[extension] reads per GPU call")
+    p.add_argument("--gpus", type=int, default=1,
+                   help="[extension] shard every batch of reads over this many GPUs of the node")
     return p
 
 
@@ -120,6 +122,8 @@ def main(argv=None):
 
     from . import _lib
     _lib.init(args.device)
+    if args.gpus > 1:
+        api.set_devices(range(args.gpus))
     out = _Batcher(args)
 
     if args.signal:

@@ -1,0 +1,118 @@
+"""GPU: the chunked DTW path and BASELINE.json's full-size MotifSeq configs.
+
+A screening call is split into chunks of (scratch budget / per-read scratch) reads
+(`sk_launch_sdtw_screen`), with chunk-relative indexing of the checkpoints, the last-row costs and the
+per-read flags.  With the default 12 GB budget only batches beyond ~280 000 reads x 4 000 samples reach a
+second chunk, so (1) SK_DTW_SCRATCH_MB forces many small chunks on a batch the oracle covers read for read,
+and (2) C4 (1 000 000 x 4 000 x 200-pt) and C5 (100 000 x 20 000 x 500-pt) run at full size from the device
+generator, with a strided sample spanning every chunk compared against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import download_rows, oracle_motifseq_threaded, strided_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(got, want, label):
+    bad = np.nonzero((got["start"] != want["start"]) | (got["end"] != want["end"]) | (got["n"] != want["n"])
+                     | ~((got["dist"] == want["dist"]) | (np.isnan(got["dist"]) & np.isnan(want["dist"]))))[0]
+    assert bad.size == 0, "%s: %d reads differ, first %s: got %s want %s" % (
+        label, bad.size, bad[:5], got[bad[:5]], want[bad[:5]])
+
+
+def _dtw_profile(L):
+    da, sb = C.c_float(), C.c_float()
+    la, lb, rpl = C.c_int32(), C.c_int32(), C.c_int32()
+    assert L.sk_last_dtw_profile(C.byref(da), C.byref(la), C.byref(sb), C.byref(lb), C.byref(rpl)) == 0
+    return la.value, rpl.value
+
+
+@pytest.mark.parametrize("scheme", ["screen", "exact2"])
+def test_forced_small_chunks_every_read(gpu, ora, monkeypatch, scheme):
+    """~3 000 ragged reads in >= 3 chunks (here 17+): every read equals the oracle, including the reads next to
+    chunk boundaries and reads that need the exact retry in chunks >= 1."""
+    from squigglekit_amd import api, synth
+    L = gpu.load()
+    R, M = 3001, 4000
+    motif = synth.synthetic_motif(200, seed=3)
+    sig = synth.squiggle_batch(R, M, 31337, motif=motif)
+    rng = np.random.default_rng(5)
+    lens = np.full(R, M, dtype=np.int32)
+    lens[rng.choice(R, 600, replace=False)] = rng.integers(1, M + 1, 600)
+    lens[[0, 1, 177, 178, 179, R - 1]] = [M, 17, 3999, 1, 2500, 777]
+    # a 4x time-stretched copy of the motif: its optimal path is far wider than the look-back window, so the
+    # read cannot be certified and takes the exact retry -- placed in many different chunks
+    stretched = np.clip(np.rint(np.repeat(motif, 4) * 93.4 + 511.0), 1, 1199).astype(np.int16)
+    forced = np.arange(7, R, 97)
+    for r in forced:
+        lens[r] = M
+        off = 100 + (int(r) * 37) % (M - 1000)
+        sig[r, off:off + stretched.size] = stretched
+    if scheme == "exact2":
+        monkeypatch.setenv("SK_DTW_SCHEME", "exact2")
+    one = api.motifseq_batch(sig, lens, motif)                       # default budget: one chunk
+    launches1, _ = _dtw_profile(L)
+    monkeypatch.setenv("SK_DTW_SCRATCH_MB", "8")
+    got = api.motifseq_batch(sig, lens, motif)
+    launches, per_launch = _dtw_profile(L)
+    retries = L.sk_last_dtw_retries()
+    assert launches1 == 1 and launches >= 3, (launches1, launches)
+    assert per_launch < R // 3
+    want = oracle_motifseq_threaded(ora, sig, lens, motif)
+    ok = (want["flags"] & 2) == 0                                    # MAD == 0 reads: flagged, not compared
+    _same(got[ok], want[ok], "chunked (%d chunks of <= %d reads)" % (launches, per_launch))
+    _same(one[ok], want[ok], "one chunk")
+    assert np.array_equal(got["flags"], want["flags"])
+    assert retries >= forced.size // 2, "stretched reads should have needed the retry (%d)" % retries
+    assert (got["end"][forced] - got["start"][forced]).max() > 600
+
+
+def _full_size(gpu, ora, R, M, N, seed, nsample, min_chunks):
+    from squigglekit_amd import synth
+    from squigglekit_amd._lib import HIT_DTYPE, check, ptr
+    L = gpu.load()
+    stride = (M + 7) // 8 * 8
+    motif = synth.synthetic_motif(N)
+    d_sig = L.sk_dev_alloc(R * stride * 2)
+    d_len = L.sk_dev_alloc(R * 4)
+    d_out = L.sk_dev_alloc(R * HIT_DTYPE.itemsize)
+    assert d_sig and d_len and d_out, L.sk_last_error()
+    try:
+        lens = np.full(R, M, dtype=np.int32)
+        check(L.sk_dev_upload(d_len, ptr(lens), lens.nbytes))
+        check(L.sk_synth_squiggles_dev(d_sig, stride, R, M, seed, ptr(motif), N))
+        check(L.sk_motifseq_dev_i16(d_sig, stride, d_len, R, ptr(motif), N, 0, 0, 1200, d_out))
+        check(L.sk_sync())
+        launches, per_launch = _dtw_profile(L)
+        assert launches >= min_chunks, "expected the chunked path (%d launches)" % launches
+        hits = np.empty(R, dtype=HIT_DTYPE)
+        check(L.sk_dev_download(ptr(hits), d_out, hits.nbytes))
+        # size-independent properties over the WHOLE batch
+        assert np.all(hits["n"] > 0) and np.all(hits["n"] <= M)
+        assert np.all((0 <= hits["start"]) & (hits["start"] <= hits["end"]) & (hits["end"] < hits["n"]))
+        assert np.all(np.isfinite(hits["dist"])) and np.all(hits["dist"] >= 0)
+        # strided sample over every chunk (runs of 4 reads, so chunk-boundary neighbours are included)
+        rows = strided_rows(R, nsample)
+        bounds = np.arange(per_launch, R, per_launch)               # first read of chunks 1, 2, ...
+        rows = np.unique(np.concatenate([rows, bounds, bounds - 1]))
+        assert np.unique(rows // per_launch).size == launches
+        sample = download_rows(L, d_sig, stride * 2, rows, np.int16, stride)
+        want = oracle_motifseq_threaded(ora, sample, lens[:len(rows)], motif)
+        _same(hits[rows], want, "full size %d x %d x %d-pt" % (R, M, N))
+    finally:
+        L.sk_dev_free(d_sig); L.sk_dev_free(d_len); L.sk_dev_free(d_out)
+
+
+def test_c4_full_size_1m_reads(gpu, ora):
+    """BASELINE configs[3] on one GPU: 1 000 000 x 4 000 int16 vs a 200-pt motif (4 chunks)."""
+    from squigglekit_amd import synth
+    _full_size(gpu, ora, 1_000_000, 4000, 200, synth.SEED_C4, 2400, 3)
+
+
+def test_c5_full_size_100k_long_reads(gpu, ora):
+    """BASELINE configs[4] on one GPU: 100 000 x 20 000 int16 vs a 500-pt motif (L = 64 kernels, chunked)."""
+    from squigglekit_amd import synth
+    _full_size(gpu, ora, 100_000, 20000, 500, synth.SEED_C5, 2000, 2)

@@ -1,0 +1,74 @@
+"""GPU (one device is all the test box has): the RCCL side of the multi-GPU path with a one-rank communicator --
+library-loaded librccl, ncclCommInitAll / ncclCommInitRank, the device all-gather of hit records, and
+bench.py's self-launched gather path.  The N > 1 structure itself is covered on CPU (test_multigpu_host.py,
+test_distributed_gloo.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_thread_group_rccl_one_rank(gpu):
+    from squigglekit_amd import multigpu
+    g = multigpu.ThreadGroup([0])
+    assert g.backend == "rccl", g.why_host
+
+    def body(comm):
+        assert comm.ranks_seen() == 1                                 # ncclCommCount
+        comm.barrier()
+        return comm.allgather_host(np.array([3.5, -1.0])).tolist()
+    assert g.run(body) == [[[3.5, -1.0]]]
+    g.close()
+    assert g.backend == "host"
+
+
+def test_motifseq_sharded_rccl_gather_equals_plain_call(gpu, ora):
+    from squigglekit_amd import api, multigpu, synth
+    motif = synth.synthetic_motif(120, seed=9)
+    sig = synth.squiggle_batch(300, 3000, 2468, motif=motif)
+    lens = np.full(300, 3000, dtype=np.int32)
+    lens[::7] = 1777
+    plain = api.motifseq_batch(sig, lens, motif)
+    got, info = multigpu.motifseq_sharded(sig, lens, motif, 0, 0, 1200, [0], gather="rccl")
+    assert info["backend"] == "rccl" and info["gather"] == "rccl" and info["shards"] == [300]
+    assert got.tobytes() == plain.tobytes()
+    want = ora.motifseq_batch_i16(sig[:40], lens[:40], motif)
+    assert np.array_equal(got["dist"][:40], want["dist"]) and np.array_equal(got["end"][:40], want["end"])
+    multigpu.close_groups()
+    # devices=[0] through the product API (single device: plain path on that device)
+    again = api.motifseq_batch(sig, lens, motif, devices=[0])
+    assert again.tobytes() == plain.tobytes()
+    segs, nsegs = api.segment_batch(sig, lens - 1, devices=[0])
+    segs1, nsegs1 = api.segment_batch(sig, lens - 1)
+    assert np.array_equal(segs, segs1) and np.array_equal(nsegs, nsegs1)
+
+
+def test_process_group_rccl_unique_id_one_rank(gpu, tmp_path, monkeypatch):
+    """The process-per-GPU shape's RCCL bootstrap (ncclGetUniqueId -> file store -> ncclCommInitRank), world 1."""
+    from squigglekit_amd import multigpu
+    monkeypatch.setenv("SK_RDZV_DIR", str(tmp_path / "store"))
+    with multigpu.ProcessGroup(0, 0, 1) as comm:
+        assert comm.backend == "rccl" and comm.ranks_seen() == 1
+        assert comm.allgather_host(np.array([7], dtype=np.int64)).tolist() == [[7]]
+    assert not (tmp_path / "store").exists()
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_gather_path_bare_python(gpu, scaling):
+    """`python bench.py` run plainly (no launcher), with the per-step RCCL gather forced on at one rank."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-comm", "--reads", "20000", "--steps", "2",
+           "--warmup", "1", "--cpu-seconds", "2", "--no-extras", "--scaling", scaling]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["scaling"] == scaling
+    assert line["config"]["gather_backend"] == "rccl" and line["config"]["ranks_seen"] == 1
+    assert line["parity"]["dist_bit_identical"] and line["parity"]["start_end_exact"]
+    assert "torch" not in p.stderr

@@ -1,0 +1,129 @@
+"""CPU: the N > 1 structure without torch -- launch-shape detection, the thread-per-GPU group, the
+process-per-GPU group over the file store (what `torch.distributed.run ... bench.py` uses), block sharding and
+the gather of fixed-size records.  No GPU: ranks compute their shard with the oracle, the exchange runs on the
+host backend (the RCCL backend has the same interface; it is exercised on the GPU box with one rank)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_plan_launch_shapes():
+    from squigglekit_amd import multigpu
+    assert multigpu.plan(1, {}) == ("single", 0, 0, 1)
+    assert multigpu.plan(8, {}) == ("threads", 0, 0, 8)            # a bare `python bench.py --gpus 8`
+    env = {"WORLD_SIZE": "4", "RANK": "3", "LOCAL_RANK": "3", "MASTER_PORT": "29500"}
+    assert multigpu.plan(4, env) == ("process", 3, 3, 4)            # under torch.distributed.run
+    assert multigpu.plan(1, env) == ("process", 3, 3, 4)            # the launcher's world size wins
+    assert multigpu.plan(2, {"WORLD_SIZE": "1", "RANK": "0"}) == ("threads", 0, 0, 2)
+    assert multigpu.launch_env({"WORLD_SIZE": "x"}) is None
+
+
+def test_bench_cli_defaults_finish_fast():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse([])
+    assert (a.gpus, a.workload, a.scaling, a.reads, a.samples, a.motif) == (1, "motifseq", "weak", 1_000_000, 4000, 200)
+    rows = bench.strided_rows(1_000_000, 8192)
+    assert rows[0] == 0 and rows[-1] == 999_999 and 8000 <= len(rows) <= 8192
+    assert np.unique(rows // 250_000).size == 4                      # every chunk of the screening path is sampled
+
+
+def test_thread_group_host_exchange_and_errors():
+    from squigglekit_amd import multigpu
+    g = multigpu.ThreadGroup([0, 1, 2], rccl=False, bind=False)
+    assert g.backend == "host"
+
+    def body(comm):
+        assert comm.ranks_seen() == 3
+        comm.barrier()
+        got = comm.allgather_host(np.array([comm.rank * 10.0, 1.5]))
+        got2 = comm.allgather_host(np.arange(4, dtype=np.int32) + comm.rank)
+        return got.tolist(), got2[:, 0].tolist()
+
+    res = g.run(body)
+    assert all(r == ([[0.0, 1.5], [10.0, 1.5], [20.0, 1.5]], [0, 1, 2]) for r in res)
+
+    def boom(comm):
+        if comm.rank == 1:
+            raise ValueError("rank 1 failed")
+        comm.barrier()                                               # must not hang: the barrier is aborted
+    g2 = multigpu.ThreadGroup([0, 1], rccl=False, bind=False)
+    with pytest.raises(ValueError, match="rank 1 failed"):
+        g2.run(boom)
+    with pytest.raises(ValueError):
+        multigpu.ThreadGroup([0, 0], rccl=False, bind=False)
+
+
+def test_sharded_host_gather_equals_unsharded(ora):
+    """run_sharded's contract: fn(lo, hi) per rank over the block split, results written into views of one
+    host array == the unsharded job."""
+    from squigglekit_amd import multigpu, sharding, synth
+    motif = synth.synthetic_motif(40)
+    sig = synth.squiggle_batch(23, 600, 99, motif=motif)
+    lens = np.full(23, 600, dtype=np.int32)
+    want = ora.motifseq_batch_i16(sig, lens, motif)
+    out = np.zeros_like(want)
+    g = multigpu.ThreadGroup([0, 1, 2], rccl=False, bind=False)
+    seen = []
+
+    def body(comm):
+        lo, hi = sharding.shard_bounds(23, comm.rank, comm.world)
+        seen.append((lo, hi))
+        out[lo:hi] = ora.motifseq_batch_i16(sig[lo:hi], lens[lo:hi], motif)
+    g.run(body)
+    assert out.tobytes() == want.tobytes()
+    assert sorted(seen) == [(0, 8), (8, 16), (16, 23)]
+
+
+_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import oracle as ora
+from squigglekit_amd import multigpu, sharding, synth
+from squigglekit_amd._lib import HIT_DTYPE
+shape, rank, local, world = multigpu.plan(int(sys.argv[2]))
+assert shape == "process" and world == int(sys.argv[2])
+total = int(sys.argv[3])
+motif = synth.synthetic_motif(40)
+sig = synth.squiggle_batch(total, 600, 4321, motif=motif)            # every rank can regenerate the job
+lo, hi = sharding.shard_bounds(total, rank, world)
+lens = np.full(hi - lo, 600, dtype=np.int32)
+local_hits = ora.motifseq_batch_i16(sig[lo:hi], lens, motif)          # this rank's shard only
+sizes = sharding.shard_sizes(total, world)
+with multigpu.ProcessGroup(rank, local, world, bind=False) as comm:
+    assert comm.backend == "host" and comm.ranks_seen() == world
+    comm.barrier()
+    padded = np.zeros(max(sizes), dtype=HIT_DTYPE)
+    padded[:hi - lo] = local_hits
+    allr = comm.allgather_host(padded)                                # [world, pad] records, rank order
+    tmax = comm.allgather_host(np.array([float(rank)])).max()
+    full = np.concatenate([allr[r, :sizes[r]] for r in range(world)])
+    if rank == 0:
+        want = ora.motifseq_batch_i16(sig, np.full(total, 600, dtype=np.int32), motif)
+        print("RESULT", full.tobytes() == want.tobytes(), full.size, tmax)
+"""
+
+
+@pytest.mark.parametrize("total", [17, 32])
+def test_process_group_file_store_world2(total, tmp_path):
+    """Two processes with the launcher's environment (as torch.distributed.run sets it), no torch: the rendezvous
+    directory, the exchange and the assembled result."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29%03d" % (total + 100), SK_COMM="host", TMPDIR=str(tmp_path))
+        env.pop("SK_RDZV_DIR", None)
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, "2", str(total)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert outs[0][0].split() == ["RESULT", "True", str(total), "1.0"]
+    assert not [d for d in os.listdir(tmp_path) if d.startswith("sk_rdzv_")]      # the store cleaned up after itself

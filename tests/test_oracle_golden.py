@@ -216,3 +216,20 @@ def test_real_read_regression_anchor(ora, example_read, example_model):
     cols = row["stdout"].strip().split("\n")[1].split("\t")
     d2, s2, e2 = ora.dtw_subsequence(m32, y)
     assert (str(s2), str(e2), repr(d2)) == (cols[3], cols[4], cols[6])
+
+
+def test_python_speed_restatements_match_the_c_oracle(ora):
+    """The interpreter-speed restatements bench.py times for the "as shipped" baseline take the same
+    decisions as the C oracle (which the reference goldens pin)."""
+    from squigglekit_amd import synth
+    sig = synth.squiggle_batch(24, 4000, 515151)
+    for r in range(24):
+        f = ora.scale_outliers(sig[r].astype(float), 0, 900)
+        assert ora.get_segs_python(f) == ora.get_segs(f)
+        g = ora.scale_outliers(sig[r].astype(float), 0, 1200)
+        assert np.array_equal(ora.medmad_python_loop(g), ora.medmad(g)[0])
+    for p in (ora.SegParams(error=60, corrector=10, window=20), ora.SegParams(error=0, window=5, seg_dist=500),
+              ora.SegParams(std_scale=2.5, stall_len=0.01)):
+        for r in range(6):
+            f = ora.scale_outliers(sig[r].astype(float), 0, 900)
+            assert ora.get_segs_python(f, p) == ora.get_segs(f, p)
