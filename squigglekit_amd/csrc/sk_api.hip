@@ -384,11 +384,23 @@ int sk_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_le
     int32_t lo = p->lim_low, hi = p->lim_hi;
     clamp_limits(&lo, &hi);
     const int64_t words = (stride + 63) / 64;
-    if ((rc = sk_reserve(c, &c->comp, (size_t)nreads * (size_t)stride * sizeof(int16_t)))) return rc;
     if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
-    if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * sizeof(uint64_t)))) return rc;
     // slots past nsegs[r] read as zero, whatever the buffer held before
     SK_HIP(hipMemsetAsync(d_segs, 0, (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t), c->stream));
+    if (sk_segment_fast_applies(d_sig, stride, lo, hi, p->std_scale)) {
+        // streaming statistics (sk_segstat.hip): reads of up to 4 096 samples, exact integer sums, certified
+        // integer thresholds; the numpy-order kernel redoes the (almost always empty) list of uncertified reads
+        const size_t mb = (size_t)nreads * (size_t)sk_segment_fast_row16(stride) * 16;
+        if ((rc = sk_reserve(c, &c->mask, mb))) return rc;
+        if ((rc = sk_reserve(c, &c->retry, ((size_t)nreads + 1) * sizeof(int32_t)))) return rc;
+        rc = sk_launch_segment_fast(c, d_sig, stride, d_len, nreads, p, lo, hi, (sk_prep *)c->prep.p, c->mask.p,
+                                    (int32_t *)c->retry.p, d_segs, d_nsegs, max_segs);
+        if (rc) return rc;
+        c->ev_valid = true;
+        return SK_OK;
+    }
+    if ((rc = sk_reserve(c, &c->comp, (size_t)nreads * (size_t)stride * sizeof(int16_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * sizeof(uint64_t)))) return rc;
     SK_HIP(hipEventRecord(c->ev[0], c->stream));
     rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nreads, lo, hi, SK_PREP_SEGMENT, p->std_scale,
                             (int16_t *)c->comp.p, (sk_prep *)c->prep.p, (uint64_t *)c->mask.p, nreads);

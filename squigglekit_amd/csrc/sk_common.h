@@ -90,7 +90,11 @@ int64_t sk_dtw_chunk_reads(size_t per_read, int64_t nreads);
 int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len,
                        int32_t nreads, int32_t lo, int32_t hi, int mode, double std_scale,
                        int16_t *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_stride,
-                       int32_t t0 = 0, int32_t t1 = 0x7fffffff);   // statistics window (filtered index)
+                       int32_t t0 = 0, int32_t t1 = 0x7fffffff,    // statistics window (filtered index)
+                       // SEGMENT mode over a device-side list of reads (d_list[0 .. *d_count)): statistics in numpy's
+                       // order, masks written as {in band, kept} entries in raw coordinates (sk_segstat.hip)
+                       const int32_t *d_list = nullptr, const int32_t *d_count = nullptr,
+                       void *d_mask2 = nullptr, int row16 = 0);
 // wavefront-per-read medmad variant (sk_prepw.hip): same results; returns 1 (nothing launched) when
 // the configuration is outside its range and the caller has to use the workgroup-per-read kernel
 int sk_launch_prepw_medmad(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len,
@@ -132,6 +136,13 @@ int sk_launch_roll_stats(sk_ctx *c, const int16_t *d_comp, int64_t stride, sk_pr
                          int32_t w, double std_scale, int64_t *d_psum, uint64_t *d_below, uint64_t *d_above);
 int sk_launch_roll_walk(sk_ctx *c, const uint64_t *d_below, const uint64_t *d_above, const sk_prep *d_prep,
                         int32_t nreads, const sk_roll_params *p, int32_t *d_xy, int32_t *d_found);
+
+// ---- segmenter, streaming path (sk_segstat.hip) ----
+int  sk_segment_fast_row16(int64_t stride);
+bool sk_segment_fast_applies(const void *d_sig, int64_t stride, int32_t lo, int32_t hi, double std_scale);
+int  sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                            const sk_seg_params *p, int32_t lo, int32_t hi, sk_prep *d_prep, void *d_mask2,
+                            int32_t *d_retry, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs);
 
 // ---- segment walk (sk_segment.hip) ----
 struct sk_drna_params;

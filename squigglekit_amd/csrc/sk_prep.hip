@@ -319,13 +319,24 @@ __device__ __forceinline__ void put8(P *dst, const unsigned (&q)[4], int al)
 // WINDOWED: statistics over filtered samples [t0, t1) only (dRNA_segmenter.py:109-110)
 // MEDMAD: the medmad variant (its own instantiation: it shares no statistics code with the
 // mean/std variants, and one kernel carrying both runs out of registers)
-template <bool LDSCOMP, bool WINDOWED, bool MEDMAD>
+// LISTED: the reads are list[0 .. *count) (the streaming segmenter's uncertified reads, sk_segstat.hip); the
+// mask goes out as {in band, kept} bytes in RAW sample coordinates into that path's per-read entries.
+struct ListedArgs {
+    const int32_t *list;
+    const int32_t *count;
+    unsigned char *mask2;
+    int            row16;
+};
+
+template <bool LDSCOMP, bool WINDOWED, bool MEDMAD, bool LISTED = false>
 __global__ __launch_bounds__(TPB, 8) __attribute__((amdgpu_num_sgpr(80)))
 void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *__restrict__ len, int nreads,
                 int lo, int hi, int mode, double std_scale, int vec_ok, int t0, int t1,
                 int16_t *__restrict__ comp, sk_prep *__restrict__ prep,
-                uint64_t *__restrict__ maskT, int64_t mask_rows)
+                uint64_t *__restrict__ maskT, int64_t mask_rows, ListedArgs la)
 {
+    if constexpr (LISTED) nreads = *la.count;
+    auto rid = [&](int k) -> int { if constexpr (LISTED) return la.list[k]; else return k; };
     extern __shared__ __align__(16) unsigned char lds_raw[];
     Scratch *sc = (Scratch *)lds_raw;
     unsigned *hist = (unsigned *)(lds_raw + sizeof(Scratch));
@@ -373,9 +384,11 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     // reject such input; device-resident callers get the clamp)
     const int maxM = (int)min(stride, (int64_t)0x7fffff00);
     auto rdlen = [&](int rr) { return min(max(len[rr], 0), maxM); };
-    int Mnext = ((int)blockIdx.x < nreads) ? rdlen(blockIdx.x) : 0;
-    if ((int)blockIdx.x < nreads) load8(sig + (int64_t)blockIdx.x * stride, Mnext, tid * 8, v);
-    for (int r = blockIdx.x; r < nreads; r += gridDim.x) {
+    int rnext = ((int)blockIdx.x < nreads) ? rid(blockIdx.x) : 0;
+    int Mnext = ((int)blockIdx.x < nreads) ? rdlen(rnext) : 0;
+    if ((int)blockIdx.x < nreads) load8(sig + (int64_t)rnext * stride, Mnext, tid * 8, v);
+    for (int rk = blockIdx.x; rk < nreads; rk += gridDim.x) {
+    const int r = rnext;                                   // the read (rk: its position in the launch / list)
     const int M = Mnext;
     const int16_t *row = sig + (int64_t)r * stride;
     int16_t *crow = comp + (int64_t)r * stride;
@@ -443,9 +456,10 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     }
     const int n = run;
     {                                                      // first tile of my next read
-        const int rn = r + gridDim.x;
-        Mnext = (rn < nreads) ? rdlen(rn) : 0;
-        if (rn < nreads) load8(sig + (int64_t)rn * stride, Mnext, tid * 8, v);
+        const int rn = rk + gridDim.x;
+        rnext = (rn < nreads) ? rid(rn) : 0;
+        Mnext = (rn < nreads) ? rdlen(rnext) : 0;
+        if (rn < nreads) load8(sig + (int64_t)rnext * stride, Mnext, tid * 8, v);
     }
     __syncthreads();                                       // histogram + compacted samples complete
 
@@ -574,6 +588,28 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     // ---- in-band mask: one compare per sample, the lane mask of the compare is the word -------
     const int first = sc->sel[2];
     const unsigned width = (unsigned)sc->sel[3];
+    if constexpr (LISTED) {                                // raw coordinates: one byte of each mask per 8 samples
+        unsigned char *mb = la.mask2 + (int64_t)r * la.row16 * 16;
+        for (int base = 0; base < M; base += TPB * 8) {
+            const int i0 = base + tid * 8;
+            if (i0 < M) {
+                unsigned q[4];
+                load8(row, M, i0, q);
+                unsigned in8 = 0, kp8 = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int x = sample(q, k);
+                    const bool kept = i0 + k < M && x > lo && x < hi;
+                    kp8 |= (kept ? 1u : 0u) << k;
+                    in8 |= ((kept && (unsigned)(x - first) < width) ? 1u : 0u) << k;
+                }
+                mb[(i0 >> 6) * 16 + ((i0 & 63) >> 3)] = (unsigned char)in8;
+                mb[(i0 >> 6) * 16 + 8 + ((i0 & 63) >> 3)] = (unsigned char)kp8;
+            }
+        }
+        lds_barrier();                                     // LDS is reused by the next read
+        continue;
+    }
     for (int base = 0; base < n; base += TPB) {
         const int i = base + tid;
         bool in = false;
@@ -932,9 +968,12 @@ int sk_launch_roll_stats(sk_ctx *c, const int16_t *d_comp, int64_t stride, sk_pr
 int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len,
                        int32_t nreads, int32_t lo, int32_t hi, int mode, double std_scale,
                        int16_t *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_stride,
-                       int32_t t0, int32_t t1)
+                       int32_t t0, int32_t t1, const int32_t *d_list, const int32_t *d_count, void *d_mask2, int row16)
 {
     if (nreads <= 0) return SK_OK;
+    const bool listed = d_list != nullptr;
+    ListedArgs la;
+    la.list = d_list; la.count = d_count; la.mask2 = (unsigned char *)d_mask2; la.row16 = row16;
     if (mode == SK_PREP_MEDMAD && t0 <= 0 && t1 == 0x7fffffff) {      // medmad: one wavefront per read
         const int rc = sk_launch_prepw_medmad(c, d_sig, stride, d_len, nreads, lo, hi, d_comp, d_prep);
         if (rc != 1) return rc;
@@ -955,7 +994,10 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
     const bool ldscomp = mode != SK_PREP_MEDMAD && lds + lds_comp <= 40 * 1024;
     if (ldscomp) lds += lds_comp;
     const bool windowed = t0 > 0 || t1 < 0x7fffffff;
-    auto fn = (mode == SK_PREP_MEDMAD) ? k_prep_i16<false, false, true>
+    if (listed && (!ldscomp || windowed || mode != SK_PREP_SEGMENT))
+        return sk_fail(SK_ERR_INVALID, "internal: listed prep needs the LDS-resident segmenter variant");
+    auto fn = listed ? k_prep_i16<true, false, false, true>
+              : (mode == SK_PREP_MEDMAD) ? k_prep_i16<false, false, true>
               : ldscomp ? (windowed ? k_prep_i16<true, true, false> : k_prep_i16<true, false, false>)
                         : (windowed ? k_prep_i16<false, true, false> : k_prep_i16<false, false, false>);
     if (lds > 64 * 1024)
@@ -971,8 +1013,9 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
     if (const char *e = getenv("SK_PREP_PERCU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }
     long long g = (long long)c->num_cu * per_cu * rounds;
     int grid = g > nreads ? nreads : (int)g;
+    if (listed && grid > c->num_cu) grid = c->num_cu;      // (the list is almost always empty)
     hipLaunchKernelGGL(fn, dim3(grid), dim3(TPB), lds, c->stream, d_sig, stride, d_len, nreads,
-                       lo, hi, mode, std_scale, vec_ok, t0, t1, d_comp, d_prep, d_mask, mask_stride);
+                       lo, hi, mode, std_scale, vec_ok, t0, t1, d_comp, d_prep, d_mask, mask_stride, la);
     SK_HIP(hipGetLastError());
     return SK_OK;
 }

@@ -1,0 +1,522 @@
+// sk_segstat.hip -- the segmenter's filter + statistics + classification as ONE streaming pass (gfx950).
+//
+// Covers, per read (segmenter.py):
+//   scale_outliers      :311-318     strict lo < x < hi
+//   np.median, np.std   :410, :412   -> top / bot (:413-414)
+//   a < top and a > bot :431         one bit per sample
+// and hands the walk kernel (k_seg_walk2 below, the state machine of :420-464) two bit masks per read in RAW
+// sample coordinates: "in band" and "kept by the filter".  The walk deletes the dropped samples' bits on the
+// fly, so nothing in here needs an order-preserving compaction.
+//
+// Why this is allowed to be simpler than numpy's arithmetic (k_prep_i16 in sk_prep.hip reproduces np.std's
+// summation order bit for bit and pays for it with a dozen dependent phases per read): the samples are
+// integers, so the only thing the state machine ever sees of top / bot is ceil(top) and floor(bot).
+//   * n, sum(x) and sum(x^2) are exact integers (v_dot2c_i32_i16 over the packed samples), so
+//     V = n sum(x^2) - sum(x)^2 is exact in int64 and std_true = sqrt(V) / n to a few ulp.
+//   * numpy's std differs from std_true by at most ~(n + 16) eps relative (mean: one rounding; each
+//     (x - mean)^2: three; a sum of n non-negative terms in ANY order: <= (n - 1) eps), so
+//     |top_numpy - top_here| <= delta := 8 eps (|spread| (n + 16) + |median| + |spread|)   (8x headroom).
+//   * if no integer lies within delta of top (resp. bot), ceil(top) (floor(bot)) is numpy's.  CERTIFIED.
+//     Otherwise (probability ~1e-10 per read) the read goes to a retry list and is redone by the
+//     numpy-order kernel (k_prep_i16 + k_segment_walk over the listed reads only).
+// One wavefront owns one read from its first load to its last store: the whole read (<= 4096 samples) sits in
+// 32 VGPRs as packed int16 pairs, all loads are issued up front, no workgroup barrier anywhere, 32 reads in
+// flight per CU.  LDS: one value histogram per wave (median by rank select from registers, as k_prepw_medmad).
+// Algorithmic HBM traffic per read: 2 M in, M / 4 out (two bit masks), 48 B of statistics.
+#include "sk_common.h"
+#include <math.h>
+#include <stdlib.h>
+
+namespace {
+
+constexpr int WPB = 4;                 // wavefronts (= reads in flight) per workgroup
+constexpr int MAXBINS = 2047;          // y = x - lo must keep (y << 2) inside 16 bits, and sum(y^2) inside 32
+
+typedef short          s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_clamp_i16(unsigned q, unsigned lo2, unsigned hi2)
+{
+    const s16x2 x = __builtin_bit_cast(s16x2, q);
+    const s16x2 c = __builtin_elementwise_min(__builtin_elementwise_max(x, __builtin_bit_cast(s16x2, lo2)),
+                                              __builtin_bit_cast(s16x2, hi2));
+    return __builtin_bit_cast(unsigned, c);
+}
+// (inline asm: given the generic vector operations the compiler turns these short packed sequences into
+// SDWA compares + selects + a permute, two to three times the instructions)
+__device__ __forceinline__ unsigned pk_sub_u16(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_subsat_u16(unsigned a, unsigned b)      // max(a - b, 0) per half
+{
+    unsigned r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_shl2_u16(unsigned a)                     // both halves << 2
+{
+    unsigned r;
+    asm("v_pk_lshlrev_b16 %0, 2, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ unsigned udot2(unsigned a, unsigned b, unsigned c)   // a.lo b.lo + a.hi b.hi + c
+{
+    unsigned r;
+    asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// inclusive scan across the wavefront on the vector ALU (see sk_prep.hip)
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_incl_scan(v), 63); }
+
+// lane i <- lane i + N inside a row of 16 (lanes without a source get 0)
+template <int N>
+__device__ __forceinline__ unsigned dpp_shl(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xF, 0xF, true);
+}
+
+struct SegStatArgs {
+    const int16_t *sig;
+    int64_t        stride;
+    const int32_t *len;
+    int            nreads;
+    int            lo, hi;           // outlier limits (strict)
+    double         std_scale;
+    double         delta_scale;      // 1.0; tests raise it to push reads onto the retry list
+    sk_prep       *prep;
+    uint4         *mask2;            // [nreads][row16] of {in band lo, hi, kept lo, hi}: 64 raw samples per entry
+    int            row16;            // entries per read (8 per 512-sample tile)
+    int32_t       *retry;            // [0] = count, [1 ..] = reads that could not be certified
+};
+
+// NT: 512-sample tiles held in registers (reads of up to 512 NT samples)
+// NQ: 16-byte histogram chunks per lane -- 256 NQ bins per wave: bin 0 = dropped samples, bin b = value lo + b
+// OCC: wavefronts per SIMD the register allocation is sized for
+template <int NT, int NQ, int OCC = 8>
+__global__ __launch_bounds__(64 * WPB, OCC)
+void k_seg_stats(const SegStatArgs a)
+{
+    constexpr int HBINS = 64 * 4 * NQ;
+    __shared__ __align__(16) unsigned hist_all[WPB][HBINS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned *hist = hist_all[w];
+    const int hb0 = lane * 4 * NQ;                         // first bin this lane owns
+
+    const int nbins = a.hi - a.lo - 1;                     // 1 .. min(HBINS - 1, MAXBINS) (host)
+    const int lo1 = max(a.lo + 1, -32768), hi1 = min(a.hi - 1, 32767);
+    const unsigned lo1p = (unsigned)(lo1 & 0xffff) * 0x10001u, hi1p = (unsigned)(hi1 & 0xffff) * 0x10001u;
+    const unsigned lop = (unsigned)(a.lo & 0xffff) * 0x10001u;         // y = x - lo  (1 .. nbins for kept samples)
+    const int maxM = (int)min(a.stride, (int64_t)(512 * NT));
+
+#pragma unroll
+    for (int j = 0; j < NQ; j++) *(uint4 *)(hist + hb0 + 4 * j) = make_uint4(0u, 0u, 0u, 0u);
+
+    const int nwaves = gridDim.x * WPB;
+    for (int r = blockIdx.x * WPB + w; r < a.nreads; r += nwaves) {
+        const int M = min(max(a.len[r], 0), maxM);
+        const int16_t *row = a.sig + (int64_t)r * a.stride;
+
+        // ---- the whole read into registers: NT x 16-byte loads per lane, all in flight at once ----------
+        unsigned y[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            if (t * 512 + lane * 8 < M) q = *(const uint4 *)(row + t * 512 + lane * 8);   // (rows are 16-byte aligned)
+            y[t][0] = q.x; y[t][1] = q.y; y[t][2] = q.z; y[t][3] = q.w;
+        }
+
+        // ---- pass 1 (registers): filter, y = x - lo (0 for dropped), exact sums, histogram ---------------
+        int sy = 0, syy = 0;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if (t * 512 >= M) continue;                    // (wave-uniform) nothing of the read in this tile
+            const int i0 = t * 512 + lane * 8;
+            const int nvalid = min(max(M - i0, 0), 8);     // samples of this lane's eight that exist
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned q = y[t][k];
+                const unsigned d = pk_clamp_i16(q, lo1p, hi1p) ^ q;          // non-zero half: outside (lo, hi)
+                unsigned km = pk_sub_u16(pk_min_u16(d, 0x10001u), 0x10001u); // 0xffff per kept half
+                if (t * 512 + 512 > M) {                                     // (wave-uniform: the read's last tile)
+                    const unsigned tail = nvalid >= 2 * k + 2 ? 0xffffffffu : (nvalid == 2 * k + 1 ? 0xffffu : 0u);
+                    km &= tail;
+                }
+                const unsigned yy = pk_sub_u16(q, lop) & km;
+                y[t][k] = yy;
+                const s16x2 ys = __builtin_bit_cast(s16x2, yy);
+                sy = __builtin_amdgcn_sdot2(ys, __builtin_bit_cast(s16x2, 0x10001u), sy, false);
+                syy = __builtin_amdgcn_sdot2(ys, ys, syy, false);
+                const unsigned y4 = pk_shl2_u16(yy);                         // byte offsets of the two bins
+                atomicAdd((unsigned *)((char *)hist + (y4 & 0xffffu)), 1u);
+                atomicAdd((unsigned *)((char *)hist + (y4 >> 16)), 1u);
+            }
+        }
+
+        // ---- exact integer totals -------------------------------------------------------------------------
+        const long long S = (long long)wave_sum(sy);                         // <= 4096 * 2047
+        const long long Q = (long long)wave_sum(syy & 0xffff) + ((long long)wave_sum((int)((unsigned)syy >> 16)) << 16);
+
+        // ---- median: rank select on the histogram, from registers (lane l owns bins [hb0, hb0 + 4 NQ)) -------
+        unsigned cnt[4 * NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; j++) {
+            const uint4 q = *(const uint4 *)(hist + hb0 + 4 * j);
+            cnt[4 * j] = q.x; cnt[4 * j + 1] = q.y; cnt[4 * j + 2] = q.z; cnt[4 * j + 3] = q.w;
+            *(uint4 *)(hist + hb0 + 4 * j) = make_uint4(0u, 0u, 0u, 0u);    // (my reads are done: LDS ops of a wave are in order)
+        }
+        if (lane == 0) cnt[0] = 0u;                                          // bin 0 collected the dropped samples
+        int local = 0;
+#pragma unroll
+        for (int i = 0; i < 4 * NQ; i++) local += (int)cnt[i];
+        const int inc = wave_incl_scan(local);
+        const int n = __builtin_amdgcn_readlane(inc, 63);                    // samples that survived the filter
+
+        sk_prep pr;
+        pr.n = n; pr.flags = 0; pr.center = 0.0; pr.scale = 1.0; pr.top = 0.0; pr.bot = 0.0;
+        int firsty = 1, width = 0;                                           // in band: (unsigned)(y - firsty) < width
+        bool certified = true;
+        if (n == 0) {
+            pr.flags = SK_FLAG_EMPTY;
+            const double qnan = __builtin_nan("");
+            pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
+        } else {
+            const int k1 = (n - 1) / 2, k2 = n / 2;
+            const int pre = inc - local;
+            int i1 = hb0, i2 = hb0, acc = pre;
+#pragma unroll
+            for (int i = 0; i < 4 * NQ; i++) {
+                acc += (int)cnt[i];
+                i1 += (acc <= k1) ? 1 : 0;
+                i2 += (acc <= k2) ? 1 : 0;
+            }
+            const unsigned long long own1 = __ballot(local > 0 && k1 >= pre && k1 < pre + local);
+            const unsigned long long own2 = __ballot(local > 0 && k2 >= pre && k2 < pre + local);
+            const int b1 = __builtin_amdgcn_readlane(i1, own1 ? (int)__builtin_ctzll(own1) : 0);
+            const int b2 = __builtin_amdgcn_readlane(i2, own2 ? (int)__builtin_ctzll(own2) : 0);
+            const double median = (double)(b1 + b2 + 2 * a.lo) * 0.5;        // exact (half-integer)
+
+            // ---- thresholds from exact integers; certify ceil(top) / floor(bot) against numpy's rounding -------
+            const long long V = (long long)n * Q - S * S;                    // n^2 var, exact (< 2^46)
+            const double sd = sqrt((double)V) / (double)n;
+            const double spread = sd * a.std_scale;                          // segmenter.py:413-414
+            const double top = median + spread, bot = median - spread;
+            const double eps8 = 8.0 * 1.1102230246251565e-16;
+            const double delta = a.delta_scale * eps8 * (fabs(spread) * (double)(n + 17) + fabs(median));
+            const double ct = ceil(top), fb = floor(bot);
+            certified = (V == 0) || (ceil(top - delta) == ct && ceil(top + delta) == ct &&
+                                     floor(bot - delta) == fb && floor(bot + delta) == fb);
+            pr.center = median; pr.scale = sd; pr.top = top; pr.bot = bot;
+            // integer band (clamped around the histogram range, so everything below stays in 16 bits)
+            const double ctc = fmin(fmax(ct, (double)a.lo - 4.0), (double)a.hi + 4.0);
+            const double fbc = fmin(fmax(fb, (double)a.lo - 4.0), (double)a.hi + 4.0);
+            const int ylo = max((int)fbc + 1 - a.lo, 1);                     // first in-band y
+            const int yhi = min((int)ctc - 1 - a.lo, nbins);                 // last in-band y
+            firsty = ylo;
+            width = max(yhi - ylo + 1, 0);
+        }
+        if (lane == 0) {
+            a.prep[r] = pr;
+            if (!certified) a.retry[1 + atomicAdd(&a.retry[0], 1)] = r;
+        }
+
+        // ---- pass 2 (registers): one "kept" and one "in band" bit per raw sample ------------------------------
+        // Each lane has 8 consecutive samples of a tile -> one byte of each mask; v_dot2_u32_u16 with the bit
+        // weights {1 << 2k, 1 << (2k + 1)} builds the bytes; three DPP steps gather the 8 bytes of lanes
+        // 8j .. 8j+7 into lane 8j, which stores 16 bytes {in band, kept} -- 128 contiguous bytes per tile.
+        const unsigned fp = (unsigned)(firsty & 0xffff) * 0x10001u;
+        const unsigned wm1 = (unsigned)((width - 1) & 0xffff) * 0x10001u;
+        uint4 *mrow = a.mask2 + (int64_t)r * a.row16;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if (t * 512 >= M) continue;                    // (tiles past the read hold nothing)
+            unsigned keep8 = 0, out8 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned wts = (1u << (2 * k)) | (2u << (2 * k + 16));
+                keep8 = udot2(pk_min_u16(y[t][k], 0x10001u), wts, keep8);                    // kept <=> y >= 1
+                const unsigned over = pk_subsat_u16(pk_sub_u16(y[t][k], fp), wm1);           // > 0: outside the band
+                out8 = udot2(pk_min_u16(over, 0x10001u), wts, out8);
+            }
+            unsigned in8 = (width > 0) ? (~out8 & keep8) : 0u;
+            unsigned h_in = in8 | (dpp_shl<1>(in8) << 8);         // 16 bits in even lanes
+            unsigned h_kp = keep8 | (dpp_shl<1>(keep8) << 8);
+            h_in |= dpp_shl<2>(h_in) << 16;                       // 32 bits in lanes = 0 mod 4
+            h_kp |= dpp_shl<2>(h_kp) << 16;
+            const unsigned in_hi = dpp_shl<4>(h_in), kp_hi = dpp_shl<4>(h_kp);   // the next four lanes' 32 bits
+            if ((lane & 7) == 0) mrow[t * 8 + (lane >> 3)] = make_uint4(h_in, in_hi, h_kp, kp_hi);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// the walk over {in band, kept} pairs: get_segs' state machine (segmenter.py:420-464), one lane per read
+// ------------------------------------------------------------------------------------------------------
+struct WalkParams {
+    int error, corrector, window, seg_dist, first_len;   // first_len = ceil(window * stall_len)
+};
+struct WalkState {
+    int prev, err, prev_err, c, w, start, nseg, last_end;
+};
+
+__device__ __forceinline__ void report_segment(WalkState &st, int start, int end, const WalkParams &p,
+                                               int32_t *my, int max_segs)
+{
+    if (st.nseg > 0 && start - st.last_end < p.seg_dist) {                         // :451 merge
+        if (st.nseg <= max_segs) my[2 * (st.nseg - 1) + 1] = end;
+    } else {
+        if (st.nseg < max_segs) { my[2 * st.nseg] = start; my[2 * st.nseg + 1] = end; }
+        st.nseg++;
+    }
+    st.last_end = end;
+}
+
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned mul24(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// 32 samples, all valid, corrector test dead (error < corrector): the straight-line step of sk_segment.hip
+__device__ __forceinline__ void walk_fast32(WalkState &st, unsigned bits, int i0, const WalkParams &p,
+                                            int thr_first, int32_t *my, int max_segs)
+{
+    unsigned prev = (unsigned)st.prev, err = (unsigned)st.err, perr = (unsigned)st.prev_err, c = (unsigned)st.c;
+    unsigned thr = (st.nseg == 0) ? (unsigned)thr_first : (unsigned)p.window;
+#pragma unroll 16
+    for (int b = 0; b < 32; b++) {
+        const unsigned inb = (bits >> b) & 1u;                                     // :431 in band
+        const unsigned ltm = (unsigned)(((int)err - p.error) >> 31);               // all ones: err < error
+        const unsigned tol = prev & ~inb & ltm;                                    // :442 tolerated
+        const unsigned closing = prev & ~inb & ~ltm;                               // :448 / :458
+        const unsigned act = inb | tol;
+        if (mul24(closing, c) >= thr) {                                            // thr >= 1
+            report_segment(st, i0 + b - (int)c, i0 + b - (int)perr, p, my, max_segs);   // :449
+            thr = (unsigned)p.window;
+        }
+        c = mad24(c, act, act);
+        err = mad24(err, act, tol);
+        perr = mad24(perr, tol, tol);
+        prev = act;
+    }
+    st.prev = (int)prev; st.err = (int)err; st.prev_err = (int)perr; st.c = (int)c;
+}
+
+// general step: any parameters, samples at index >= n ignored; keeps `start` and `w`
+__device__ __forceinline__ void walk_general32(WalkState &st, unsigned bits, int i0, int n, const WalkParams &p,
+                                               int32_t *my, int max_segs)
+{
+    int prev = st.prev, err = st.err, prev_err = st.prev_err, c = st.c, w = st.w, start = st.start;
+#pragma unroll 4
+    for (int b = 0; b < 32; b++) {
+        const int i = i0 + b;
+        const int valid = i < n;
+        const int inb = (int)((bits >> b) & 1u) & valid;                           // :431 in band
+        const int tol = (inb ^ 1) & prev & (int)(err < p.error) & valid;           // :442 tolerated
+        const int act = inb | tol;
+        const int closing = prev & (act ^ 1) & valid;                              // :448 / :458
+        if (closing && (c >= p.window || (st.nseg == 0 && c >= p.first_len)))
+            report_segment(st, start, i - prev_err, p, my, max_segs);              // :449
+        start = (inb & (prev ^ 1)) ? i : start;
+        c = act ? c + 1 : (valid ? 0 : c);
+        w += inb;
+        err = tol ? err + 1 : (act ? err : (valid ? 0 : err));
+        prev_err = tol ? prev_err + 1 : (valid ? 0 : prev_err);
+        prev = valid ? act : prev;
+        if (act && c >= p.window && c >= w) {                                      // :439 / :446
+            if ((c % w) == 0) err--;
+        }
+    }
+    st.prev = prev; st.err = err; st.prev_err = prev_err; st.c = c; st.w = w; st.start = start;
+}
+
+// FAST: error < corrector (the corrector test can never fire, see sk_segment.hip) and positive thresholds.
+// Each lane streams its read's entries; the kept bits of an entry are squeezed together (the filter drops a
+// handful of samples per read, so the squeeze loop runs a few times per READ) and appended to a bit queue;
+// whenever the queue holds 64 bits they go through the state machine.
+template <bool FAST>
+__global__ __launch_bounds__(64)
+void k_seg_walk2(const uint4 *__restrict__ mask2, int row16, const int32_t *__restrict__ len, int64_t stride,
+                 int nreads, WalkParams p, int32_t *__restrict__ segs, int32_t *__restrict__ nsegs, int max_segs)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r < nreads;
+    const int M = live ? min(max(len[r], 0), (int)min(stride, (int64_t)row16 * 64)) : 0;
+    const uint4 *mrow = mask2 + (int64_t)(live ? r : 0) * row16;
+    int32_t *my = segs + (int64_t)(live ? r : 0) * 2 * max_segs;
+
+    WalkState st;
+    st.prev = 0; st.err = 0; st.prev_err = 0; st.c = 0;
+    st.w = FAST ? 0x7fffffff : p.corrector;       // segmenter.py:424 -- never reset inside a read
+    st.start = 0; st.nseg = 0; st.last_end = 0;
+    const int thr_first = min(p.window, p.first_len);
+
+    const int nent = (M + 63) >> 6;               // my entries
+    int nmax = nent;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+
+    unsigned long long qlo = 0ull, qhi = 0ull;    // bit queue: `fill` bits, oldest at bit 0 of qlo
+    int fill = 0, done = 0;                       // done: filtered samples already through the state machine
+    uint4 next = (nent > 0) ? mrow[0] : make_uint4(0u, 0u, 0u, 0u);
+    for (int e = 0; e < nmax; e++) {
+        const uint4 cur = next;
+        if (e + 1 < nent) next = mrow[e + 1];     // prefetch
+        if (e < nent) {
+            unsigned long long inb = ((unsigned long long)cur.y << 32) | cur.x;
+            unsigned long long kp = ((unsigned long long)cur.w << 32) | cur.z;
+            int cnt = 64;
+            if (kp == 0ull) { cnt = 0; kp = ~0ull; }
+            const int hz = __builtin_clzll(kp);   // dropped samples at the top of the entry (the read's tail) go at once
+            if (hz > 0) { cnt -= hz; kp |= ~0ull << (64 - hz); }
+            while (kp != ~0ull) {                 // delete the lowest dropped sample's bit, close the gap
+                const int pos = __builtin_ctzll(~kp);
+                const unsigned long long below = (1ull << pos) - 1ull;
+                inb = (inb & below) | ((inb >> 1) & ~below);
+                kp = (kp & below) | ((kp >> 1) & ~below) | (1ull << 63);
+                cnt--;
+            }
+            // (the `cnt` surviving bits are now bits 0 .. cnt-1 of inb; bits above are garbage -> masked)
+            if (cnt < 64) inb &= (1ull << cnt) - 1ull;
+            qlo |= (fill < 64) ? inb << fill : 0ull;
+            qhi |= (fill > 0) ? inb >> (64 - fill) : 0ull;
+            fill += cnt;
+        }
+        if (fill >= 64) {
+            if (FAST) {
+                walk_fast32(st, (unsigned)qlo, done, p, thr_first, my, max_segs);
+                walk_fast32(st, (unsigned)(qlo >> 32), done + 32, p, thr_first, my, max_segs);
+            } else {
+                walk_general32(st, (unsigned)qlo, done, 0x7fffffff, p, my, max_segs);
+                walk_general32(st, (unsigned)(qlo >> 32), done + 32, 0x7fffffff, p, my, max_segs);
+            }
+            done += 64; fill -= 64;
+            qlo = qhi; qhi = 0ull;
+        }
+    }
+    // the last fill (< 64) bits
+    if (FAST) st.start = done - st.c;             // hand over to the general step (which tracks `start`)
+    if (fill > 0) {
+        const int n = done + fill;
+        walk_general32(st, (unsigned)qlo, done, n, p, my, max_segs);
+        walk_general32(st, (unsigned)(qlo >> 32), done + 32, n, p, my, max_segs);
+    }
+    if (live) nsegs[r] = st.nseg;                 // a segment still open at EOF is dropped (:466)
+}
+
+typedef void (*segstat_fn)(const SegStatArgs);
+
+segstat_fn pick_stats(int NT, int nbins)
+{
+    const bool small = nbins <= 1023;          // 4 KB of histogram per wave: 8 workgroups per CU
+    if (NT <= 2) return small ? k_seg_stats<2, 4> : k_seg_stats<2, 8>;
+    if (NT <= 4) return small ? k_seg_stats<4, 4> : k_seg_stats<4, 8>;
+    if (small) {
+        if (const char *e = getenv("SK_SEG_OCC")) {         // tuning: registers per lane vs reads in flight
+            const int v = atoi(e);
+            if (v == 6) return k_seg_stats<8, 4, 6>;
+            if (v == 5) return k_seg_stats<8, 4, 5>;
+            if (v == 4) return k_seg_stats<8, 4, 4>;
+        }
+        return k_seg_stats<8, 4, 8>;
+    }
+    return k_seg_stats<8, 8>;
+}
+
+} // namespace
+
+// 16-byte entries per read in the {in band, kept} mask: 8 per 512-sample tile the statistics kernel holds
+int sk_segment_fast_row16(int64_t stride)
+{
+    const int NT = (int)((stride + 511) / 512);
+    return 8 * (NT <= 2 ? 2 : NT <= 4 ? 4 : 8);
+}
+
+// Is (stride, limits, std_scale) inside the streaming path's range?  (else: k_prep_i16 + k_segment_walk)
+bool sk_segment_fast_applies(const void *d_sig, int64_t stride, int32_t lo, int32_t hi, double std_scale)
+{
+    if (getenv("SK_SEG_OLD")) return false;                 // A/B switch: the numpy-order kernels for everything
+    const int64_t nbins = (int64_t)hi - lo - 1;
+    if (nbins < 1 || nbins > MAXBINS) return false;
+    if (stride > 4096 || (stride % 8) != 0 || ((uintptr_t)d_sig & 15) != 0) return false;
+    if (!(std_scale == std_scale) || fabs(std_scale) > 1e6) return false;
+    return true;
+}
+
+// Streaming statistics, the numpy-order redo of the (almost always empty) list of uncertified reads, then the walk.
+// d_retry: nreads + 1 ints ([0] = count, zeroed here).  Records ev[0..3] like the other segment paths.
+int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                           const sk_seg_params *p, int32_t lo, int32_t hi, sk_prep *d_prep, void *d_mask2,
+                           int32_t *d_retry, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs)
+{
+    const int NT = (int)((stride + 511) / 512);
+    segstat_fn fn = pick_stats(NT, hi - lo - 1);
+    SegStatArgs a;
+    a.sig = d_sig; a.stride = stride; a.len = d_len; a.nreads = nreads; a.lo = lo; a.hi = hi;
+    a.std_scale = p->std_scale; a.delta_scale = 1.0;
+    if (const char *e = getenv("SK_SEG_DELTA_SCALE")) { const double v = atof(e); if (v > 0) a.delta_scale = v; }
+    a.prep = d_prep; a.mask2 = (uint4 *)d_mask2; a.row16 = sk_segment_fast_row16(stride); a.retry = d_retry;
+
+    SK_HIP(hipMemsetAsync(d_retry, 0, sizeof(int32_t), c->stream));
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    int per_cu = 8, rounds = 4;
+    if (const char *e = getenv("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
+    if (const char *e = getenv("SK_PREP_PERCU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }
+    const long long g = (long long)c->num_cu * per_cu * rounds;
+    const long long need = ((long long)nreads + WPB - 1) / WPB;
+    const int grid = (int)(g > need ? need : g);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * WPB), 0, c->stream, a);
+    SK_HIP(hipGetLastError());
+    // reads whose ceil(top) / floor(bot) could not be certified: numpy-order statistics, masks rewritten in place
+    int rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nreads, lo, hi, SK_PREP_SEGMENT, p->std_scale, nullptr, d_prep,
+                                nullptr, 0, 0, 0x7fffffff, d_retry + 1, d_retry, d_mask2, a.row16);
+    if (rc) return rc;
+    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+
+    WalkParams wp;
+    wp.error = p->error; wp.corrector = p->corrector; wp.window = p->window; wp.seg_dist = p->seg_dist;
+    const double fl = (double)p->window * p->stall_len;            // segmenter.py:448
+    if (!(fl == fl))           wp.first_len = 0x7fffffff;          // NaN: never true
+    else if (fl > 2147483000.) wp.first_len = 0x7fffffff;
+    else if (fl < -2147483000.) wp.first_len = -0x7fffffff;
+    else                       wp.first_len = (int)ceil(fl);
+    const bool fast = wp.error < wp.corrector && wp.window >= 1 && wp.first_len >= 1 &&
+                      getenv("SK_WALK_GENERAL") == nullptr;
+    const int wgrid = (nreads + 63) / 64;
+    SK_HIP(hipEventRecord(c->ev[2], c->stream));
+    if (fast)
+        hipLaunchKernelGGL(k_seg_walk2<true>, dim3(wgrid), dim3(64), 0, c->stream, (const uint4 *)d_mask2, a.row16,
+                           d_len, stride, nreads, wp, d_segs, d_nsegs, max_segs);
+    else
+        hipLaunchKernelGGL(k_seg_walk2<false>, dim3(wgrid), dim3(64), 0, c->stream, (const uint4 *)d_mask2, a.row16,
+                           d_len, stride, nreads, wp, d_segs, d_nsegs, max_segs);
+    SK_HIP(hipGetLastError());
+    SK_HIP(hipEventRecord(c->ev[3], c->stream));
+    return SK_OK;
+}

@@ -127,3 +127,73 @@ def test_invalid_params_are_loud(gpu):
     from squigglekit_amd._lib import SquiggleKitError
     with pytest.raises(SquiggleKitError):
         api.segment_batch(np.full((1, 64), 500, dtype=np.int16), None, _params(dict(corrector=-1)))
+
+
+def _check_vs_oracle(api, ora, sig, lens, kw, label, max_segs=24):
+    p = _params(kw)
+    segs, nsegs = api.segment_batch(sig, lens, p, max_segs=max_segs)
+    okw = {k: v for k, v in kw.items() if k not in ("lim_low", "lim_hi")}
+    osegs, onsegs = ora.segment_batch_i16(sig, lens, ora.SegParams(**okw), lo=p.lim_low, hi=p.lim_hi,
+                                          max_segs=segs.shape[1])
+    assert np.array_equal(nsegs, onsegs), (label, kw, np.nonzero(nsegs != onsegs)[0][:5])
+    keep = np.arange(segs.shape[1])[None, :] < nsegs[:, None]
+    assert np.array_equal(segs[keep], osegs[keep]), (label, kw)
+    assert not segs[~keep].any(), "slots past nsegs must read as zero"
+    return nsegs
+
+
+def _streaming_cases(rng):
+    """Reads of up to 4 096 samples (the streaming statistics path, sk_segstat.hip) with everything that path
+    treats specially: ragged tails, outliers anywhere (also runs of them, and most of a read), reads that are
+    empty after the filter, constant reads, reads shorter than one mask entry."""
+    from squigglekit_amd import synth
+    sig = synth.squiggle_batch(320, 4096, 424299)
+    lens = rng.integers(1, 4097, size=320).astype(np.int32)
+    lens[:12] = [1, 2, 7, 8, 9, 63, 64, 65, 511, 512, 513, 4096]
+    lens[64:192] = 4096
+    sig[12, :] = 0                                   # empty after the filter
+    sig[13, :] = 901
+    sig[14, :] = 500                                 # std == 0: empty band
+    sig[15, :2000] = 500; sig[15, 2000:] = 501       # V > 0, tiny std
+    for r in range(16, 48):                          # many outliers: single, runs, and a read that is mostly outliers
+        k = int(rng.integers(1, 3000))
+        pos = rng.integers(0, 4096, size=k)
+        sig[r, pos] = rng.choice(np.array([-5, 0, 900, 950, 1100, 32767, -32768], dtype=np.int16), size=k)
+    sig[48, 100:900] = 0
+    sig[49, :4000] = 1000                            # only the tail survives
+    sig[50, 64:] = 0                                 # only the first entry survives
+    sig[51, ::2] = 0                                 # every other sample dropped
+    return sig, lens
+
+
+STREAM_PARAMS = [dict(), dict(error=10, corrector=0), dict(error=12, corrector=3, window=30),
+                 dict(window=10, seg_dist=0, stall_len=0.0), dict(std_scale=3.0), dict(std_scale=-0.5),
+                 dict(error=0), dict(window=1, error=0, seg_dist=1000), dict(lim_low=400, lim_hi=600),
+                 dict(lim_low=-10, lim_hi=1500), dict(lim_low=499, lim_hi=502), dict(lim_low=-32769, lim_hi=-30722),
+                 dict(std_scale=1e-9), dict(std_scale=40.0), dict(stall_len=1.5), dict(lim_low=0, lim_hi=2048)]
+
+
+def test_streaming_statistics_path_vs_oracle(gpu, ora):
+    from squigglekit_amd import api
+    sig, lens = _streaming_cases(np.random.default_rng(20260928))
+    total = 0
+    for kw in STREAM_PARAMS:
+        total += int(_check_vs_oracle(api, ora, sig, lens, kw, "streaming").sum())
+    assert total > 2000                              # the cases do produce segments
+    # narrower rows use the 2- and 4-tile instantiations
+    for width in (8, 1000, 1024, 1032, 2048, 2056):
+        _check_vs_oracle(api, ora, np.ascontiguousarray(sig[:, :width]), np.minimum(lens, width), dict(),
+                         "width %d" % width)
+
+
+def test_streaming_path_retry_list_and_old_kernels_agree(gpu, ora, monkeypatch):
+    """SK_SEG_DELTA_SCALE widens the certification margin until (nearly) every read fails it, so the numpy-order
+    redo of listed reads is what produces the masks; SK_SEG_OLD runs the numpy-order kernels for everything.
+    All three must give the oracle's segments."""
+    from squigglekit_amd import api
+    sig, lens = _streaming_cases(np.random.default_rng(7))
+    for env, val in (("SK_SEG_DELTA_SCALE", "1e13"), ("SK_SEG_DELTA_SCALE", "3e10"), ("SK_SEG_OLD", "1")):
+        monkeypatch.setenv(env, val)
+        for kw in STREAM_PARAMS[:9]:
+            _check_vs_oracle(api, ora, sig, lens, kw, "%s=%s" % (env, val))
+        monkeypatch.delenv(env)
