@@ -527,6 +527,8 @@ def rank_body(a, comm, rank, world, shape):
 
 def main(argv=None):
     a = parse(argv)
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"        # no RCCL version banner on stdout: the JSON line stands alone
     from squigglekit_amd import _lib, multigpu
     _lib.load()
     shape, rank, local, world = multigpu.plan(a.gpus)
@@ -544,7 +546,14 @@ def main(argv=None):
         _lib.init(0)
         line = rank_body(a, None, 0, 1, shape)
     if line is not None:
-        print(json.dumps(line))
+        # the JSON line is the last thing on stdout: RCCL prints a version banner through C stdio, which would
+        # otherwise be flushed at exit, after Python's own buffer
+        sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

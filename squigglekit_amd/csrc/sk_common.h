@@ -55,7 +55,11 @@ struct sk_ctx {
     std::vector<double> motif64_host;
     sk_buf lastq;     // screening pass: last-row costs per column
     sk_buf qflag;     // screening pass: per-read "left the fixed-point range" flags
-    sk_buf retry;     // DTW pass-B retry counter + read list
+    sk_buf retry;     // DTW retry list: [0] = count, [1] = pad, [2 ..] = reads (segmenter: [0] = count, [1 ..] = reads)
+    sk_buf dtwcnt;    // [0] = reads retried by the exact pass, summed over the launches of one API call (device)
+    bool   retry_dev = false;   // the last DTW call left its retry count on the device (read lazily)
+    std::vector<unsigned> motifq_host;
+    bool   motifq_valid = false;
     int    last_retry = 0;   // reads that needed the exact single-pass retry in the last DTW call
     std::vector<hipEvent_t> evpool;   // per-launch events of the two-pass DTW (3 per chunk)
     int    prof_chunks = 0;  // chunks of the last two-pass DTW call (0: single pass)
@@ -122,6 +126,7 @@ struct sk_sdtw_args {
     double       *last_row;    // device, optional: cost[-1,:] of read 0 (single-pair call)
     int64_t       max_len;     // upper bound of any read's filtered length (chooses 1 vs 2 passes)
     int           force_single;// 1: always the single FULL pass
+    int           accumulate = 0;  // 1: a further launch set of the same API call (keep the retry total)
 };
 int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a);
 // fixed-point screening + certified window over all reads (sk_sdtwq.hip); leaves the retry list on the device

@@ -120,7 +120,7 @@ int sk_shutdown(void)
         (void)hipStreamSynchronize(c->stream);
         sk_buf *bufs[] = {&c->sig, &c->len, &c->off, &c->comp, &c->prep, &c->mask,
                           &c->motif, &c->out, &c->out2, &c->misc, &c->ckpt, &c->retry, &c->motifq, &c->lastq, &c->qflag,
-                          &c->motif64, &c->commbuf};
+                          &c->motif64, &c->commbuf, &c->dtwcnt};
         for (sk_buf *b : bufs) free_buf(b);
         for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev[i]);
         for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
@@ -233,6 +233,13 @@ int sk_last_dtw_retries(void)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    if (c->retry_dev && c->dtwcnt.p) {              // the count stayed on the device: fetch it now
+        int32_t n = 0;
+        if (hipMemcpyAsync(&n, c->dtwcnt.p, sizeof n, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+            return sk_fail(SK_ERR_HIP, "reading the retry count failed");
+        c->last_retry = n;
+    }
     return c->last_retry;
 }
 

@@ -59,9 +59,16 @@ void k_sdtw(const sdtw_kargs a)
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int g = lane / L, l = lane % L;
     int slot = wave * G + g;
-    const bool live = slot < a.nreads;
-    if (!live) slot = a.nreads - 1;
-    const int r = a.ridx ? a.ridx[slot] : a.read0 + slot;
+    int nreads = a.nreads;
+    if (a.count_ptr) {                              // retry pass: the list length is only known on the device
+        const int cnt = *a.count_ptr;
+        if (a.total_ptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.total_ptr, cnt);
+        nreads = min(cnt - a.list_off, a.nreads);
+        if (nreads <= 0) return;                    // (block-uniform) nothing listed for this launch
+    }
+    const bool live = slot < nreads;
+    if (!live) slot = nreads - 1;
+    const int r = a.ridx ? a.ridx[a.list_off + slot] : a.read0 + slot;
 
     // ---- per-read parameters -------------------------------------------------
     int n, flags = 0;
@@ -364,6 +371,7 @@ static int launch_chained(sk_ctx *c, const sk_sdtw_args *a)
         c->motif_src.assign(a->motif, a->motif + N);
         c->motif_L = -1;                            // (chunked layout: never equal to a plain one)
         c->motif64_valid = false;
+        c->motifq_valid = false;
     }
     // row buffers: two (ping-pong) of [batch][row_stride] doubles + ints
     const int64_t row_stride = (a->max_len > 0 ? a->max_len : 1);
@@ -381,6 +389,7 @@ static int launch_chained(sk_ctx *c, const sk_sdtw_args *a)
     k.samples = a->samples; k.stride = a->stride; k.off = a->off; k.prep = a->prep;
     k.out = a->out; k.last_row = nullptr; k.row_stride = row_stride;
     c->last_retry = 0;
+    c->retry_dev = false;
     c->prof_chunks = 0;
     SK_HIP(hipEventRecord(c->ev[2], c->stream));
     for (int64_t r0 = 0; r0 < a->nreads; r0 += batch) {
@@ -440,6 +449,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
         c->motif_src.assign(a->motif, a->motif + N);
         c->motif_L = L;
         c->motif64_valid = false;
+        c->motifq_valid = false;
     }
 
     sdtw_kargs k;
@@ -467,6 +477,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     SK_HIP(hipEventRecord(c->ev[2], c->stream));
     if (!two_pass) {
         c->last_retry = 0;
+        c->retry_dev = false;
         c->prof_chunks = 0;
         sdtw_fn fn = pick_any(a->feed, L, R, MODE_FULL);
         if (!fn) return sk_fail(SK_ERR_UNSUPPORTED, "no kernel for L=%d R=%d", L, R);
@@ -487,53 +498,62 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     bool qok = true;
     for (int i = 0; i < N; i++) qok = qok && (fabs(a->motif[i]) < QLIM);
     if (const char *e = getenv("SK_DTW_SCHEME")) qok = qok && strcmp(e, "exact2") != 0;
-    if (qok) {
-        int rc;
-        if ((rc = sk_reserve(c, &c->retry, ((size_t)a->nreads + 1) * sizeof(int32_t)))) return rc;
-        int32_t *cnt = (int32_t *)c->retry.p;
-        SK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), c->stream));
-        if ((rc = sk_launch_sdtw_screen(c, a, L, R, P, ck, span, cnt, cnt + 1))) return rc;
-        int32_t nretry = 0;
-        SK_HIP(hipMemcpyAsync(&nretry, cnt, sizeof nretry, hipMemcpyDeviceToHost, c->stream));
-        SK_HIP(hipStreamSynchronize(c->stream));
-        c->last_retry = nretry;
-        if (nretry > 0) {                                  // exact single pass on the uncertified reads
-            k.read0 = 0; k.nreads = nretry; k.ridx = cnt + 1;
-            // A handful of reads cannot fill the chip, so what counts is the latency of one sweep:
-            // spread each read over 64 lanes (R64 rows per lane instead of R) when the list is short.
-            const int R64 = (N + 63) / 64, P64 = 64 * R64 - N;
-            sdtw_fn f64 = (L == 16 && nretry <= 8192) ? pick_any(a->feed, 64, R64, MODE_FULL) : nullptr;
-            if (f64) {
-                if (!c->motif64_valid) {
-                    SK_HIP(hipStreamSynchronize(c->stream));      // an earlier launch may still read it
-                    c->motif64_host.assign((size_t)64 * R64, 0.0);
-                    int row = 0;
-                    for (int l = 0; l < 64; l++) {
-                        const int rows = (l < P64) ? R64 - 1 : R64;
-                        for (int kk = 0; kk < rows; kk++) c->motif64_host[(size_t)l * R64 + kk] = a->motif[row++];
-                    }
-                    if ((rc = sk_reserve(c, &c->motif64, c->motif64_host.size() * sizeof(double)))) return rc;
-                    SK_HIP(hipMemcpyAsync(c->motif64.p, c->motif64_host.data(),
-                                          c->motif64_host.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-                    c->motif64_valid = true;
+    // Reads the windowed pass cannot certify are appended to a device-side list and redone by the exact single
+    // pass.  The host never learns the count (no sync inside the call): the retry launches are sized for the
+    // worst case and return at once where the list ends.  A short list is latency-bound, so its first 8 192
+    // entries are swept with each read spread over 64 lanes; whatever lies beyond uses the batch layout.
+    int rc;
+    if ((rc = sk_reserve(c, &c->retry, ((size_t)a->nreads + 2) * sizeof(int32_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->dtwcnt, 64))) return rc;
+    int32_t *cnt = (int32_t *)c->retry.p;                  // [0] = counter, [2..] = read indices
+    SK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), c->stream));
+    if (!a->accumulate) SK_HIP(hipMemsetAsync(c->dtwcnt.p, 0, sizeof(int32_t), c->stream));
+    c->retry_dev = true;
+    auto launch_retry = [&]() -> int {
+        sdtw_kargs kr = k;
+        kr.read0 = 0; kr.ridx = cnt + 2; kr.count_ptr = cnt; kr.ckpt = nullptr;
+        kr.total_ptr = (int32_t *)c->dtwcnt.p; kr.list_off = 0;
+        const int R64 = (N + 63) / 64, P64 = 64 * R64 - N;
+        sdtw_fn f64 = (L == 16) ? pick_any(a->feed, 64, R64, MODE_FULL) : nullptr;
+        if (f64) {
+            if (!c->motif64_valid) {
+                SK_HIP(hipStreamSynchronize(c->stream));      // an earlier launch may still read it
+                c->motif64_host.assign((size_t)64 * R64, 0.0);
+                int row = 0;
+                for (int l = 0; l < 64; l++) {
+                    const int rows = (l < P64) ? R64 - 1 : R64;
+                    for (int kk = 0; kk < rows; kk++) c->motif64_host[(size_t)l * R64 + kk] = a->motif[row++];
                 }
-                k.xlay = (const double *)c->motif64.p; k.P = P64;
-                if ((rc = launch(c, f64, k, 64))) return rc;
-            } else if ((rc = launch(c, ff, k, L))) return rc;
+                int rc2;
+                if ((rc2 = sk_reserve(c, &c->motif64, c->motif64_host.size() * sizeof(double)))) return rc2;
+                SK_HIP(hipMemcpyAsync(c->motif64.p, c->motif64_host.data(),
+                                      c->motif64_host.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                c->motif64_valid = true;
+            }
+            sdtw_kargs k64 = kr;
+            k64.xlay = (const double *)c->motif64.p; k64.P = P64;
+            k64.nreads = a->nreads < 8192 ? a->nreads : 8192;
+            int rc2;
+            if ((rc2 = launch(c, f64, k64, 64))) return rc2;
+            if (a->nreads <= 8192) return SK_OK;
+            kr.list_off = 8192; kr.total_ptr = nullptr; kr.nreads = a->nreads - 8192;
+            return launch(c, ff, kr, L);
         }
+        kr.nreads = a->nreads;
+        return launch(c, ff, kr, L);
+    };
+    if (qok) {
+        if ((rc = sk_launch_sdtw_screen(c, a, L, R, P, ck, span, cnt, cnt + 2))) return rc;
+        if ((rc = launch_retry())) return rc;
         SK_HIP(hipEventRecord(c->ev[3], c->stream));
         return SK_OK;
     }
     const int nck = (int)((maxlen + L - 1) / ck);          // checkpoints at steps ck, 2ck, ... <= last step
     const size_t per_read = (size_t)(nck > 0 ? nck : 1) * L * (R + 3) * sizeof(double);
     const int64_t chunk = sk_dtw_chunk_reads(per_read, a->nreads);   // checkpoint scratch per chunk
-    int rc;
     if ((rc = sk_reserve(c, &c->ckpt, (size_t)chunk * per_read))) return rc;
-    if ((rc = sk_reserve(c, &c->retry, ((size_t)a->nreads + 1) * sizeof(int32_t)))) return rc;
-    int32_t *cnt = (int32_t *)c->retry.p;                  // [0] = counter, [1..] = read indices
-    SK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), c->stream));
     k.ckpt = (double *)c->ckpt.p; k.nck = nck; k.ck = ck; k.span = span;
-    k.retry = cnt + 1; k.retry_cnt = cnt;
+    k.retry = cnt + 2; k.retry_cnt = cnt;
     // per-launch HIP events (pool grows on demand) so a profile can name each pass's duration
     const size_t nchunks = (size_t)((a->nreads + chunk - 1) / chunk);
     while (c->evpool.size() < 3 * nchunks) {
@@ -555,14 +575,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
         c->prof_chunks++;
     }
     // reads whose path crossed the restart front: exact single pass on just those
-    int32_t nretry = 0;
-    SK_HIP(hipMemcpyAsync(&nretry, cnt, sizeof nretry, hipMemcpyDeviceToHost, c->stream));
-    SK_HIP(hipStreamSynchronize(c->stream));
-    c->last_retry = nretry;
-    if (nretry > 0) {
-        k.read0 = 0; k.nreads = nretry; k.ridx = cnt + 1; k.ckpt = nullptr;
-        if ((rc = launch(c, ff, k, L))) return rc;
-    }
+    if ((rc = launch_retry())) return rc;
     SK_HIP(hipEventRecord(c->ev[3], c->stream));
     return SK_OK;
 }

@@ -52,6 +52,9 @@ struct sdtw_kargs {
     int            nreads;      // reads (or entries of ridx) covered by this launch
     int            read0;       // first read of this launch (chunking); checkpoint slot = r - read0
     const int32_t *ridx;        // optional indirection: launch slot -> read (retry pass)
+    const int32_t *count_ptr;   // with ridx: the list length lives on the device (nreads = capacity of the launch)
+    int            list_off;    //            first list entry this launch covers
+    int32_t       *total_ptr;   //            optional: += list length (diagnostic, read by sk_last_dtw_retries)
     const double  *xlay;        // motif laid out per lane [L][R]
     int            P;           // number of short lanes
     sk_hit        *out;

@@ -485,18 +485,23 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P,
                           int32_t *d_retry_cnt, int32_t *d_retry)
 {
     const int N = a->nmotif;
-    // quantised motif in the same per-lane layout as the exact one
-    std::vector<unsigned> layq((size_t)L * R, 0x80000000u);
-    int row = 0;
-    for (int l = 0; l < L; l++) {
-        const int cnt = (l < P) ? R - 1 : R;
-        for (int k = 0; k < cnt; k++)
-            layq[(size_t)l * R + k] = (unsigned)((int)rint(a->motif[row++] * QSCALE)) + 0x80000000u;
-    }
+    // quantised motif in the same per-lane layout as the exact one; resident like the exact layout (the caller
+    // invalidates it when the motif or its layout changes), so a call makes no host-side synchronisation
     int rc;
-    if ((rc = sk_reserve(c, &c->motifq, layq.size() * sizeof(unsigned)))) return rc;
-    SK_HIP(hipMemcpyAsync(c->motifq.p, layq.data(), layq.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
-    SK_HIP(hipStreamSynchronize(c->stream));            // layq is a local
+    if (!c->motifq_valid) {
+        SK_HIP(hipStreamSynchronize(c->stream));        // an earlier launch may still read the old one
+        std::vector<unsigned> &layq = c->motifq_host;
+        layq.assign((size_t)L * R, 0x80000000u);
+        int row = 0;
+        for (int l = 0; l < L; l++) {
+            const int cnt = (l < P) ? R - 1 : R;
+            for (int k = 0; k < cnt; k++)
+                layq[(size_t)l * R + k] = (unsigned)((int)rint(a->motif[row++] * QSCALE)) + 0x80000000u;
+        }
+        if ((rc = sk_reserve(c, &c->motifq, layq.size() * sizeof(unsigned)))) return rc;
+        SK_HIP(hipMemcpyAsync(c->motifq.p, layq.data(), layq.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+        c->motifq_valid = true;
+    }
 
     const int64_t maxlen = a->max_len;
     const int nck = (int)((maxlen + L - 1) / ck);

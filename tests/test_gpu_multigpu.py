@@ -67,7 +67,9 @@ def test_bench_gather_path_bare_python(gpu, scaling):
            "--warmup", "1", "--cpu-seconds", "2", "--no-extras", "--scaling", scaling]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
-    line = json.loads(p.stdout.strip().splitlines()[-1])
+    lines = p.stdout.strip().splitlines()
+    assert lines[-1].startswith("{"), "the JSON line must be the last thing on stdout: %r" % lines[-3:]
+    line = json.loads(lines[-1])
     assert line["n_gpus"] == 1 and line["scaling"] == scaling
     assert line["config"]["gather_backend"] == "rccl" and line["config"]["ranks_seen"] == 1
     assert line["parity"]["dist_bit_identical"] and line["parity"]["start_end_exact"]
