@@ -43,23 +43,30 @@ __device__ __forceinline__ unsigned pk_clamp_i16(unsigned q, unsigned lo2, unsig
     return __builtin_bit_cast(unsigned, c);
 }
 // (inline asm: given the generic vector operations the compiler turns these short packed sequences into
-// SDWA compares + selects + a permute, two to three times the instructions)
-__device__ __forceinline__ unsigned pk_sub_u16(unsigned a, unsigned b)
+// SDWA compares + selects + a permute, two to three times the instructions.  The second operand of each is a
+// wave-uniform constant: it rides in an SGPR, so no v_mov and no vector register is spent on it.)
+__device__ __forceinline__ unsigned pk_sub_u16(unsigned a, unsigned b_uniform)
 {
     unsigned r;
-    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b_uniform));
     return r;
 }
-__device__ __forceinline__ unsigned pk_subsat_u16(unsigned a, unsigned b)      // max(a - b, 0) per half
+__device__ __forceinline__ unsigned pk_subsat_u16(unsigned a, unsigned b_uniform)      // max(a - b, 0) per half
 {
     unsigned r;
-    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(b_uniform));
     return r;
 }
-__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b)
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b_uniform)
 {
     unsigned r;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b_uniform));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_min1_u16(unsigned a)                     // min(a, 1) per half
+{
+    unsigned r;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(a));
     return r;
 }
 __device__ __forceinline__ unsigned pk_shl2_u16(unsigned a)                     // both halves << 2
@@ -68,10 +75,10 @@ __device__ __forceinline__ unsigned pk_shl2_u16(unsigned a)                     
     asm("v_pk_lshlrev_b16 %0, 2, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
     return r;
 }
-__device__ __forceinline__ unsigned udot2(unsigned a, unsigned b, unsigned c)   // a.lo b.lo + a.hi b.hi + c
+__device__ __forceinline__ unsigned udot2(unsigned a, unsigned b_uniform, unsigned c)   // a.lo b.lo + a.hi b.hi + c
 {
     unsigned r;
-    asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
     return r;
 }
 
@@ -110,22 +117,29 @@ struct SegStatArgs {
 };
 
 // NT: 512-sample tiles held in registers (reads of up to 512 NT samples)
-// NQ: 16-byte histogram chunks per lane -- 256 NQ bins per wave: bin 0 = dropped samples, bin b = value lo + b
+// NQ: 16-byte histogram chunks per lane -- 256 NQ bins per wave
 // OCC: wavefronts per SIMD the register allocation is sized for
+//
+// Sample images.  t = (x - (lo + 1)) mod 2^16 is the sample's histogram bin: kept <=> t < nbins (hi <= 32768 makes
+// every dropped x land at t >= nbins, no aliasing), and t' = min(t, nbins) sends every dropped sample -- and the
+// slots past the read's end -- to ONE dump bin, `nbins`.  Two packed instructions per pair of samples; the exact
+// sums run over t' and are corrected by the dump bin's count afterwards.
 template <int NT, int NQ, int OCC = 8>
 __global__ __launch_bounds__(64 * WPB, OCC)
 void k_seg_stats(const SegStatArgs a)
 {
     constexpr int HBINS = 64 * 4 * NQ;
     __shared__ __align__(16) unsigned hist_all[WPB][HBINS];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ __align__(16) unsigned char plane_all[WPB][2][64 * NT];     // one byte per 8 samples: in band / dropped
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // (scalar: r, M and every row address too)
     unsigned *hist = hist_all[w];
+    unsigned char *p_in = plane_all[w][0], *p_dr = plane_all[w][1];
     const int hb0 = lane * 4 * NQ;                         // first bin this lane owns
 
     const int nbins = a.hi - a.lo - 1;                     // 1 .. min(HBINS - 1, MAXBINS) (host)
-    const int lo1 = max(a.lo + 1, -32768), hi1 = min(a.hi - 1, 32767);
-    const unsigned lo1p = (unsigned)(lo1 & 0xffff) * 0x10001u, hi1p = (unsigned)(hi1 & 0xffff) * 0x10001u;
-    const unsigned lop = (unsigned)(a.lo & 0xffff) * 0x10001u;         // y = x - lo  (1 .. nbins for kept samples)
+    const unsigned lo1p = (unsigned)((a.lo + 1) & 0xffff) * 0x10001u;
+    const unsigned nbp = (unsigned)nbins * 0x10001u, nbm1p = (unsigned)(nbins - 1) * 0x10001u;
     const int maxM = (int)min(a.stride, (int64_t)(512 * NT));
 
 #pragma unroll
@@ -133,8 +147,9 @@ void k_seg_stats(const SegStatArgs a)
 
     const int nwaves = gridDim.x * WPB;
     for (int r = blockIdx.x * WPB + w; r < a.nreads; r += nwaves) {
-        const int M = min(max(a.len[r], 0), maxM);
+        const int M = __builtin_amdgcn_readfirstlane(min(max(a.len[r], 0), maxM));
         const int16_t *row = a.sig + (int64_t)r * a.stride;
+        const int ntiles = (M + 511) >> 9;
 
         // ---- the whole read into registers: NT x 16-byte loads per lane, all in flight at once ----------
         unsigned y[NT][4];
@@ -145,75 +160,80 @@ void k_seg_stats(const SegStatArgs a)
             y[t][0] = q.x; y[t][1] = q.y; y[t][2] = q.z; y[t][3] = q.w;
         }
 
-        // ---- pass 1 (registers): filter, y = x - lo (0 for dropped), exact sums, histogram ---------------
-        int sy = 0, syy = 0;
+        // ---- pass 1 (registers): t' per sample, exact sums, histogram ----------------------------------------
+        int st = 0, stt = 0;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            if (t * 512 >= M) continue;                    // (wave-uniform) nothing of the read in this tile
-            const int i0 = t * 512 + lane * 8;
-            const int nvalid = min(max(M - i0, 0), 8);     // samples of this lane's eight that exist
+            if (t >= ntiles) continue;                     // (wave-uniform) nothing of the read in this tile
+            const int nvalid = min(max(M - (t * 512 + lane * 8), 0), 8);   // samples of this lane's eight that exist
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const unsigned q = y[t][k];
-                const unsigned d = pk_clamp_i16(q, lo1p, hi1p) ^ q;          // non-zero half: outside (lo, hi)
-                unsigned km = pk_sub_u16(pk_min_u16(d, 0x10001u), 0x10001u); // 0xffff per kept half
-                if (t * 512 + 512 > M) {                                     // (wave-uniform: the read's last tile)
+                unsigned tt = pk_min_u16(pk_sub_u16(y[t][k], lo1p), nbp);
+                if (t == ntiles - 1) {                     // (wave-uniform) the read's last tile: slots past its end
                     const unsigned tail = nvalid >= 2 * k + 2 ? 0xffffffffu : (nvalid == 2 * k + 1 ? 0xffffu : 0u);
-                    km &= tail;
+                    tt = (tt & tail) | (nbp & ~tail);
                 }
-                const unsigned yy = pk_sub_u16(q, lop) & km;
-                y[t][k] = yy;
-                const s16x2 ys = __builtin_bit_cast(s16x2, yy);
-                sy = __builtin_amdgcn_sdot2(ys, __builtin_bit_cast(s16x2, 0x10001u), sy, false);
-                syy = __builtin_amdgcn_sdot2(ys, ys, syy, false);
-                const unsigned y4 = pk_shl2_u16(yy);                         // byte offsets of the two bins
-                atomicAdd((unsigned *)((char *)hist + (y4 & 0xffffu)), 1u);
-                atomicAdd((unsigned *)((char *)hist + (y4 >> 16)), 1u);
+                y[t][k] = tt;
+                const s16x2 ts = __builtin_bit_cast(s16x2, tt);
+                st = __builtin_amdgcn_sdot2(ts, __builtin_bit_cast(s16x2, 0x10001u), st, false);
+                stt = __builtin_amdgcn_sdot2(ts, ts, stt, false);
+                const unsigned t4 = pk_shl2_u16(tt);                         // byte offsets of the two bins
+                atomicAdd((unsigned *)((char *)hist + (t4 & 0xffffu)), 1u);
+                atomicAdd((unsigned *)((char *)hist + (t4 >> 16)), 1u);
             }
+            // keep the tiles apart: left alone the scheduler precomputes the LDS addresses of all 8 tiles (64 more
+            // live registers) before it issues the first atomic
+            __builtin_amdgcn_sched_barrier(0);
         }
 
-        // ---- exact integer totals -------------------------------------------------------------------------
-        const long long S = (long long)wave_sum(sy);                         // <= 4096 * 2047
-        const long long Q = (long long)wave_sum(syy & 0xffff) + ((long long)wave_sum((int)((unsigned)syy >> 16)) << 16);
+        // ---- exact integer totals (dump-bin entries taken out) ------------------------------------------------
+        const long long D = (long long)__builtin_amdgcn_readfirstlane((int)hist[nbins]);   // dropped samples + slots past the end
+        if (lane == 0) hist[nbins] = 0u;                                     // (LDS ops of a wave are in order)
+        const long long S = (long long)wave_sum(st) - D * nbins;
+        const long long Q = (long long)wave_sum(stt & 0xffff) + ((long long)wave_sum((int)((unsigned)stt >> 16)) << 16)
+                            - D * nbins * nbins;
+        const int n = ntiles * 512 - (int)D;                                 // samples that survived the filter
 
-        // ---- median: rank select on the histogram, from registers (lane l owns bins [hb0, hb0 + 4 NQ)) -------
-        unsigned cnt[4 * NQ];
+        // ---- median: rank select on the histogram (lane l owns bins [hb0, hb0 + 4 NQ)) ---------------------------
+        // Two sweeps over the lane's own bins, four at a time (16-byte LDS reads), instead of holding all of them:
+        // the samples already occupy 4 NT registers per lane.
+        int local = 0;
 #pragma unroll
         for (int j = 0; j < NQ; j++) {
             const uint4 q = *(const uint4 *)(hist + hb0 + 4 * j);
-            cnt[4 * j] = q.x; cnt[4 * j + 1] = q.y; cnt[4 * j + 2] = q.z; cnt[4 * j + 3] = q.w;
-            *(uint4 *)(hist + hb0 + 4 * j) = make_uint4(0u, 0u, 0u, 0u);    // (my reads are done: LDS ops of a wave are in order)
+            local += (int)(q.x + q.y + q.z + q.w);
         }
-        if (lane == 0) cnt[0] = 0u;                                          // bin 0 collected the dropped samples
-        int local = 0;
-#pragma unroll
-        for (int i = 0; i < 4 * NQ; i++) local += (int)cnt[i];
-        const int inc = wave_incl_scan(local);
-        const int n = __builtin_amdgcn_readlane(inc, 63);                    // samples that survived the filter
+        asm volatile("" ::: "memory");                     // (the second sweep re-reads: do not keep the bins live)
 
         sk_prep pr;
         pr.n = n; pr.flags = 0; pr.center = 0.0; pr.scale = 1.0; pr.top = 0.0; pr.bot = 0.0;
-        int firsty = 1, width = 0;                                           // in band: (unsigned)(y - firsty) < width
+        int tlo = 0, width = 0;                                              // in band: (unsigned)(t - tlo) < width
         bool certified = true;
         if (n == 0) {
             pr.flags = SK_FLAG_EMPTY;
             const double qnan = __builtin_nan("");
             pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
         } else {
+            const int inc = wave_incl_scan(local);
             const int k1 = (n - 1) / 2, k2 = n / 2;
             const int pre = inc - local;
             int i1 = hb0, i2 = hb0, acc = pre;
 #pragma unroll
-            for (int i = 0; i < 4 * NQ; i++) {
-                acc += (int)cnt[i];
-                i1 += (acc <= k1) ? 1 : 0;
-                i2 += (acc <= k2) ? 1 : 0;
+            for (int j = 0; j < NQ; j++) {
+                const uint4 q = *(const uint4 *)(hist + hb0 + 4 * j);
+                const unsigned c4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    acc += (int)c4[i];
+                    i1 += (acc <= k1) ? 1 : 0;
+                    i2 += (acc <= k2) ? 1 : 0;
+                }
             }
             const unsigned long long own1 = __ballot(local > 0 && k1 >= pre && k1 < pre + local);
             const unsigned long long own2 = __ballot(local > 0 && k2 >= pre && k2 < pre + local);
             const int b1 = __builtin_amdgcn_readlane(i1, own1 ? (int)__builtin_ctzll(own1) : 0);
             const int b2 = __builtin_amdgcn_readlane(i2, own2 ? (int)__builtin_ctzll(own2) : 0);
-            const double median = (double)(b1 + b2 + 2 * a.lo) * 0.5;        // exact (half-integer)
+            const double median = (double)(b1 + b2 + 2 * (a.lo + 1)) * 0.5;  // exact (half-integer)
 
             // ---- thresholds from exact integers; certify ceil(top) / floor(bot) against numpy's rounding -------
             const long long V = (long long)n * Q - S * S;                    // n^2 var, exact (< 2^46)
@@ -226,44 +246,45 @@ void k_seg_stats(const SegStatArgs a)
             certified = (V == 0) || (ceil(top - delta) == ct && ceil(top + delta) == ct &&
                                      floor(bot - delta) == fb && floor(bot + delta) == fb);
             pr.center = median; pr.scale = sd; pr.top = top; pr.bot = bot;
-            // integer band (clamped around the histogram range, so everything below stays in 16 bits)
+            // integer band in bin coordinates (clamped around the histogram range first: everything stays small)
             const double ctc = fmin(fmax(ct, (double)a.lo - 4.0), (double)a.hi + 4.0);
             const double fbc = fmin(fmax(fb, (double)a.lo - 4.0), (double)a.hi + 4.0);
-            const int ylo = max((int)fbc + 1 - a.lo, 1);                     // first in-band y
-            const int yhi = min((int)ctc - 1 - a.lo, nbins);                 // last in-band y
-            firsty = ylo;
-            width = max(yhi - ylo + 1, 0);
+            tlo = max((int)fbc - a.lo, 0);                                   // first in-band bin: value floor(bot) + 1
+            const int thi = min((int)ctc - a.lo - 2, nbins - 1);             // last in-band bin: value ceil(top) - 1
+            width = max(thi - tlo + 1, 0);
         }
+#pragma unroll
+        for (int j = 0; j < NQ; j++) *(uint4 *)(hist + hb0 + 4 * j) = make_uint4(0u, 0u, 0u, 0u);   // (my reads are done)
         if (lane == 0) {
             a.prep[r] = pr;
             if (!certified) a.retry[1 + atomicAdd(&a.retry[0], 1)] = r;
         }
 
-        // ---- pass 2 (registers): one "kept" and one "in band" bit per raw sample ------------------------------
+        // ---- pass 2 (registers): one "in band" and one "dropped" bit per raw sample ------------------------------
         // Each lane has 8 consecutive samples of a tile -> one byte of each mask; v_dot2_u32_u16 with the bit
-        // weights {1 << 2k, 1 << (2k + 1)} builds the bytes; three DPP steps gather the 8 bytes of lanes
-        // 8j .. 8j+7 into lane 8j, which stores 16 bytes {in band, kept} -- 128 contiguous bytes per tile.
-        const unsigned fp = (unsigned)(firsty & 0xffff) * 0x10001u;
-        const unsigned wm1 = (unsigned)((width - 1) & 0xffff) * 0x10001u;
-        uint4 *mrow = a.mask2 + (int64_t)r * a.row16;
+        // weights {1 << 2k, 1 << (2k + 1)} builds the bytes from 0/1 flags.  The bytes go through LDS so that
+        // lane e can pick up entry e's 8 + 8 bytes and the wave stores the read's masks with ONE 16-byte store
+        // per lane (1 KB contiguous).
+        const unsigned tlop = (unsigned)__builtin_amdgcn_readfirstlane(tlo) * 0x10001u;
+        const unsigned wm1p = (unsigned)((__builtin_amdgcn_readfirstlane(width) - 1) & 0xffff) * 0x10001u;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            if (t * 512 >= M) continue;                    // (tiles past the read hold nothing)
-            unsigned keep8 = 0, out8 = 0;
+            if (t >= ntiles) continue;
+            unsigned drop8 = 0, out8 = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const unsigned wts = (1u << (2 * k)) | (2u << (2 * k + 16));
-                keep8 = udot2(pk_min_u16(y[t][k], 0x10001u), wts, keep8);                    // kept <=> y >= 1
-                const unsigned over = pk_subsat_u16(pk_sub_u16(y[t][k], fp), wm1);           // > 0: outside the band
-                out8 = udot2(pk_min_u16(over, 0x10001u), wts, out8);
+                drop8 = udot2(pk_subsat_u16(y[t][k], nbm1p), wts, drop8);                    // t' - (nbins - 1) is 0 or 1
+                const unsigned over = pk_subsat_u16(pk_sub_u16(y[t][k], tlop), wm1p);        // > 0: outside the band
+                out8 = udot2(pk_min1_u16(over), wts, out8);
             }
-            unsigned in8 = (width > 0) ? (~out8 & keep8) : 0u;
-            unsigned h_in = in8 | (dpp_shl<1>(in8) << 8);         // 16 bits in even lanes
-            unsigned h_kp = keep8 | (dpp_shl<1>(keep8) << 8);
-            h_in |= dpp_shl<2>(h_in) << 16;                       // 32 bits in lanes = 0 mod 4
-            h_kp |= dpp_shl<2>(h_kp) << 16;
-            const unsigned in_hi = dpp_shl<4>(h_in), kp_hi = dpp_shl<4>(h_kp);   // the next four lanes' 32 bits
-            if ((lane & 7) == 0) mrow[t * 8 + (lane >> 3)] = make_uint4(h_in, in_hi, h_kp, kp_hi);
+            p_in[t * 64 + lane] = (unsigned char)((width > 0) ? ~out8 : 0u);
+            p_dr[t * 64 + lane] = (unsigned char)drop8;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (lane < 8 * ntiles) {
+            const uint2 vi = *(const uint2 *)(p_in + 8 * lane), vd = *(const uint2 *)(p_dr + 8 * lane);
+            a.mask2[(int64_t)r * a.row16 + lane] = make_uint4(vi.x, vi.y, ~vd.x, ~vd.y);     // {in band, kept}
         }
     }
 }
@@ -440,11 +461,11 @@ segstat_fn pick_stats(int NT, int nbins)
     if (small) {
         if (const char *e = getenv("SK_SEG_OCC")) {         // tuning: registers per lane vs reads in flight
             const int v = atoi(e);
-            if (v == 6) return k_seg_stats<8, 4, 6>;
-            if (v == 5) return k_seg_stats<8, 4, 5>;
+            if (v == 8) return k_seg_stats<8, 4, 8>;
+            if (v == 7) return k_seg_stats<8, 4, 7>;
             if (v == 4) return k_seg_stats<8, 4, 4>;
         }
-        return k_seg_stats<8, 4, 8>;
+        return k_seg_stats<8, 4, 6>;
     }
     return k_seg_stats<8, 8>;
 }
