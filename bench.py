@@ -367,19 +367,33 @@ def motifseq_roofline(a, w, prof, steps, mean_n):
             "valu": valu}
 
 
+def segmenter_isolated(w, steps=3):
+    """Kernel times with the two kernels run one after the other (SK_SEG_CHUNKS=1): by default the walk of one
+    chunk runs beside the statistics of the next, which is what `value` measures but not what a per-kernel
+    roofline can be computed from."""
+    os.environ["SK_SEG_CHUNKS"] = "1"
+    try:
+        _, prof = timed(w, None, steps, 1)
+    finally:
+        del os.environ["SK_SEG_CHUNKS"]
+    return prof, steps
+
+
 def segmenter_roofline(w, prof, steps):
     R, M = w.R, w.M
     prep_ms, main_ms = prof["prep_ms"] / steps, prof["main_ms"] / steps
     alg_bytes = R * (2 * M + 4 + 8 * 2)
     dominant, dom_ms = ("k_seg_stats (filter + statistics + in-band mask)", prep_ms) if prep_ms >= main_ms \
         else ("k_segment_walk", main_ms)
-    per_read, src = traffic_from_profiles("segmenter", "k_seg" if prep_ms >= main_ms else "k_segment_walk")
+    per_read, src = traffic_from_profiles("segmenter", "k_seg_stats" if prep_ms >= main_ms else "k_seg_walk2")
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
     both = alg_bytes / ((prep_ms + main_ms) * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": per_read * R if per_read else None, "traffic_source": src,
             "kernel_ms": {"prep": prep_ms, "main": main_ms, "dominant_avg_launch": dom_ms},
             "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms_note": "the two kernels timed one after the other (SK_SEG_CHUNKS=1); `value` uses the "
+                              "default, where the walk of one chunk overlaps the statistics of the next",
             "both_kernels": {"achieved": both, "frac": both / HBM_PEAK_GBS}}
 
 
@@ -400,7 +414,8 @@ def extras_single_gpu(a, L, main):
                                 "unit": "reads/s", "ms_per_step": el / 5 * 1e3, "steps": 5, "warmup": 1,
                                 "config": {"workload": "segmenter C2-1M: %d reads x %d int16 samples, default flags"
                                                        % (w.R, w.M), "seed": w.seed},
-                                "roofline": segmenter_roofline(w, prof, 5), "cpu_baseline": cpu, "parity": par}
+                                "roofline": segmenter_roofline(w, *segmenter_isolated(w)), "cpu_baseline": cpu,
+                                "parity": par}
         finally:
             w.free()
     # ---- what the screening buys: the exact-only schemes on 200 000 of the same reads ------------------------
@@ -496,7 +511,8 @@ def rank_body(a, comm, rank, world, shape):
         wl = "MotifSeq C4: %d reads x %d int16 samples %s, %d-pt motif, %s" % (
             a.reads, a.samples, "per GPU" if a.scaling == "weak" else "in total", a.motif, a.scale)
     else:
-        roofline = segmenter_roofline(w, prof, a.steps)
+        roofline = segmenter_roofline(w, *segmenter_isolated(w)) if use_comm is None else \
+            segmenter_roofline(w, prof, a.steps)
         name = "reads/sec segmenter (4k-sample read)"
         wl = "segmenter C2-1M: %d reads x %d int16 samples %s, default flags" % (
             a.reads, a.samples, "per GPU" if a.scaling == "weak" else "in total")

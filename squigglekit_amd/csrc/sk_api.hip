@@ -392,7 +392,7 @@ int sk_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_le
         // integer thresholds; the numpy-order kernel redoes the (almost always empty) list of uncertified reads
         const size_t mb = (size_t)nreads * (size_t)sk_segment_fast_row16(stride) * 16;
         if ((rc = sk_reserve(c, &c->mask, mb))) return rc;
-        if ((rc = sk_reserve(c, &c->retry, ((size_t)nreads + 1) * sizeof(int32_t)))) return rc;
+        if ((rc = sk_reserve(c, &c->retry, ((size_t)nreads + 16) * sizeof(int32_t)))) return rc;
         rc = sk_launch_segment_fast(c, d_sig, stride, d_len, nreads, p, lo, hi, (sk_prep *)c->prep.p, c->mask.p,
                                     (int32_t *)c->retry.p, d_segs, d_nsegs, max_segs);
         if (rc) return rc;

@@ -34,6 +34,8 @@ struct sk_ctx {
     int         device = -1;
     bool        ready = false;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;    // second stream (created on first use): overlapped walks / copies
+    hipEvent_t  ev_chunk[9] = {};     // ordering events between the two streams (no timing)
     hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};   // prep start/stop, main start/stop
     bool        ev_valid = false;
     int         num_cu = 0;

@@ -124,6 +124,11 @@ int sk_shutdown(void)
         for (sk_buf *b : bufs) free_buf(b);
         for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev[i]);
         for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
+        if (c->stream2) {
+            (void)hipStreamSynchronize(c->stream2);
+            for (int i = 0; i < 9; i++) if (c->ev_chunk[i]) (void)hipEventDestroy(c->ev_chunk[i]);
+            (void)hipStreamDestroy(c->stream2);
+        }
         (void)hipStreamDestroy(c->stream);
         *c = sk_ctx();
     }

@@ -491,7 +491,11 @@ bool sk_segment_fast_applies(const void *d_sig, int64_t stride, int32_t lo, int3
 }
 
 // Streaming statistics, the numpy-order redo of the (almost always empty) list of uncertified reads, then the walk.
-// d_retry: nreads + 1 ints ([0] = count, zeroed here).  Records ev[0..3] like the other segment paths.
+// Large batches go in chunks (SK_SEG_CHUNKS, default 4): the walk of chunk i runs on a second stream beside the
+// statistics of chunk i + 1 -- one is a stream of HBM loads with vector work in between, the other pure vector
+// work on 1/64th as many wavefronts.
+// d_retry: nreads + 16 ints (per chunk: [0] = count, [1 ..] = list; zeroed here).  Records ev[0..3] like the
+// other segment paths: ev[0]..ev[1] statistics of all chunks, ev[2]..ev[3] what is left of the walks after that.
 int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
                            const sk_seg_params *p, int32_t lo, int32_t hi, sk_prep *d_prep, void *d_mask2,
                            int32_t *d_retry, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs)
@@ -499,26 +503,10 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
     const int NT = (int)((stride + 511) / 512);
     segstat_fn fn = pick_stats(NT, hi - lo - 1);
     SegStatArgs a;
-    a.sig = d_sig; a.stride = stride; a.len = d_len; a.nreads = nreads; a.lo = lo; a.hi = hi;
+    a.stride = stride; a.lo = lo; a.hi = hi;
     a.std_scale = p->std_scale; a.delta_scale = 1.0;
     if (const char *e = getenv("SK_SEG_DELTA_SCALE")) { const double v = atof(e); if (v > 0) a.delta_scale = v; }
-    a.prep = d_prep; a.mask2 = (uint4 *)d_mask2; a.row16 = sk_segment_fast_row16(stride); a.retry = d_retry;
-
-    SK_HIP(hipMemsetAsync(d_retry, 0, sizeof(int32_t), c->stream));
-    SK_HIP(hipEventRecord(c->ev[0], c->stream));
-    int per_cu = 8, rounds = 4;
-    if (const char *e = getenv("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
-    if (const char *e = getenv("SK_PREP_PERCU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }
-    const long long g = (long long)c->num_cu * per_cu * rounds;
-    const long long need = ((long long)nreads + WPB - 1) / WPB;
-    const int grid = (int)(g > need ? need : g);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * WPB), 0, c->stream, a);
-    SK_HIP(hipGetLastError());
-    // reads whose ceil(top) / floor(bot) could not be certified: numpy-order statistics, masks rewritten in place
-    int rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nreads, lo, hi, SK_PREP_SEGMENT, p->std_scale, nullptr, d_prep,
-                                nullptr, 0, 0, 0x7fffffff, d_retry + 1, d_retry, d_mask2, a.row16);
-    if (rc) return rc;
-    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+    a.row16 = sk_segment_fast_row16(stride);
 
     WalkParams wp;
     wp.error = p->error; wp.corrector = p->corrector; wp.window = p->window; wp.seg_dist = p->seg_dist;
@@ -529,15 +517,65 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
     else                       wp.first_len = (int)ceil(fl);
     const bool fast = wp.error < wp.corrector && wp.window >= 1 && wp.first_len >= 1 &&
                       getenv("SK_WALK_GENERAL") == nullptr;
-    const int wgrid = (nreads + 63) / 64;
-    SK_HIP(hipEventRecord(c->ev[2], c->stream));
-    if (fast)
-        hipLaunchKernelGGL(k_seg_walk2<true>, dim3(wgrid), dim3(64), 0, c->stream, (const uint4 *)d_mask2, a.row16,
-                           d_len, stride, nreads, wp, d_segs, d_nsegs, max_segs);
-    else
-        hipLaunchKernelGGL(k_seg_walk2<false>, dim3(wgrid), dim3(64), 0, c->stream, (const uint4 *)d_mask2, a.row16,
-                           d_len, stride, nreads, wp, d_segs, d_nsegs, max_segs);
-    SK_HIP(hipGetLastError());
+
+    int nchunks = 4;
+    if (const char *e = getenv("SK_SEG_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 8) nchunks = v; }
+    if (nreads < 65536) nchunks = 1;
+    if (nchunks > 1 && !c->stream2) {
+        SK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 9; i++) SK_HIP(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
+    }
+    int per_cu = 8, rounds = 4;
+    if (const char *e = getenv("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
+    if (const char *e = getenv("SK_PREP_PERCU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }
+
+    SK_HIP(hipMemsetAsync(d_retry, 0, ((size_t)nreads + 16) * sizeof(int32_t), c->stream));
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    if (nchunks > 1) {                                             // the second stream starts behind the memsets
+        SK_HIP(hipEventRecord(c->ev_chunk[8], c->stream));
+        SK_HIP(hipStreamWaitEvent(c->stream2, c->ev_chunk[8], 0));
+    }
+    const int32_t per = (int32_t)(((int64_t)nreads + nchunks - 1) / nchunks);
+    for (int ci = 0; ci < nchunks; ci++) {
+        const int32_t r0 = ci * per;
+        const int32_t nr = (nreads - r0 < per) ? nreads - r0 : per;
+        if (nr <= 0) break;
+        int32_t *retry = d_retry + r0 + ci;
+        a.sig = d_sig + (int64_t)r0 * stride; a.len = d_len + r0; a.nreads = nr;
+        a.prep = d_prep + r0; a.mask2 = (uint4 *)d_mask2 + (int64_t)r0 * a.row16; a.retry = retry;
+        const long long g = (long long)c->num_cu * per_cu * rounds;
+        const long long need = ((long long)nr + WPB - 1) / WPB;
+        const int grid = (int)(g > need ? need : g);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * WPB), 0, c->stream, a);
+        SK_HIP(hipGetLastError());
+        // reads whose ceil(top) / floor(bot) could not be certified: numpy-order statistics, masks rewritten in place
+        int rc = sk_launch_prep_i16(c, a.sig, stride, a.len, nr, lo, hi, SK_PREP_SEGMENT, p->std_scale, nullptr, a.prep,
+                                    nullptr, 0, 0, 0x7fffffff, retry + 1, retry, a.mask2, a.row16);
+        if (rc) return rc;
+        hipStream_t ws = c->stream;
+        if (nchunks > 1) {
+            SK_HIP(hipEventRecord(c->ev_chunk[ci], c->stream));
+            SK_HIP(hipStreamWaitEvent(c->stream2, c->ev_chunk[ci], 0));
+            ws = c->stream2;
+        } else {
+            SK_HIP(hipEventRecord(c->ev[1], c->stream));
+            SK_HIP(hipEventRecord(c->ev[2], c->stream));
+        }
+        const int wgrid = (nr + 63) / 64;
+        if (fast)
+            hipLaunchKernelGGL(k_seg_walk2<true>, dim3(wgrid), dim3(64), 0, ws, (const uint4 *)a.mask2, a.row16,
+                               a.len, stride, nr, wp, d_segs + (int64_t)r0 * 2 * max_segs, d_nsegs + r0, max_segs);
+        else
+            hipLaunchKernelGGL(k_seg_walk2<false>, dim3(wgrid), dim3(64), 0, ws, (const uint4 *)a.mask2, a.row16,
+                               a.len, stride, nr, wp, d_segs + (int64_t)r0 * 2 * max_segs, d_nsegs + r0, max_segs);
+        SK_HIP(hipGetLastError());
+    }
+    if (nchunks > 1) {
+        SK_HIP(hipEventRecord(c->ev[1], c->stream));
+        SK_HIP(hipEventRecord(c->ev[2], c->stream));
+        SK_HIP(hipEventRecord(c->ev_chunk[8], c->stream2));        // the caller's stream continues behind the walks
+        SK_HIP(hipStreamWaitEvent(c->stream, c->ev_chunk[8], 0));
+    }
     SK_HIP(hipEventRecord(c->ev[3], c->stream));
     return SK_OK;
 }

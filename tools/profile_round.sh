@@ -1,28 +1,37 @@
 #!/bin/bash
 # Regenerate the measurement artefacts kept under profiles/ on a GPU box:
 #   tools/profile_round.sh <tag>      (run from the repo root; writes gpurun_out/prof_<tag>/)
-# bench lines (default flags), rocprofv3 --kernel-trace --stats summaries of the same command, and
-# HBM traffic from separate --pmc passes (FETCH_SIZE / WRITE_SIZE, kernel trace only -- no other
-# trace domains together with counters).
+# bench lines (default flags), rocprofv3 --kernel-trace --stats summaries of the same command, HBM traffic from
+# separate --pmc passes (FETCH_SIZE / WRITE_SIZE) and one SQ pass (VALU instruction counts / issue cycles) --
+# counters always with --kernel-trace only, never with other trace domains -- and the VALU issue-cost
+# microbenchmark the DTW roof rests on.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+"$R/tools/ubench/valu_rate" > "$OUT/valu_rate.txt" 2>&1
+python "$R/bench.py" > "$OUT/bench_motifseq.json" 2> "$OUT/bench_motifseq.err"
+SK_SEG_CHUNKS=1 python "$R/bench.py" --workload segmenter --no-extras > "$OUT/bench_segmenter.json" 2> "$OUT/bench_segmenter.err"
+SQ="SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
 for WL in motifseq segmenter; do
-    python "$R/bench.py" --workload $WL > "$OUT/bench_$WL.json" 2> "$OUT/bench_$WL.err"
+    export SK_SEG_CHUNKS=1      # kernels timed one after the other (the default overlaps the walk with the statistics)
     rocprofv3 --kernel-trace --stats -d "$OUT/kt_$WL" -- python "$R/bench.py" --workload $WL --steps 3 --warmup 1 \
-        --cpu-seconds 0 > "$OUT/kt_$WL.log" 2>&1
+        --cpu-seconds 0 --no-extras > "$OUT/kt_$WL.log" 2>&1
     DB=$(find "$OUT/kt_$WL" -name '*_results.db' | head -1)
     python "$R/tools/rocprof_summary.py" "$DB" "bench.py --workload $WL --steps 3 --warmup 1 ($TAG)" \
         > "$OUT/${WL}_kernel_stats.txt"
     for C in FETCH_SIZE WRITE_SIZE; do
         rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_$WL" -- \
-            python "$R/bench.py" --workload $WL --steps 2 --warmup 0 --cpu-seconds 0 > "$OUT/pmc_${C}_$WL.log" 2>&1
+            python "$R/bench.py" --workload $WL --steps 2 --warmup 0 --cpu-seconds 0 --no-extras > "$OUT/pmc_${C}_$WL.log" 2>&1
     done
     python "$R/tools/pmc_traffic.py" 1000000 2 "$OUT/pmc_FETCH_SIZE_$WL" "$OUT/pmc_WRITE_SIZE_$WL" \
         "bench.py --workload $WL --steps 2 --warmup 0 ($TAG, 1M reads/call)" > "$OUT/traffic_$WL.json"
-    rm -rf "$OUT/kt_$WL" "$OUT/pmc_FETCH_SIZE_$WL" "$OUT/pmc_WRITE_SIZE_$WL"
+    rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d "$OUT/pmc_sq_$WL" -- \
+        python "$R/bench.py" --workload $WL --steps 2 --warmup 0 --cpu-seconds 0 --no-extras > "$OUT/pmc_sq_$WL.log" 2>&1
+    python "$R/tools/pmc_sq.py" "$OUT/pmc_sq_$WL" "bench.py --workload $WL --steps 2 --warmup 0 ($TAG)" > "$OUT/sq_$WL.json"
+    rm -rf "$OUT/kt_$WL" "$OUT/pmc_FETCH_SIZE_$WL" "$OUT/pmc_WRITE_SIZE_$WL" "$OUT/pmc_sq_$WL"
+    unset SK_SEG_CHUNKS
 done
 ls -la "$OUT"
