@@ -451,6 +451,136 @@ void k_seg_walk2(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
     if (live) nsegs[r] = st.nseg;                 // a segment still open at EOF is dropped (:466)
 }
 
+// ------------------------------------------------------------------------------------------------------
+// the same walk by RUNS instead of by samples (error < corrector, positive thresholds: what k_seg_walk2<true> covers)
+// ------------------------------------------------------------------------------------------------------
+// With the corrector test dead, get_segs' per-sample state has a closed form.  A candidate segment ("run") opens at
+// an in-band sample s; every in-band sample and the first E = max(error, 0) out-of-band ones extend it (:431-447);
+// the (E + 1)-th out-of-band sample z closes it (:448 / :458) with
+//     c = z - s                      (every sample of [s, z) was counted)
+//     end = z - prev_err = l + 1     (l = last in-band sample before z: prev_err counts the out-of-band tail)
+// and the scan resumes behind z.  So a lane hops from run to run with bit scans (find-first-set, popcount,
+// clear-lowest-set) on 32-bit pieces of its read's in-band mask instead of stepping through every sample:
+// ~200 runs instead of 4 000 samples per read, 3-4x fewer vector instructions (the kernel is issue-bound).
+struct RunState {
+    int in_run, zl, start, last1;     // zl: out-of-band samples the open run still needs to close
+    int nseg, last_end;
+    unsigned thr;                     // report threshold: min(window, first_len) until the first segment (:448)
+};
+
+__device__ __forceinline__ void run_report(RunState &st, int start, int end, const WalkParams &p, int32_t *my, int max_segs)
+{
+    if (st.nseg > 0 && start - st.last_end < p.seg_dist) {                         // :451 merge
+        if (st.nseg <= max_segs) my[2 * (st.nseg - 1) + 1] = end;
+    } else {
+        if (st.nseg < max_segs) { my[2 * st.nseg] = start; my[2 * st.nseg + 1] = end; }
+        st.nseg++;
+    }
+    st.last_end = end;
+    st.thr = (unsigned)p.window;
+}
+
+// 32 samples W (bit b = filtered sample base + b in band), all valid
+__device__ __forceinline__ void run_word32(RunState &st, unsigned W, int base, int E1, const WalkParams &p,
+                                           int32_t *my, int max_segs)
+{
+    int pos = 0;
+    while (pos < 32) {
+        if (!st.in_run) {
+            const unsigned m = W >> pos;
+            if (m == 0u) break;                                   // nothing opens in the rest of the word
+            pos += __builtin_ctz(m);
+            st.in_run = 1; st.start = base + pos; st.zl = E1; st.last1 = st.start;
+        }
+        const unsigned ones = W >> pos;                           // (pos < 32)
+        unsigned Z = ~W >> pos;                                   // out-of-band samples at >= pos
+        const int nz = __builtin_popcount(Z);
+        if (nz < st.zl) {                                         // the run outlives this word
+            st.zl -= nz;
+            if (ones) st.last1 = base + 31 - __builtin_clz(W);
+            break;
+        }
+        for (int i = 1; i < st.zl; i++) Z &= Z - 1u;              // the zl-th out-of-band sample closes the run
+        const int q = __builtin_ctz(Z);
+        const unsigned before = ones & ((1u << q) - 1u);          // in-band samples of [pos, z)
+        if (before) st.last1 = base + pos + 31 - __builtin_clz(before);
+        const int z = base + pos + q;
+        if ((unsigned)(z - st.start) >= st.thr) run_report(st, st.start, st.last1 + 1, p, my, max_segs);   // :448-454
+        st.in_run = 0;
+        pos += q + 1;
+    }
+}
+
+__global__ __launch_bounds__(64)
+void k_seg_walk3(const uint4 *__restrict__ mask2, int row16, const int32_t *__restrict__ len, int64_t stride,
+                 int nreads, WalkParams p, int32_t *__restrict__ segs, int32_t *__restrict__ nsegs, int max_segs)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r < nreads;
+    const int M = live ? min(max(len[r], 0), (int)min(stride, (int64_t)row16 * 64)) : 0;
+    const uint4 *mrow = mask2 + (int64_t)(live ? r : 0) * row16;
+    int32_t *my = segs + (int64_t)(live ? r : 0) * 2 * max_segs;
+
+    RunState st;
+    st.in_run = 0; st.zl = 0; st.start = 0; st.last1 = 0; st.nseg = 0; st.last_end = 0;
+    st.thr = (unsigned)min(p.window, p.first_len);
+    const int E1 = max(p.error, 0) + 1;
+
+    const int nent = (M + 63) >> 6;               // my entries
+    int nmax = nent;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+
+    unsigned long long qlo = 0ull, qhi = 0ull;    // bit queue: `fill` bits, oldest at bit 0 of qlo
+    int fill = 0, done = 0;                       // done: filtered samples already walked
+    for (int e0 = 0; e0 < nmax; e0 += 8) {
+        // eight entries = one 128-byte line of my row per visit (the rows of a wave's 64 lanes are 1 KB apart:
+        // fetching an entry at a time brings every line in from HBM three times over)
+        uint4 buf[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) buf[k] = (e0 + k < nent) ? mrow[e0 + k] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (e0 + k >= nmax) break;            // (wave-uniform)
+            if (e0 + k < nent) {
+                unsigned long long inb = ((unsigned long long)buf[k].y << 32) | buf[k].x;
+                unsigned long long kp = ((unsigned long long)buf[k].w << 32) | buf[k].z;
+                int cnt = 64;
+                if (kp != ~0ull) {                // the filter dropped samples here: squeeze their bits out
+                    if (kp == 0ull) { cnt = 0; kp = ~0ull; }
+                    const int hz = __builtin_clzll(kp);        // dropped samples at the top of the entry go at once
+                    if (hz > 0) { cnt -= hz; kp |= ~0ull << (64 - hz); }
+                    while (kp != ~0ull) {         // delete the lowest dropped sample's bit, close the gap
+                        const int pos = __builtin_ctzll(~kp);
+                        const unsigned long long below = (1ull << pos) - 1ull;
+                        inb = (inb & below) | ((inb >> 1) & ~below);
+                        kp = (kp & below) | ((kp >> 1) & ~below) | (1ull << 63);
+                        cnt--;
+                    }
+                    if (cnt < 64) inb &= (1ull << cnt) - 1ull;
+                }
+                if (fill == 0) { qlo = inb; qhi = 0ull; }
+                else { qlo |= inb << fill; qhi = inb >> (64 - fill); }
+                fill += cnt;
+            }
+            if (fill >= 64) {
+                run_word32(st, (unsigned)qlo, done, E1, p, my, max_segs);
+                run_word32(st, (unsigned)(qlo >> 32), done + 32, E1, p, my, max_segs);
+                done += 64; fill -= 64;
+                qlo = qhi; qhi = 0ull;
+            }
+        }
+    }
+    // the last fill (< 64) samples: slots past the read's end count as in band -- they can extend an open run
+    // (which is dropped at EOF either way, :466) but never close one, and a run opening there never closes
+    if (fill > 0) {
+        const unsigned long long w = qlo | (~0ull << fill);
+        run_word32(st, (unsigned)w, done, E1, p, my, max_segs);
+        run_word32(st, (unsigned)(w >> 32), done + 32, E1, p, my, max_segs);
+    }
+    if (live) nsegs[r] = st.nseg;
+}
+
 typedef void (*segstat_fn)(const SegStatArgs);
 
 segstat_fn pick_stats(int NT, int nbins)
@@ -491,9 +621,8 @@ bool sk_segment_fast_applies(const void *d_sig, int64_t stride, int32_t lo, int3
 }
 
 // Streaming statistics, the numpy-order redo of the (almost always empty) list of uncertified reads, then the walk.
-// Large batches go in chunks (SK_SEG_CHUNKS, default 4): the walk of chunk i runs on a second stream beside the
-// statistics of chunk i + 1 -- one is a stream of HBM loads with vector work in between, the other pure vector
-// work on 1/64th as many wavefronts.
+// With SK_SEG_CHUNKS > 1 the batch goes in chunks and the walk of chunk i runs on a second stream beside the
+// statistics of chunk i + 1 (kept as a switch; it does not pay, see below).
 // d_retry: nreads + 16 ints (per chunk: [0] = count, [1 ..] = list; zeroed here).  Records ev[0..3] like the
 // other segment paths: ev[0]..ev[1] statistics of all chunks, ev[2]..ev[3] what is left of the walks after that.
 int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
@@ -518,7 +647,10 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
     const bool fast = wp.error < wp.corrector && wp.window >= 1 && wp.first_len >= 1 &&
                       getenv("SK_WALK_GENERAL") == nullptr;
 
-    int nchunks = 4;
+    const bool by_runs = getenv("SK_WALK_STEP") == nullptr;       // A/B switch: the per-sample straight-line walk
+    // (measured: the two kernels are both vector-issue bound, so running them side by side gains nothing --
+    // 3.35 / 3.33 / 3.38 / 3.78 ms for 1 / 2 / 4 / 8 chunks per 1 M reads; one chunk is the default)
+    int nchunks = 1;
     if (const char *e = getenv("SK_SEG_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 8) nchunks = v; }
     if (nreads < 65536) nchunks = 1;
     if (nchunks > 1 && !c->stream2) {
@@ -562,7 +694,10 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
             SK_HIP(hipEventRecord(c->ev[2], c->stream));
         }
         const int wgrid = (nr + 63) / 64;
-        if (fast)
+        if (fast && by_runs)
+            hipLaunchKernelGGL(k_seg_walk3, dim3(wgrid), dim3(64), 0, ws, (const uint4 *)a.mask2, a.row16,
+                               a.len, stride, nr, wp, d_segs + (int64_t)r0 * 2 * max_segs, d_nsegs + r0, max_segs);
+        else if (fast)
             hipLaunchKernelGGL(k_seg_walk2<true>, dim3(wgrid), dim3(64), 0, ws, (const uint4 *)a.mask2, a.row16,
                                a.len, stride, nr, wp, d_segs + (int64_t)r0 * 2 * max_segs, d_nsegs + r0, max_segs);
         else

@@ -188,11 +188,13 @@ def test_streaming_statistics_path_vs_oracle(gpu, ora):
 
 def test_streaming_path_retry_list_and_old_kernels_agree(gpu, ora, monkeypatch):
     """SK_SEG_DELTA_SCALE widens the certification margin until (nearly) every read fails it, so the numpy-order
-    redo of listed reads is what produces the masks; SK_SEG_OLD runs the numpy-order kernels for everything.
-    All three must give the oracle's segments."""
+    redo of listed reads is what produces the masks; SK_SEG_OLD runs the numpy-order kernels for everything;
+    SK_WALK_STEP takes the per-sample walk instead of the run-hopping one; SK_SEG_CHUNKS overlaps walk and
+    statistics on two streams.  All must give the oracle's segments."""
     from squigglekit_amd import api
     sig, lens = _streaming_cases(np.random.default_rng(7))
-    for env, val in (("SK_SEG_DELTA_SCALE", "1e13"), ("SK_SEG_DELTA_SCALE", "3e10"), ("SK_SEG_OLD", "1")):
+    for env, val in (("SK_SEG_DELTA_SCALE", "1e13"), ("SK_SEG_DELTA_SCALE", "3e10"), ("SK_SEG_OLD", "1"),
+                     ("SK_WALK_STEP", "1"), ("SK_SEG_CHUNKS", "3")):
         monkeypatch.setenv(env, val)
         for kw in STREAM_PARAMS[:9]:
             _check_vs_oracle(api, ora, sig, lens, kw, "%s=%s" % (env, val))
