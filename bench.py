@@ -437,33 +437,39 @@ def extras_single_gpu(a, L, main):
                 del os.environ["SK_DTW_SCHEME"]
         ex["reads"] = Rx
         out["exact_only_reads_per_s"] = ex
-    # ---- end to end: host (pageable numpy) buffers in, host records out, PCIe included -----------------------
-    Rh = min(main.R, 400_000)
-    host = np.empty((Rh, main.stride), dtype=np.int16)
-    check(L.sk_dev_download(ptr(host), main.d_sig, host.nbytes))
-    lens = main.lens[:Rh]
-    e2e = {"reads": Rh, "note": "sk_*_batch_i16 on pageable host arrays: H2D + kernels + D2H, wall clock; "
-                                "PCIe Gen5 x16 ceiling ~63 GB/s = 7.9 M reads/s at 8 KB per read"}
-    hits = np.zeros(Rh, dtype=HIT_DTYPE)
-    ts = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        check(L.sk_motifseq_batch_i16(ptr(host), main.stride, ptr(lens), Rh, ptr(main.motif), main.N, main.mode,
-                                      0, 1200, ptr(hits)))
-        ts.append(time.perf_counter() - t0)
-    e2e["motifseq_reads_per_s"] = Rh / min(ts[1:])
+    # ---- end to end: host buffers in, host records out, PCIe included --------------------------------------------
+    # (sub-batches: the H2D copy of one runs under the kernels of the previous one -- csrc/sk_api.hip)
+    from squigglekit_amd import api
     from squigglekit_amd._lib import SegParams
+    Rh = min(main.R, 400_000)
+    e2e = {"reads": Rh, "note": "sk_*_batch_i16 on host arrays: H2D + kernels + D2H, wall clock, best of 3 after a "
+                                "warm-up call; pageable = ordinary numpy memory, pinned = api.pinned_empty() "
+                                "(sk_host_alloc); PCIe Gen5 x16 ceiling ~63 GB/s = 7.9 M reads/s at 8 KB per read"}
+    lens = main.lens[:Rh]
+    lens_s = (lens - 1).astype(np.int32)
+    hits = np.zeros(Rh, dtype=HIT_DTYPE)
     segs = np.zeros((Rh, MAX_SEGS, 2), dtype=np.int32)
     nsegs = np.zeros(Rh, dtype=np.int32)
     sp = SegParams()
-    lens_s = (lens - 1).astype(np.int32)
-    ts = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        check(L.sk_segment_batch_i16(ptr(host), main.stride, ptr(lens_s), Rh, C.byref(sp), ptr(segs), ptr(nsegs),
-                                     MAX_SEGS))
-        ts.append(time.perf_counter() - t0)
-    e2e["segmenter_reads_per_s"] = Rh / min(ts[1:])
+    for kind in ("pageable", "pinned"):
+        host = (np.empty((Rh, main.stride), dtype=np.int16) if kind == "pageable"
+                else api.pinned_empty((Rh, main.stride), np.int16))
+        check(L.sk_dev_download(ptr(host), main.d_sig, host.nbytes))
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            check(L.sk_motifseq_batch_i16(ptr(host), main.stride, ptr(lens), Rh, ptr(main.motif), main.N, main.mode,
+                                          0, 1200, ptr(hits)))
+            ts.append(time.perf_counter() - t0)
+        e2e["motifseq_%s_reads_per_s" % kind] = Rh / min(ts[1:])
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            check(L.sk_segment_batch_i16(ptr(host), main.stride, ptr(lens_s), Rh, C.byref(sp), ptr(segs), ptr(nsegs),
+                                         MAX_SEGS))
+            ts.append(time.perf_counter() - t0)
+        e2e["segmenter_%s_reads_per_s" % kind] = Rh / min(ts[1:])
+        del host
     out["end_to_end"] = e2e
     return out
 

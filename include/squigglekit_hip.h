@@ -93,6 +93,14 @@ int   sk_dev_free(void *dptr);
 int   sk_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
 int   sk_dev_download(void *dst_host, const void *src_dev, size_t bytes);
 
+/* ---- pinned host memory (optional, for the host entry points) ---------- */
+/* The host entry points (sk_*_batch_*) move a large batch in sub-batches, the H2D copy of one under the kernels
+ * of the previous one.  With ordinary (pageable) caller memory the copies are staged by the HIP runtime; buffers
+ * from sk_host_alloc() are page-locked and go by DMA at PCIe speed.  Either kind may be passed anywhere a host
+ * pointer is expected. */
+void *sk_host_alloc(size_t bytes);          /* NULL on failure                            */
+int   sk_host_free(void *hptr);
+
 /* ---- segmenter path --------------------------------------------------- */
 /* Replaces, per read r: scale_outliers(sig) (segmenter.py:209,311-318) then
  * get_segs(sig, args) (segmenter.py:211,399-470).

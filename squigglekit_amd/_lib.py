@@ -90,6 +90,8 @@ ABI = {
     "sk_dev_free": (C.c_int, [_vp]),
     "sk_dev_upload": (C.c_int, [_vp, _vp, C.c_size_t]),
     "sk_dev_download": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "sk_host_alloc": (_vp, [C.c_size_t]),
+    "sk_host_free": (C.c_int, [_vp]),
     "sk_segment_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, C.POINTER(SegParams),
                                        _vp, _vp, C.c_int32]),
     "sk_segment_batch_f64": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(SegParams), _vp, _vp, C.c_int32]),

@@ -39,6 +39,25 @@ def _devs(devices):
 
 
 # ----------------------------------------------------------------------------
+# pinned host buffers
+# ----------------------------------------------------------------------------
+def pinned_empty(shape, dtype=np.int16):
+    """A numpy array in page-locked host memory (sk_host_alloc): the batch calls copy from it by DMA at PCIe
+    speed, under the kernels of the previous sub-batch.  Freed when the array (and every view of it) is gone."""
+    import weakref
+    L = _lib.ensure_init()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = L.sk_host_alloc(max(1, n))
+    if not p:
+        check(-4)
+    raw = (C.c_char * max(1, n)).from_address(p)
+    arr = np.frombuffer(raw, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    weakref.finalize(raw, L.sk_host_free, C.c_void_p(p))
+    return arr
+
+
+# ----------------------------------------------------------------------------
 # packing helpers
 # ----------------------------------------------------------------------------
 def pack_i16(reads):

@@ -57,9 +57,61 @@ __global__ void k_normalise_f64(const double *__restrict__ comp, const sk_prep *
         out[i] = ((comp[i] - pr.center) - pr.top) / pr.scale - pr.bot;   // top / bot: sklearn's re-centring, 0 unless applied
 }
 
+// The host entry points move a large batch in sub-batches: the H2D copy of sub-batch k + 1 (second stream) runs
+// under the kernels of sub-batch k.  Pageable caller memory: hipMemcpyAsync stages it and returns, the kernels
+// launched before keep running meanwhile.  Memory from sk_host_alloc() (pinned): plain DMA at PCIe speed.
+struct SubBatches {
+    int32_t per = 0, n = 1;
+};
+SubBatches sub_batches(int32_t nreads, int64_t stride)
+{
+    SubBatches sb;
+    int64_t target = (int64_t)256 << 20;                    // bytes of samples per sub-batch
+    if (const char *e = getenv("SK_INGEST_MB")) { const long v = atol(e); if (v > 0) target = (int64_t)v << 20; }
+    int64_t per = target / (stride * (int64_t)sizeof(int16_t));
+    if (per < 4096) per = 4096;
+    if (per * 2 > nreads) { sb.per = nreads; sb.n = 1; return sb; }
+    sb.n = (int32_t)((nreads + per - 1) / per);
+    sb.per = (int32_t)(((int64_t)nreads + sb.n - 1) / sb.n);
+    return sb;
+}
+
+int second_stream(sk_ctx *c)
+{
+    if (!c->stream2) {
+        SK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 9; i++) SK_HIP(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
+    }
+    return SK_OK;
+}
+
+int motifseq_dev(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                 const double *motif, int32_t nmotif, int32_t scale_mode, int32_t scale_low, int32_t scale_hi,
+                 sk_hit *d_out, int accumulate);
+
 } // namespace
 
 extern "C" {
+
+// ------------------------------------------------------------------ pinned host memory for callers
+void *sk_host_alloc(size_t bytes)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return nullptr;
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        sk_fail(SK_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+int sk_host_free(void *p)
+{
+    if (p) SK_HIP(hipHostFree(p));
+    return SK_OK;
+}
 
 // ------------------------------------------------------------------ MotifSeq, device resident
 int sk_motifseq_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
@@ -68,6 +120,17 @@ int sk_motifseq_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_l
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    return motifseq_dev(c, d_sig, stride, d_len, nreads, motif, nmotif, scale_mode, scale_low, scale_hi, d_out, 0);
+}
+
+} // extern "C"
+
+namespace {
+
+int motifseq_dev(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                 const double *motif, int32_t nmotif, int32_t scale_mode, int32_t scale_low, int32_t scale_hi,
+                 sk_hit *d_out, int accumulate)
+{
     int rc = check_i16(d_sig, stride, d_len, nreads);
     if (rc) return rc;
     if (!motif || nmotif <= 0) return sk_fail(SK_ERR_INVALID, "empty motif");
@@ -89,12 +152,16 @@ int sk_motifseq_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_l
     sk_sdtw_args a;
     a.feed = SK_FEED_I16; a.samples = c->comp.p; a.stride = stride; a.off = nullptr;
     a.prep = (const sk_prep *)c->prep.p; a.nreads = nreads; a.motif = motif; a.nmotif = nmotif;
-    a.out = d_out; a.last_row = nullptr; a.max_len = stride; a.force_single = 0;
+    a.out = d_out; a.last_row = nullptr; a.max_len = stride; a.force_single = 0; a.accumulate = accumulate;
     rc = sk_launch_sdtw(c, &a);
     if (rc) return rc;
     c->ev_valid = true;
     return SK_OK;
 }
+
+} // namespace
+
+extern "C" {
 
 // ------------------------------------------------------------------ MotifSeq, host buffers
 int sk_motifseq_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
@@ -112,11 +179,26 @@ int sk_motifseq_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len
     if ((rc = sk_reserve(c, &c->sig, sb))) return rc;
     if ((rc = sk_reserve(c, &c->len, (size_t)nreads * sizeof(int32_t)))) return rc;
     if ((rc = sk_reserve(c, &c->out, (size_t)nreads * sizeof(sk_hit)))) return rc;
-    SK_HIP(hipMemcpyAsync(c->sig.p, sig, sb, hipMemcpyHostToDevice, c->stream));
-    SK_HIP(hipMemcpyAsync(c->len.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    rc = sk_motifseq_dev_i16((const int16_t *)c->sig.p, stride, (const int32_t *)c->len.p, nreads, motif,
-                             nmotif, scale_mode, scale_low, scale_hi, (sk_hit *)c->out.p);
-    if (rc) return rc;
+    const SubBatches B = sub_batches(nreads, stride);
+    if (B.n > 1 && (rc = second_stream(c))) return rc;
+    for (int32_t bi = 0; bi < B.n; bi++) {
+        const int32_t r0 = bi * B.per;
+        const int32_t nr = (nreads - r0 < B.per) ? nreads - r0 : B.per;
+        if (nr <= 0) break;
+        int16_t *d_sig = (int16_t *)c->sig.p + (size_t)r0 * (size_t)stride;
+        int32_t *d_len = (int32_t *)c->len.p + r0;
+        hipStream_t cs = (B.n > 1) ? c->stream2 : c->stream;
+        SK_HIP(hipMemcpyAsync(d_sig, sig + (size_t)r0 * (size_t)stride, (size_t)nr * (size_t)stride * sizeof(int16_t),
+                              hipMemcpyHostToDevice, cs));
+        SK_HIP(hipMemcpyAsync(d_len, len + r0, (size_t)nr * sizeof(int32_t), hipMemcpyHostToDevice, cs));
+        if (B.n > 1) {                                      // the kernels of this sub-batch wait for its copy only
+            SK_HIP(hipEventRecord(c->ev_chunk[bi & 7], cs));
+            SK_HIP(hipStreamWaitEvent(c->stream, c->ev_chunk[bi & 7], 0));
+        }
+        rc = motifseq_dev(c, d_sig, stride, d_len, nr, motif, nmotif, scale_mode, scale_low, scale_hi,
+                          (sk_hit *)c->out.p + r0, bi > 0);
+        if (rc) return rc;
+    }
     SK_HIP(hipMemcpyAsync(out, c->out.p, (size_t)nreads * sizeof(sk_hit), hipMemcpyDeviceToHost, c->stream));
     SK_HIP(hipStreamSynchronize(c->stream));
     return SK_OK;
@@ -431,11 +513,26 @@ int sk_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len,
     if ((rc = sk_reserve(c, &c->len, (size_t)nreads * sizeof(int32_t)))) return rc;
     if ((rc = sk_reserve(c, &c->out, gb))) return rc;
     if ((rc = sk_reserve(c, &c->out2, (size_t)nreads * sizeof(int32_t)))) return rc;
-    SK_HIP(hipMemcpyAsync(c->sig.p, sig, sb, hipMemcpyHostToDevice, c->stream));
-    SK_HIP(hipMemcpyAsync(c->len.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    rc = sk_segment_dev_i16((const int16_t *)c->sig.p, stride, (const int32_t *)c->len.p, nreads, p,
-                            (int32_t *)c->out.p, (int32_t *)c->out2.p, max_segs);
-    if (rc) return rc;
+    const SubBatches B = sub_batches(nreads, stride);
+    if (B.n > 1 && (rc = second_stream(c))) return rc;
+    for (int32_t bi = 0; bi < B.n; bi++) {
+        const int32_t r0 = bi * B.per;
+        const int32_t nr = (nreads - r0 < B.per) ? nreads - r0 : B.per;
+        if (nr <= 0) break;
+        int16_t *d_sig = (int16_t *)c->sig.p + (size_t)r0 * (size_t)stride;
+        int32_t *d_len = (int32_t *)c->len.p + r0;
+        hipStream_t cs = (B.n > 1) ? c->stream2 : c->stream;
+        SK_HIP(hipMemcpyAsync(d_sig, sig + (size_t)r0 * (size_t)stride, (size_t)nr * (size_t)stride * sizeof(int16_t),
+                              hipMemcpyHostToDevice, cs));
+        SK_HIP(hipMemcpyAsync(d_len, len + r0, (size_t)nr * sizeof(int32_t), hipMemcpyHostToDevice, cs));
+        if (B.n > 1) {
+            SK_HIP(hipEventRecord(c->ev_chunk[bi & 7], cs));
+            SK_HIP(hipStreamWaitEvent(c->stream, c->ev_chunk[bi & 7], 0));
+        }
+        rc = sk_segment_dev_i16(d_sig, stride, d_len, nr, p, (int32_t *)c->out.p + (size_t)r0 * 2 * (size_t)max_segs,
+                                (int32_t *)c->out2.p + r0, max_segs);
+        if (rc) return rc;
+    }
     SK_HIP(hipMemcpyAsync(segs, c->out.p, gb, hipMemcpyDeviceToHost, c->stream));
     SK_HIP(hipMemcpyAsync(nsegs, c->out2.p, (size_t)nreads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     SK_HIP(hipStreamSynchronize(c->stream));

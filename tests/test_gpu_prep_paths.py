@@ -108,3 +108,36 @@ def test_segmenter_wide_limits_route_to_f64(gpu, ora):
     assert np.array_equal(nsegs, onsegs)
     for r in range(24):
         assert np.array_equal(segs[r, :nsegs[r]], osegs[r, :nsegs[r]]), r
+
+
+def test_pipelined_ingest_sub_batches_and_pinned_buffers(gpu, ora, monkeypatch):
+    """The host entry points move big batches in sub-batches (copy of one under the kernels of the previous one).
+    SK_INGEST_MB=1 forces many sub-batches on a small batch; pageable and pinned (api.pinned_empty) sources must
+    give the same records as the single-shot call and the oracle, retry counts summed over sub-batches."""
+    from squigglekit_amd import api, synth
+    L = gpu.load()
+    motif = synth.synthetic_motif(150, seed=21)
+    R, M = 9000, 2000
+    sig = synth.squiggle_batch(R, M, 777001, motif=motif)
+    lens = np.full(R, M, dtype=np.int32)
+    lens[::13] = 1234
+    one = api.motifseq_batch(sig, lens, motif)
+    segs1, nsegs1 = api.segment_batch(sig, lens - 1)
+    monkeypatch.setenv("SK_INGEST_MB", "1")                 # 4 096 reads per sub-batch -> 3 sub-batches
+    monkeypatch.setenv("SK_DTW_SPAN", "30")                 # many retries, so the summed count is visible
+    ref = api.motifseq_batch(sig[:4096], lens[:4096], motif)
+    r_first = L.sk_last_dtw_retries()
+    got = api.motifseq_batch(sig, lens, motif)
+    r_all = L.sk_last_dtw_retries()
+    assert got.tobytes() == one.tobytes() and ref.tobytes() == one[:4096].tobytes()
+    assert r_first > 100 and r_all > 2 * r_first            # summed over the sub-batches of one call
+    monkeypatch.delenv("SK_DTW_SPAN")
+    pin = api.pinned_empty(sig.shape, np.int16)
+    pin[:] = sig
+    got2 = api.motifseq_batch(pin, lens, motif)
+    segs2, nsegs2 = api.segment_batch(pin, lens - 1)
+    assert got2.tobytes() == one.tobytes()
+    assert np.array_equal(segs2, segs1) and np.array_equal(nsegs2, nsegs1)
+    want = ora.motifseq_batch_i16(sig[8990:], lens[8990:], motif)
+    assert np.array_equal(got["dist"][8990:], want["dist"]) and np.array_equal(got["start"][8990:], want["start"])
+    del pin
