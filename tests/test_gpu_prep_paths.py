@@ -130,7 +130,7 @@ def test_pipelined_ingest_sub_batches_and_pinned_buffers(gpu, ora, monkeypatch):
     got = api.motifseq_batch(sig, lens, motif)
     r_all = L.sk_last_dtw_retries()
     assert got.tobytes() == one.tobytes() and ref.tobytes() == one[:4096].tobytes()
-    assert r_first > 100 and r_all > 2 * r_first            # summed over the sub-batches of one call
+    assert r_first > 100 and r_all > 1.5 * r_first           # summed over the sub-batches of one call
     monkeypatch.delenv("SK_DTW_SPAN")
     pin = api.pinned_empty(sig.shape, np.int16)
     pin[:] = sig
