@@ -3,7 +3,9 @@
 Same flags, the same stderr banner, the same 12/13-column TSV on stdout.  Per read,
 scale_outliers + medmad/zscale + dtw_subsequence run on the GPU (batched, C ABI);
 the scoring of MotifSeq.py:441-445 stays in Python so the printed floats are the
-reference's digit for digit.  Additive flags: --device, --batch, --strict-compat.
+reference's digit for digit.  fast5 input (-f / -p) goes through h5py when it is importable and
+through the built-in reader (hdf5min.py) otherwise, with the reference's stderr messages.
+Additive flags: --device, --gpus, --batch, --after_stall, --strict-compat.
 """
 import argparse
 import os
@@ -34,8 +36,8 @@ def build_parser():
     p = _Parser(description="MotifSeq (MI355X) - find a sequence motif's signal inside raw nanopore reads")
     src = p.add_mutually_exclusive_group()
     mod = p.add_mutually_exclusive_group()
-    src.add_argument("-f", "--f5f", help="text file listing fast5 paths (needs h5py)")
-    src.add_argument("-p", "--f5_path", help="directory searched recursively for fast5 files (needs h5py)")
+    src.add_argument("-f", "--f5f", help="text file listing fast5 paths")
+    src.add_argument("-p", "--f5_path", help="directory searched recursively for fast5 files")
     src.add_argument("-s", "--signal", help="signal TSV written by SquigglePull (.gz accepted)")
     p.add_argument("-l", "--scale", default="medmad", choices=["zscale", "medmad"],
                    help="per-read normalisation applied before the search")
@@ -83,6 +85,9 @@ def load_models(args):
         models, order, lens = tsvio.read_model_auto(args.model)
         if args.strict_compat:
             order, lens = [], []                     # MotifSeq.py:413-428 never fills them
+        elif order:
+            sys.stderr.write("MotifSeq: note: -m searches for the model's motif(s); the reference's read_bait_model "
+                             "never registers them and prints the header only (--strict-compat reproduces that)\n")
         return models, order, lens
     if args.fasta_input:
         try:
@@ -141,6 +146,10 @@ class _Batcher:
                 if h["flags"] & 1:
                     sys.stderr.write("MotifSeq: no sample of {} survived the outlier limits; skipped\n".format(read_id))
                     break
+                if h["flags"] & 2:                                      # SK_FLAG_DEGENERATE
+                    sys.stderr.write("MotifSeq: the MAD of {} is 0 (medmad divides by it, MotifSeq.py:196-199); "
+                                     "skipped\n".format(read_id))
+                    break
                 dist, start, end = float(h["dist"]), int(h["start"]), int(h["end"])
                 mod_mean = (a.slope * self.lens[c]) + a.intercept
                 mod_stdev = mod_mean * a.std_const
@@ -184,9 +193,6 @@ def main(argv=None):
         sys.stderr.write("Unknown file or path input")
         parser.print_help(sys.stderr)
         sys.exit(1)
-    if (args.f5f or args.f5_path) and not tsvio.have_h5py():
-        sys.stderr.write("MotifSeq: fast5 input needs h5py, which is not installed; use -s <SquigglePull TSV>\n")
-        sys.exit(1)
     if not order:                                    # nothing to search for: header only
         return
 
@@ -214,12 +220,12 @@ def main(argv=None):
             files = [os.path.join(d, f) for d, _, fs in os.walk(args.f5_path) for f in fs if f.endswith(".fast5")]
         for path in files:
             fast5 = path.split("/")[-1]
-            try:
-                sig, read_id = tsvio.read_single_fast5(path, raw_signal=True)     # MotifSeq.py:326-345: raw ints
-            except Exception:
-                sig, read_id = [], ""
+            sig, read_id = tsvio.motifseq_process_fast5(path, sys.stderr)          # MotifSeq.py:180,211,327-350
             if not len(sig):
-                out.note("Failed to extract signal: {} {}\n".format(path, fast5))
+                if args.f5f:
+                    out.note("Failed to extract signal: {} {}\n".format(path, fast5))              # MotifSeq.py:182
+                else:
+                    out.note("main():data not extracted. Moving to next file - {}\n".format(path))  # MotifSeq.py:213
                 continue
             out.add(fast5, read_id, np.array(sig, dtype=int))
     out.flush()

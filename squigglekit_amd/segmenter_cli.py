@@ -25,8 +25,8 @@ class _Parser(argparse.ArgumentParser):
 def build_parser():
     p = _Parser(description="segmenter (MI355X) - find stall / homopolymer stretches in squiggle data")
     src = p.add_mutually_exclusive_group()
-    src.add_argument("-i", "--ind", nargs="+", help="one or more fast5 files (needs h5py)")
-    src.add_argument("-p", "--f5_path", help="directory searched recursively for fast5 files (needs h5py)")
+    src.add_argument("-i", "--ind", nargs="+", help="one or more fast5 files")
+    src.add_argument("-p", "--f5_path", help="directory searched recursively for fast5 files")
     src.add_argument("-s", "--signal", help="signal TSV written by SquigglePull (.gz accepted)")
     src.add_argument("--blow5", help="[extension] BLOW5 file (uncompressed or zlib records)")
     p.add_argument("--single", action="store_true", help="fast5 files hold one read each")
@@ -110,11 +110,6 @@ def main(argv=None):
     if args.view:
         sys.stderr.write("segmenter: -v/--view plotting is not part of this build; ignoring\n")
 
-    fast5_mode = bool(args.f5_path or args.ind)
-    if fast5_mode and not tsvio.have_h5py():
-        sys.stderr.write("segmenter: fast5 input needs h5py, which is not installed; "
-                         "use -s <SquigglePull TSV> or --blow5\n")
-        sys.exit(1)
     if not (args.f5_path or args.ind or args.signal or args.blow5):
         sys.stderr.write("Unknown file or path input")
         parser.print_help(sys.stderr)
@@ -153,7 +148,7 @@ def main(argv=None):
         for path in files:
             label = os.path.basename(path) if args.f5_path else path
             if args.single:
-                sig, _ = tsvio.read_single_fast5(path, args.raw_signal)
+                sig = tsvio.segmenter_process_fast5(path, args.raw_signal, sys.stderr)   # segmenter.py:146,262
                 if not np.asarray(sig).any():
                     out.note("main():data not extracted. Moving to next file: {}".format(label))
                     continue

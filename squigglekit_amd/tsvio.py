@@ -178,7 +178,7 @@ def fasta_to_models(path, scrappie_model):
 
 
 # ----------------------------------------------------------------------------
-# fast5 (only when h5py exists; HDF5 is out of this build's scope otherwise)
+# fast5: h5py when it is importable, else the built-in reader (hdf5min.py)
 # ----------------------------------------------------------------------------
 def _h5py():
     try:
@@ -192,15 +192,24 @@ def have_h5py():
     return _h5py() is not None
 
 
+def open_fast5(path):
+    """An h5py.File-shaped handle (groups by name, keys(), Dataset[()], attrs)."""
+    h5py = _h5py()
+    if h5py is not None:
+        return h5py.File(path, "r")
+    from . import hdf5min
+    return hdf5min.File(path)
+
+
 def pA(raw, digitisation, range_, offset):
     """convert_to_pA_numpy + round (segmenter.py:515-517,347-349)."""
     return np.round((np.asarray(raw, dtype=int) + offset) * (range_ / digitisation), 2)
 
 
 def read_single_fast5(path, raw_signal):
-    """segmenter.process_fast5 (segmenter.py:321-356): (signal, read_id)."""
-    h5py = _h5py()
-    with h5py.File(path, "r") as hdf:
+    """segmenter.process_fast5 (segmenter.py:321-356): (signal, read_id).  Exceptions propagate; the *_cli
+    wrappers below reproduce the reference's try/except messages."""
+    with open_fast5(path) as hdf:
         key = list(hdf["Raw/Reads"].keys())[0]
         read = hdf["Raw/Reads/"][key]
         sig = np.array(read["Signal"][()], dtype=int)
@@ -212,15 +221,75 @@ def read_single_fast5(path, raw_signal):
     return sig, rid
 
 
-def read_multi_fast5(path, raw_signal):
-    """segmenter.get_multi_fast5_signal (segmenter.py:358-396): {read_name: signal}."""
-    h5py = _h5py()
-    out = {}
-    with h5py.File(path, "r") as hdf:
-        for read in list(hdf.keys()):
-            sig = np.array(hdf[read]["Raw/Signal"][()], dtype=int)
+def segmenter_process_fast5(path, raw_signal, err):
+    """segmenter.process_fast5 with its error handling (segmenter.py:326-355): a traceback plus one of two
+    messages (no newline, like the reference) on `err`, and an empty signal."""
+    import traceback
+    try:
+        hdf = open_fast5(path)
+    except Exception:
+        traceback.print_exc(file=err)
+        err.write("process_fast5():fast5 file failed to open: {}".format(path))
+        return np.array([])
+    try:
+        with hdf:
+            key = list(hdf["Raw/Reads"].keys())[0]
+            read = hdf["Raw/Reads/"][key]
+            sig = np.array(read["Signal"][()], dtype=int)
+            read.attrs["read_id"].decode()
+            ch = hdf["UniqueGlobalKey/channel_id"].attrs
+            dig, off, rng = ch["digitisation"], ch["offset"], float("{0:.2f}".format(ch["range"]))
             if not raw_signal:
+                sig = pA(sig, dig, rng, off)
+        return sig
+    except Exception:
+        traceback.print_exc(file=err)
+        err.write("process_fast5():failed to extract events or fastq from: {}".format(path))
+        return np.array([])
+
+
+def motifseq_process_fast5(path, err):
+    """MotifSeq.process_fast5 (MotifSeq.py:327-350): (list of ints, read_id as the attribute holds it -- bytes,
+    which the reference then formats with "{}" -- ); on failure a traceback, the reference's message and ([], "")."""
+    import traceback
+    try:
+        hdf = open_fast5(path)
+    except Exception:
+        traceback.print_exc(file=err)
+        err.write("process_fast5():fast5 file failed to open: {}\n".format(path))
+        return [], ""
+    try:
+        with hdf:
+            key = list(hdf["Raw/Reads"].keys())[0]
+            read = hdf["Raw/Reads/"][key]
+            squig = [int(v) for v in read["Signal"][()]]
+            return squig, read.attrs["read_id"]
+    except Exception:
+        traceback.print_exc(file=err)
+        err.write("process_fast5():failed to extract events or fastq from: {}\n".format(path))
+        return [], ""
+
+
+def read_multi_fast5(path, raw_signal, err=None):
+    """segmenter.get_multi_fast5_signal (segmenter.py:358-396): {read_name: signal}; a read that cannot be
+    extracted gets a traceback + message on `err` and an empty signal, like the reference."""
+    import sys
+    import traceback
+    err = err or sys.stderr
+    out = {}
+    with open_fast5(path) as hdf:
+        for read in list(hdf.keys()):
+            try:
+                hdf[read]["Raw"].attrs["read_id"].decode()
                 ch = hdf[read]["channel_id"].attrs
-                sig = pA(sig, ch["digitisation"], float("{0:.2f}".format(ch["range"])), ch["offset"])
+                dig, off, rng = ch["digitisation"], ch["offset"], float("{0:.2f}".format(ch["range"]))
+                ch["sampling_rate"]
+                sig = np.array(hdf[read]["Raw/Signal"][()], dtype=int)
+                if not raw_signal:
+                    sig = pA(sig, dig, rng, off)
+            except Exception:
+                traceback.print_exc(file=err)
+                err.write("extract_fast5():failed to read readID: {}".format(read))
+                sig = np.array([], dtype=int)
             out[read] = sig
     return out

@@ -216,3 +216,19 @@ def test_gz_and_error_paths(oracle_backend, tsv_files, tmp_path):
     assert so == so0 and so.count("\n") >= 5
     so, se, code = run_cli(main, ["--bogus"])
     assert code == 2 and se.startswith("error: ")
+
+
+@pytest.mark.gpu
+def test_motifseq_cli_constant_read_is_reported_not_printed(gpu, tmp_path):
+    """A read whose MAD is 0 (medmad divides by it, MotifSeq.py:196-199): the library flags it
+    (SK_FLAG_DEGENERATE) and the CLI says so on stderr instead of printing a row of inf / nan."""
+    from squigglekit_amd.motifseq_cli import main
+    p = tmp_path / "const.tsv"
+    good = (np.arange(3000) % 97 + 400).tolist()
+    p.write_text("\t".join(["a.fast5", "flat"] + ["c%d" % i for i in range(6)] + ["500"] * 2000) + "\n"
+                 + "\t".join(["b.fast5", "fine"] + ["c%d" % i for i in range(6)] + [str(v) for v in good]) + "\n")
+    so, se, code = run_cli(main, ["-s", str(p), "-m", os.path.join(GOLD, "CATCTATCCAGGGTTAAATT.model")])
+    rows = so.strip().split("\n")
+    assert code == 0 and len(rows) == 2 and rows[1].startswith("b.fast5\tfine\t")
+    assert "the MAD of flat is 0" in se and "flat" not in so
+    assert "note: -m searches for the model's motif(s)" in se
