@@ -57,6 +57,7 @@ struct sk_ctx {
     std::vector<double> motif64_host;
     sk_buf lastq;     // screening pass: last-row costs per column
     sk_buf qflag;     // screening pass: per-read "left the fixed-point range" flags
+    sk_buf wsoft;     // window pass: reads of the chunk that go to its second tier ([0] = count)
     sk_buf retry;     // DTW retry list: [0] = count, [1] = pad, [2 ..] = reads (segmenter: [0] = count, [1 ..] = reads)
     sk_buf dtwcnt;    // [0] = reads retried by the exact pass, summed over the launches of one API call (device)
     bool   retry_dev = false;   // the last DTW call left its retry count on the device (read lazily)
@@ -132,7 +133,7 @@ struct sk_sdtw_args {
 };
 int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a);
 // fixed-point screening + certified window over all reads (sk_sdtwq.hip); leaves the retry list on the device
-int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P, int ck, int span,
+int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P, int ck, int span, int span2,
                           int32_t *d_retry_cnt, int32_t *d_retry);
 
 // ---- dRNA --signal branch (rolling mean): statistics + masks (sk_prep.hip), scan (sk_segment.hip) ----

@@ -73,6 +73,11 @@ struct sdtw_kargs {
     int32_t       *qflag;       // [slot]: screening minimum of the read; QINF = a sample left the fixed-point range
     unsigned       qerr;        // E: bound (in units) on |screening cost - exact cost| of any cell
     int            wmax;        // widest candidate-column range the window pass accepts
+    // window pass, second tier: the reads of one chunk whose path crossed the first (short) look-back
+    const int32_t *wl_list;     // reads to process (nullptr: all of the chunk); wl_count: their number (device)
+    const int32_t *wl_count;
+    int32_t       *soft;        // where a read goes whose path crossed THIS look-back (nullptr: the exact retry list)
+    int32_t       *soft_cnt;
     // row-chunked motifs (MODE_CHAIN): the last row of the chunk above / of this chunk, per column
     const double  *prevD;       // [slot][row_stride] or nullptr (first chunk: virtual row -1)
     const int32_t *prevS;

@@ -230,9 +230,14 @@ void k_sdtw_w(const sdtw_kargs a)
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int g = lane / L, l = lane % L;
     int slot = wave * G + g;
-    const bool live = slot < a.nreads;
-    if (!live) slot = a.nreads - 1;
-    const int r = a.read0 + slot;
+    int nreads = a.nreads;
+    if (a.wl_count) {                               // second tier: the list length is only known on the device
+        nreads = min(*a.wl_count, a.nreads);
+        if (nreads <= 0) return;                    // (block-uniform)
+    }
+    const bool live = slot < nreads;
+    if (!live) slot = nreads - 1;
+    const int r = a.wl_list ? a.wl_list[slot] : a.read0 + slot;
 
     int n, flags = 0;
     double center = 0.0, scale = 1.0;
@@ -443,9 +448,10 @@ void k_sdtw_w(const sdtw_kargs a)
             h.dist = best; h.start = bestS; h.end = bestJ;
             a.out[r] = h;
         } else {
-            h.dist = __builtin_nan(""); h.start = -1; h.end = -1;    // overwritten by the retry pass
+            h.dist = __builtin_nan(""); h.start = -1; h.end = -1;    // overwritten by a later pass
             a.out[r] = h;
-            a.retry[atomicAdd(a.retry_cnt, 1)] = r;
+            if (screened && a.soft) a.soft[atomicAdd(a.soft_cnt, 1)] = r;   // path wider than this look-back: next tier
+            else                    a.retry[atomicAdd(a.retry_cnt, 1)] = r; // the exact single pass
         }
     }
 }
@@ -481,7 +487,9 @@ sdtw_fn pick(int feed, int L, int R)
 
 // Screening + certified window over all reads; fills out[] and the retry list (device).
 // The caller (sk_launch_sdtw) reads the retry count and runs the exact pass on those reads.
-int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P, int ck, int span,
+// span / span2: look-back of the window pass's first tier (every read) and of its second tier (the reads whose
+// optimal path turned out wider than `span`); span2 <= span: one tier only.
+int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P, int ck, int span, int span2,
                           int32_t *d_retry_cnt, int32_t *d_retry)
 {
     const int N = a->nmotif;
@@ -512,6 +520,8 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P,
     if ((rc = sk_reserve(c, &c->ckpt, (size_t)chunk * (size_t)(nck > 0 ? nck : 1) * L * (R + 2) * sizeof(unsigned)))) return rc;
     if ((rc = sk_reserve(c, &c->lastq, (size_t)chunk * lq_stride * sizeof(unsigned)))) return rc;
     if ((rc = sk_reserve(c, &c->qflag, (size_t)chunk * sizeof(int32_t)))) return rc;
+    const bool tiers = span2 > span;
+    if (tiers && (rc = sk_reserve(c, &c->wsoft, ((size_t)chunk + 1) * sizeof(int32_t)))) return rc;
 
     sdtw_fn fq = pick<0>(a->feed, L, R), fw = pick<1>(a->feed, L, R);
     if (!fq || !fw) return sk_fail(SK_ERR_UNSUPPORTED, "no screening kernel for L=%d R=%d", L, R);
@@ -543,6 +553,14 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P,
         hipLaunchKernelGGL(fq, dim3(grid), dim3(256), 0, c->stream, k);
         SK_HIP(hipGetLastError());
         SK_HIP(hipEventRecord(ev[1], c->stream));
+        if (tiers) {
+            int32_t *soft = (int32_t *)c->wsoft.p;
+            SK_HIP(hipMemsetAsync(soft, 0, sizeof(int32_t), c->stream));
+            k.span = span; k.wl_list = nullptr; k.wl_count = nullptr; k.soft = soft + 1; k.soft_cnt = soft;
+            hipLaunchKernelGGL(fw, dim3(grid), dim3(256), 0, c->stream, k);
+            SK_HIP(hipGetLastError());
+            k.span = span2; k.wl_list = soft + 1; k.wl_count = soft; k.soft = nullptr; k.soft_cnt = nullptr;
+        }
         hipLaunchKernelGGL(fw, dim3(grid), dim3(256), 0, c->stream, k);
         SK_HIP(hipGetLastError());
         SK_HIP(hipEventRecord(ev[2], c->stream));
