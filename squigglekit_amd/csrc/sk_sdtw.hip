@@ -466,12 +466,12 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     // Measured on the C4 workload: optimal paths are 0.4-1.06 N columns wide (median 0.46 N for
     // reads without the motif, 0.98 N with it); a path wider than the look-back only costs that
     // read an exact retry.
-    // Look-back in two tiers (screening scheme): every read first gets N + N/16 + 4 columns (optimal paths on the C4
+    // Look-back in two tiers (screening scheme): every read first gets N + 8 columns (optimal paths on the C4
     // workload are 0.4-1.0 N columns wide) and the reads whose path crossed that front are redone with 2 N + N/4 + 16 columns before anything falls back to the
     // exact single pass (measured, C4: window pass 19.3 ms per 1 M reads with one tier of N + N/8 + 8 columns,
     // 17.4 ms at N columns).  The exact two-pass scheme keeps one tier of N + N/8 + 8.
     int ck = 128;
-    int span = N + N / 8 + 8, span_q = N + N / 16 + 4, span2 = 2 * N + N / 4 + 16;
+    int span = N + N / 8 + 8, span_q = N + 8, span2 = 2 * N + N / 4 + 16;
     if (const char *e = getenv("SK_DTW_CK")) { int v = atoi(e); if (v >= 64 && v % 64 == 0) ck = v; }
     if (const char *e = getenv("SK_DTW_SPAN")) { int v = atoi(e); if (v > 0) { span = span_q = v; span2 = 0; } }
     if (const char *e = getenv("SK_DTW_SPAN2")) { int v = atoi(e); if (v >= 0) span2 = v; }
