@@ -391,7 +391,8 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
     const int r = rnext;                                   // the read (rk: its position in the launch / list)
     const int M = Mnext;
     const int16_t *row = sig + (int64_t)r * stride;
-    int16_t *crow = comp + (int64_t)r * stride;
+    // (LISTED without the LDS-resident copy: one scratch row per persistent workgroup is enough)
+    int16_t *crow = comp + (int64_t)(LISTED ? (int)blockIdx.x : r) * stride;
     if (dirty) for (int b = tid; b < nb4; b += TPB) hist[b] = 0u;
     dirty = false;
     if (tid < 4) sc->sel[tid] = 0;
@@ -994,9 +995,9 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
     const bool ldscomp = mode != SK_PREP_MEDMAD && lds + lds_comp <= 40 * 1024;
     if (ldscomp) lds += lds_comp;
     const bool windowed = t0 > 0 || t1 < 0x7fffffff;
-    if (listed && (!ldscomp || windowed || mode != SK_PREP_SEGMENT))
-        return sk_fail(SK_ERR_INVALID, "internal: listed prep needs the LDS-resident segmenter variant");
-    auto fn = listed ? k_prep_i16<true, false, false, true>
+    if (listed && (windowed || mode != SK_PREP_SEGMENT || (!ldscomp && d_comp == nullptr)))
+        return sk_fail(SK_ERR_INVALID, "internal: listed prep is the segmenter variant (scratch rows for long reads)");
+    auto fn = listed ? (ldscomp ? k_prep_i16<true, false, false, true> : k_prep_i16<false, false, false, true>)
               : (mode == SK_PREP_MEDMAD) ? k_prep_i16<false, false, true>
               : ldscomp ? (windowed ? k_prep_i16<true, true, false> : k_prep_i16<true, false, false>)
                         : (windowed ? k_prep_i16<false, true, false> : k_prep_i16<false, false, false>);

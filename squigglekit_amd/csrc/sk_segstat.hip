@@ -30,7 +30,8 @@
 namespace {
 
 constexpr int WPB = 4;                 // wavefronts (= reads in flight) per workgroup
-constexpr int MAXBINS = 2047;          // y = x - lo must keep (y << 2) inside 16 bits, and sum(y^2) inside 32
+constexpr int MAXBINS = 2047;          // t' = min(x - lo - 1, nbins) must keep (t' << 2) inside 16 bits, sum(t'^2) inside 32
+constexpr int MAXLONG = 1 << 20;       // longest read: n (n sum t^2) - (sum t)^2 stays inside 63 bits
 
 typedef short          s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -116,19 +117,22 @@ struct SegStatArgs {
     int32_t       *retry;            // [0] = count, [1 ..] = reads that could not be certified
 };
 
-// NT: 512-sample tiles held in registers (reads of up to 512 NT samples)
+// NT: 512-sample tiles held in registers (one "window" of 512 NT samples)
 // NQ: 16-byte histogram chunks per lane -- 256 NQ bins per wave
 // OCC: wavefronts per SIMD the register allocation is sized for
+// LONG: reads longer than one window.  The statistics need the whole read before any sample can be classified, so a
+//       long read is looked at twice, window by window: the second look re-reads it (L2 / Infinity Cache / HBM).
 //
 // Sample images.  t = (x - (lo + 1)) mod 2^16 is the sample's histogram bin: kept <=> t < nbins (hi <= 32768 makes
 // every dropped x land at t >= nbins, no aliasing), and t' = min(t, nbins) sends every dropped sample -- and the
 // slots past the read's end -- to ONE dump bin, `nbins`.  Two packed instructions per pair of samples; the exact
 // sums run over t' and are corrected by the dump bin's count afterwards.
-template <int NT, int NQ, int OCC = 8>
+template <int NT, int NQ, int OCC, bool LONG>
 __global__ __launch_bounds__(64 * WPB, OCC)
 void k_seg_stats(const SegStatArgs a)
 {
     constexpr int HBINS = 64 * 4 * NQ;
+    constexpr int WIN = 512 * NT;
     __shared__ __align__(16) unsigned hist_all[WPB][HBINS];
     __shared__ __align__(16) unsigned char plane_all[WPB][2][64 * NT];     // one byte per 8 samples: in band / dropped
     const int lane = threadIdx.x & 63;
@@ -140,59 +144,74 @@ void k_seg_stats(const SegStatArgs a)
     const int nbins = a.hi - a.lo - 1;                     // 1 .. min(HBINS - 1, MAXBINS) (host)
     const unsigned lo1p = (unsigned)((a.lo + 1) & 0xffff) * 0x10001u;
     const unsigned nbp = (unsigned)nbins * 0x10001u, nbm1p = (unsigned)(nbins - 1) * 0x10001u;
-    const int maxM = (int)min(a.stride, (int64_t)(512 * NT));
+    const int maxM = (int)min(a.stride, (int64_t)(LONG ? MAXLONG : WIN));
 
 #pragma unroll
     for (int j = 0; j < NQ; j++) *(uint4 *)(hist + hb0 + 4 * j) = make_uint4(0u, 0u, 0u, 0u);
+
+    unsigned y[NT][4];                                     // one window of the read: packed samples, then their t'
+    // the window's samples into registers: NT x 16-byte loads per lane, all in flight at once
+    auto load_window = [&](const int16_t *wrow, int Mw) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            if (t * 512 + lane * 8 < Mw) q = *(const uint4 *)(wrow + t * 512 + lane * 8);   // (rows are 16-byte aligned)
+            y[t][0] = q.x; y[t][1] = q.y; y[t][2] = q.z; y[t][3] = q.w;
+        }
+    };
+    // t' of one packed pair; the read's last tile also sends the slots past its end to the dump bin
+    auto image = [&](unsigned q, int t, int k, int ntiles, int nvalid) -> unsigned {
+        unsigned tt = pk_min_u16(pk_sub_u16(q, lo1p), nbp);
+        if (t == ntiles - 1) {                             // (wave-uniform)
+            const unsigned tail = nvalid >= 2 * k + 2 ? 0xffffffffu : (nvalid == 2 * k + 1 ? 0xffffu : 0u);
+            tt = (tt & tail) | (nbp & ~tail);
+        }
+        return tt;
+    };
 
     const int nwaves = gridDim.x * WPB;
     for (int r = blockIdx.x * WPB + w; r < a.nreads; r += nwaves) {
         const int M = __builtin_amdgcn_readfirstlane(min(max(a.len[r], 0), maxM));
         const int16_t *row = a.sig + (int64_t)r * a.stride;
-        const int ntiles = (M + 511) >> 9;
+        const int nwin = LONG ? (M + WIN - 1) / WIN : 1;
+        const int tiles_total = (M + 511) >> 9;
 
-        // ---- the whole read into registers: NT x 16-byte loads per lane, all in flight at once ----------
-        unsigned y[NT][4];
+        // ---- first look: t' per sample, exact sums, histogram -------------------------------------------------
+        long long S = 0, Q = 0;
+        for (int wi = 0; wi < nwin; wi++) {
+            const int Mw = min(M - wi * WIN, WIN);
+            const int ntiles = (Mw + 511) >> 9;
+            load_window(row + (int64_t)wi * WIN, Mw);
+            int st = 0, stt = 0;
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            uint4 q = make_uint4(0u, 0u, 0u, 0u);
-            if (t * 512 + lane * 8 < M) q = *(const uint4 *)(row + t * 512 + lane * 8);   // (rows are 16-byte aligned)
-            y[t][0] = q.x; y[t][1] = q.y; y[t][2] = q.z; y[t][3] = q.w;
-        }
-
-        // ---- pass 1 (registers): t' per sample, exact sums, histogram ----------------------------------------
-        int st = 0, stt = 0;
+            for (int t = 0; t < NT; t++) {
+                if (t >= ntiles) continue;                 // (wave-uniform) nothing of the read in this tile
+                const int nvalid = min(max(Mw - (t * 512 + lane * 8), 0), 8);   // samples of this lane's eight that exist
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            if (t >= ntiles) continue;                     // (wave-uniform) nothing of the read in this tile
-            const int nvalid = min(max(M - (t * 512 + lane * 8), 0), 8);   // samples of this lane's eight that exist
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                unsigned tt = pk_min_u16(pk_sub_u16(y[t][k], lo1p), nbp);
-                if (t == ntiles - 1) {                     // (wave-uniform) the read's last tile: slots past its end
-                    const unsigned tail = nvalid >= 2 * k + 2 ? 0xffffffffu : (nvalid == 2 * k + 1 ? 0xffffu : 0u);
-                    tt = (tt & tail) | (nbp & ~tail);
+                for (int k = 0; k < 4; k++) {
+                    const unsigned tt = image(y[t][k], t, k, ntiles, nvalid);
+                    y[t][k] = tt;
+                    const s16x2 ts = __builtin_bit_cast(s16x2, tt);
+                    st = __builtin_amdgcn_sdot2(ts, __builtin_bit_cast(s16x2, 0x10001u), st, false);
+                    stt = __builtin_amdgcn_sdot2(ts, ts, stt, false);
+                    const unsigned t4 = pk_shl2_u16(tt);                     // byte offsets of the two bins
+                    atomicAdd((unsigned *)((char *)hist + (t4 & 0xffffu)), 1u);
+                    atomicAdd((unsigned *)((char *)hist + (t4 >> 16)), 1u);
                 }
-                y[t][k] = tt;
-                const s16x2 ts = __builtin_bit_cast(s16x2, tt);
-                st = __builtin_amdgcn_sdot2(ts, __builtin_bit_cast(s16x2, 0x10001u), st, false);
-                stt = __builtin_amdgcn_sdot2(ts, ts, stt, false);
-                const unsigned t4 = pk_shl2_u16(tt);                         // byte offsets of the two bins
-                atomicAdd((unsigned *)((char *)hist + (t4 & 0xffffu)), 1u);
-                atomicAdd((unsigned *)((char *)hist + (t4 >> 16)), 1u);
+                // keep the tiles apart: left alone the scheduler precomputes the LDS addresses of all 8 tiles
+                // before it issues the first atomic
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // keep the tiles apart: left alone the scheduler precomputes the LDS addresses of all 8 tiles (64 more
-            // live registers) before it issues the first atomic
-            __builtin_amdgcn_sched_barrier(0);
+            S += (long long)wave_sum(st);
+            Q += (long long)wave_sum(stt & 0xffff) + ((long long)wave_sum((int)((unsigned)stt >> 16)) << 16);
         }
 
         // ---- exact integer totals (dump-bin entries taken out) ------------------------------------------------
         const long long D = (long long)__builtin_amdgcn_readfirstlane((int)hist[nbins]);   // dropped samples + slots past the end
         if (lane == 0) hist[nbins] = 0u;                                     // (LDS ops of a wave are in order)
-        const long long S = (long long)wave_sum(st) - D * nbins;
-        const long long Q = (long long)wave_sum(stt & 0xffff) + ((long long)wave_sum((int)((unsigned)stt >> 16)) << 16)
-                            - D * nbins * nbins;
-        const int n = ntiles * 512 - (int)D;                                 // samples that survived the filter
+        S -= D * nbins;
+        Q -= D * nbins * nbins;
+        const int n = tiles_total * 512 - (int)D;                            // samples that survived the filter
 
         // ---- median: rank select on the histogram (lane l owns bins [hb0, hb0 + 4 NQ)) ---------------------------
         // Two sweeps over the lane's own bins, four at a time (16-byte LDS reads), instead of holding all of them:
@@ -236,7 +255,7 @@ void k_seg_stats(const SegStatArgs a)
             const double median = (double)(b1 + b2 + 2 * (a.lo + 1)) * 0.5;  // exact (half-integer)
 
             // ---- thresholds from exact integers; certify ceil(top) / floor(bot) against numpy's rounding -------
-            const long long V = (long long)n * Q - S * S;                    // n^2 var, exact (< 2^46)
+            const long long V = (long long)n * Q - S * S;                    // n^2 var, exact (n <= 2^20: below 2^63)
             const double sd = sqrt((double)V) / (double)n;
             const double spread = sd * a.std_scale;                          // segmenter.py:413-414
             const double top = median + spread, bot = median - spread;
@@ -260,31 +279,45 @@ void k_seg_stats(const SegStatArgs a)
             if (!certified) a.retry[1 + atomicAdd(&a.retry[0], 1)] = r;
         }
 
-        // ---- pass 2 (registers): one "in band" and one "dropped" bit per raw sample ------------------------------
+        // ---- second look: one "in band" and one "dropped" bit per raw sample ------------------------------------
         // Each lane has 8 consecutive samples of a tile -> one byte of each mask; v_dot2_u32_u16 with the bit
         // weights {1 << 2k, 1 << (2k + 1)} builds the bytes from 0/1 flags.  The bytes go through LDS so that
-        // lane e can pick up entry e's 8 + 8 bytes and the wave stores the read's masks with ONE 16-byte store
+        // lane e can pick up entry e's 8 + 8 bytes and the wave stores a window's masks with ONE 16-byte store
         // per lane (1 KB contiguous).
         const unsigned tlop = (unsigned)__builtin_amdgcn_readfirstlane(tlo) * 0x10001u;
         const unsigned wm1p = (unsigned)((__builtin_amdgcn_readfirstlane(width) - 1) & 0xffff) * 0x10001u;
+        for (int wi = 0; wi < nwin; wi++) {
+            const int Mw = min(M - wi * WIN, WIN);
+            const int ntiles = (Mw + 511) >> 9;
+            if (LONG) {                                    // (one window: the t' are still in the registers)
+                load_window(row + (int64_t)wi * WIN, Mw);
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            if (t >= ntiles) continue;
-            unsigned drop8 = 0, out8 = 0;
+                for (int t = 0; t < NT; t++) {
+                    if (t >= ntiles) continue;
+                    const int nvalid = min(max(Mw - (t * 512 + lane * 8), 0), 8);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const unsigned wts = (1u << (2 * k)) | (2u << (2 * k + 16));
-                drop8 = udot2(pk_subsat_u16(y[t][k], nbm1p), wts, drop8);                    // t' - (nbins - 1) is 0 or 1
-                const unsigned over = pk_subsat_u16(pk_sub_u16(y[t][k], tlop), wm1p);        // > 0: outside the band
-                out8 = udot2(pk_min1_u16(over), wts, out8);
+                    for (int k = 0; k < 4; k++) y[t][k] = image(y[t][k], t, k, ntiles, nvalid);
+                }
             }
-            p_in[t * 64 + lane] = (unsigned char)((width > 0) ? ~out8 : 0u);
-            p_dr[t * 64 + lane] = (unsigned char)drop8;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (lane < 8 * ntiles) {
-            const uint2 vi = *(const uint2 *)(p_in + 8 * lane), vd = *(const uint2 *)(p_dr + 8 * lane);
-            a.mask2[(int64_t)r * a.row16 + lane] = make_uint4(vi.x, vi.y, ~vd.x, ~vd.y);     // {in band, kept}
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (t >= ntiles) continue;
+                unsigned drop8 = 0, out8 = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const unsigned wts = (1u << (2 * k)) | (2u << (2 * k + 16));
+                    drop8 = udot2(pk_subsat_u16(y[t][k], nbm1p), wts, drop8);                    // t' - (nbins - 1) is 0 or 1
+                    const unsigned over = pk_subsat_u16(pk_sub_u16(y[t][k], tlop), wm1p);        // > 0: outside the band
+                    out8 = udot2(pk_min1_u16(over), wts, out8);
+                }
+                p_in[t * 64 + lane] = (unsigned char)((width > 0) ? ~out8 : 0u);
+                p_dr[t * 64 + lane] = (unsigned char)drop8;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lane < 8 * ntiles) {
+                const uint2 vi = *(const uint2 *)(p_in + 8 * lane), vd = *(const uint2 *)(p_dr + 8 * lane);
+                a.mask2[(int64_t)r * a.row16 + wi * (8 * NT) + lane] = make_uint4(vi.x, vi.y, ~vd.x, ~vd.y);   // {in band, kept}
+            }
         }
     }
 }
@@ -583,29 +616,32 @@ void k_seg_walk3(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
 
 typedef void (*segstat_fn)(const SegStatArgs);
 
-segstat_fn pick_stats(int NT, int nbins)
+segstat_fn pick_stats(int64_t stride, int nbins)
 {
-    const bool small = nbins <= 1023;          // 4 KB of histogram per wave: 8 workgroups per CU
-    if (NT <= 2) return small ? k_seg_stats<2, 4> : k_seg_stats<2, 8>;
-    if (NT <= 4) return small ? k_seg_stats<4, 4> : k_seg_stats<4, 8>;
+    const bool small = nbins <= 1023;          // 4 KB of histogram per wave
+    const int NT = (int)((stride + 511) / 512);
+    if (NT <= 2) return small ? k_seg_stats<2, 4, 8, false> : k_seg_stats<2, 8, 8, false>;
+    if (NT <= 4) return small ? k_seg_stats<4, 4, 8, false> : k_seg_stats<4, 8, 8, false>;
+    if (NT > 8) return small ? k_seg_stats<8, 4, 6, true> : k_seg_stats<8, 8, 8, true>;
     if (small) {
         if (const char *e = getenv("SK_SEG_OCC")) {         // tuning: registers per lane vs reads in flight
             const int v = atoi(e);
-            if (v == 8) return k_seg_stats<8, 4, 8>;
-            if (v == 7) return k_seg_stats<8, 4, 7>;
-            if (v == 4) return k_seg_stats<8, 4, 4>;
+            if (v == 8) return k_seg_stats<8, 4, 8, false>;
+            if (v == 7) return k_seg_stats<8, 4, 7, false>;
         }
-        return k_seg_stats<8, 4, 6>;
+        return k_seg_stats<8, 4, 6, false>;
     }
-    return k_seg_stats<8, 8>;
+    return k_seg_stats<8, 8, 8, false>;
 }
 
 } // namespace
 
 // 16-byte entries per read in the {in band, kept} mask: 8 per 512-sample tile the statistics kernel holds
+// (reads longer than 4 096 samples: whole 64-entry windows)
 int sk_segment_fast_row16(int64_t stride)
 {
     const int NT = (int)((stride + 511) / 512);
+    if (NT > 8) return 64 * (int)((stride + 4095) / 4096);
     return 8 * (NT <= 2 ? 2 : NT <= 4 ? 4 : 8);
 }
 
@@ -615,7 +651,7 @@ bool sk_segment_fast_applies(const void *d_sig, int64_t stride, int32_t lo, int3
     if (getenv("SK_SEG_OLD")) return false;                 // A/B switch: the numpy-order kernels for everything
     const int64_t nbins = (int64_t)hi - lo - 1;
     if (nbins < 1 || nbins > MAXBINS) return false;
-    if (stride > 4096 || (stride % 8) != 0 || ((uintptr_t)d_sig & 15) != 0) return false;
+    if (stride > MAXLONG || (stride % 8) != 0 || ((uintptr_t)d_sig & 15) != 0) return false;
     if (!(std_scale == std_scale) || fabs(std_scale) > 1e6) return false;
     return true;
 }
@@ -629,8 +665,7 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
                            const sk_seg_params *p, int32_t lo, int32_t hi, sk_prep *d_prep, void *d_mask2,
                            int32_t *d_retry, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs)
 {
-    const int NT = (int)((stride + 511) / 512);
-    segstat_fn fn = pick_stats(NT, hi - lo - 1);
+    segstat_fn fn = pick_stats(stride, hi - lo - 1);
     SegStatArgs a;
     a.stride = stride; a.lo = lo; a.hi = hi;
     a.std_scale = p->std_scale; a.delta_scale = 1.0;
@@ -681,7 +716,14 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
         hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * WPB), 0, c->stream, a);
         SK_HIP(hipGetLastError());
         // reads whose ceil(top) / floor(bot) could not be certified: numpy-order statistics, masks rewritten in place
-        int rc = sk_launch_prep_i16(c, a.sig, stride, a.len, nr, lo, hi, SK_PREP_SEGMENT, p->std_scale, nullptr, a.prep,
+        // (reads too long for the redo's LDS copy: one scratch row per workgroup of its persistent grid, <= one per CU)
+        int16_t *scratch_rows = nullptr;
+        if (stride * (int64_t)sizeof(int16_t) > 24 * 1024) {
+            int rc0 = sk_reserve(c, &c->comp, (size_t)c->num_cu * (size_t)stride * sizeof(int16_t));
+            if (rc0) return rc0;
+            scratch_rows = (int16_t *)c->comp.p;
+        }
+        int rc = sk_launch_prep_i16(c, a.sig, stride, a.len, nr, lo, hi, SK_PREP_SEGMENT, p->std_scale, scratch_rows, a.prep,
                                     nullptr, 0, 0, 0x7fffffff, retry + 1, retry, a.mask2, a.row16);
         if (rc) return rc;
         hipStream_t ws = c->stream;

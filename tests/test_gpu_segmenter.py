@@ -199,3 +199,27 @@ def test_streaming_path_retry_list_and_old_kernels_agree(gpu, ora, monkeypatch):
         for kw in STREAM_PARAMS[:9]:
             _check_vs_oracle(api, ora, sig, lens, kw, "%s=%s" % (env, val))
         monkeypatch.delenv(env)
+
+
+@pytest.mark.parametrize("M", [4104, 9000, 20000, 36984])
+def test_streaming_path_long_reads(gpu, ora, monkeypatch, M):
+    """Reads longer than one 4 096-sample window: the statistics kernel looks at them twice (window by window);
+    with the certification margin blown up, the numpy-order redo runs on them too (LDS-resident copy up to
+    ~14 000 samples, a scratch row per workgroup beyond)."""
+    from squigglekit_amd import api, synth
+    rng = np.random.default_rng(M)
+    R = 40
+    sig = synth.squiggle_batch(R, M, 1000 + M)
+    lens = rng.integers(1, M + 1, size=R).astype(np.int32)
+    lens[:8] = [M, M - 1, 4096, 4097, 8192, 8193, 1, 4095]
+    sig[8, :] = 0
+    sig[9, :] = 500
+    sig[10, 3000:M - 50] = 0                         # a hole of dropped samples across window borders
+    k = 5000
+    sig[11, rng.integers(0, M, k)] = rng.choice(np.array([-5, 0, 950, 1100], dtype=np.int16), k)
+    cases = [dict(), dict(error=12, corrector=3, window=30), dict(std_scale=2.0, window=400), dict(lim_low=300, lim_hi=700)]
+    for kw in cases:
+        _check_vs_oracle(api, ora, sig, lens, kw, "long M=%d" % M, max_segs=160)
+    monkeypatch.setenv("SK_SEG_DELTA_SCALE", "1e13")
+    for kw in cases[:2]:
+        _check_vs_oracle(api, ora, sig, lens, kw, "long M=%d, redo" % M, max_segs=160)
