@@ -371,11 +371,15 @@ def segmenter_isolated(w, steps=3):
     """Kernel times with the two kernels run one after the other (SK_SEG_CHUNKS=1): by default the walk of one
     chunk runs beside the statistics of the next, which is what `value` measures but not what a per-kernel
     roofline can be computed from."""
+    had = os.environ.get("SK_SEG_CHUNKS")
     os.environ["SK_SEG_CHUNKS"] = "1"
     try:
         _, prof = timed(w, None, steps, 1)
     finally:
-        del os.environ["SK_SEG_CHUNKS"]
+        if had is None:
+            del os.environ["SK_SEG_CHUNKS"]
+        else:
+            os.environ["SK_SEG_CHUNKS"] = had
     return prof, steps
 
 
@@ -549,8 +553,7 @@ def rank_body(a, comm, rank, world, shape):
 
 def main(argv=None):
     a = parse(argv)
-    if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
-        os.environ["NCCL_DEBUG"] = "WARN"        # no RCCL version banner on stdout: the JSON line stands alone
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # RCCL logs to stdout by default: the JSON line stands alone
     from squigglekit_amd import _lib, multigpu
     _lib.load()
     shape, rank, local, world = multigpu.plan(a.gpus)

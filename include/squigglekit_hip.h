@@ -218,6 +218,14 @@ int sk_tsv_parse(const char *buf, size_t len, int32_t start_col, int64_t nlines,
                  double *values, int64_t *name_off, int32_t *name_len, int64_t *id_off, int32_t *id_len,
                  int32_t *flags, int32_t nthreads);
 
+/* Integer lines straight into int16 rows (the raw-signal TSVs SquigglePull writes): rows[i * stride ..] = line i's
+ * data tokens, nsamp[i] their number.  flags[i] has SK_TSV_ALLINT only if every data token is [+-]digits, fits
+ * int16 and the line has at most `stride` of them (the row is valid only then); other lines get SK_TSV_SLOW /
+ * SK_TSV_SHORT and go the general way.  line_off[i] (nlines + 1 entries) = byte offset of line i. */
+int sk_tsv_parse_i16(const char *buf, size_t len, int32_t start_col, int64_t nlines, int64_t stride, int16_t *rows,
+                     int32_t *nsamp, int64_t *name_off, int32_t *name_len, int64_t *id_off, int32_t *id_len,
+                     int32_t *flags, int64_t *line_off, int32_t nthreads);
+
 /* ---- multi-GPU: the final gather of result records (RCCL over xGMI) ------ */
 /* The reference's per-read loops (segmenter.py:189-230, MotifSeq.py:261-298) carry no state from one read
  * to the next, so N GPUs take contiguous blocks of the reads with no data-path collective; the one exchange

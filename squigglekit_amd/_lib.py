@@ -115,6 +115,8 @@ ABI = {
     "sk_tsv_count_tokens": (C.c_int, [_vp, C.c_size_t, C.c_int32, C.c_int64, _vp, C.c_int32]),
     "sk_tsv_parse": (C.c_int, [_vp, C.c_size_t, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                C.c_int32]),
+    "sk_tsv_parse_i16": (C.c_int, [_vp, C.c_size_t, C.c_int32, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, C.c_int32]),
     "sk_comm_unique_id": (C.c_int, [_vp]),
     "sk_comm_init_rank": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sk_comm_init_all": (C.c_int, [_i32p, C.c_int]),

@@ -207,4 +207,82 @@ int sk_tsv_parse(const char *buf, size_t len, int32_t start_col, int64_t nlines,
     return SK_OK;
 }
 
+// Lines of integer samples straight into int16 rows: the common case (SquigglePull's raw TSV), without the float64
+// detour and without a Python object per read.  rows[i * stride ..] receives line i's data tokens (columns
+// start_col ..), nsamp[i] their number.  flags[i]: SK_TSV_ALLINT only if EVERY data token is [+-]digits, fits int16
+// and the line has at most `stride` of them -- only then is the row valid; any other line gets SK_TSV_SLOW (or
+// SK_TSV_SHORT) and is left to the caller's general path.  SK_TSV_ANY: some value is non-zero.  line_off[i] =
+// byte offset of line i in buf (line_off[nlines] = end), so the caller can slice the odd lines out.
+int sk_tsv_parse_i16(const char *buf, size_t len, int32_t start_col, int64_t nlines, int64_t stride, int16_t *rows,
+                     int32_t *nsamp, int64_t *name_off, int32_t *name_len, int64_t *id_off, int32_t *id_len,
+                     int32_t *flags, int64_t *line_off, int32_t nthreads)
+{
+    if (!buf || !rows || !nsamp || !flags || !line_off || start_col < 0 || nlines < 0 || stride <= 0)
+        return SK_ERR_INVALID;
+    {
+        const char *p = buf, *end = buf + len;
+        for (int64_t i = 0; i < nlines; i++) {
+            const char *q = (const char *)memchr(p, '\n', (size_t)(end - p));
+            line_off[i] = p - buf;
+            p = q ? q + 1 : end;
+        }
+        line_off[nlines] = (int64_t)len;
+    }
+    if (nthreads < 1) nthreads = 1;
+    auto work = [&](int t) {
+        // contiguous blocks of lines per thread: neighbouring rows are written by one thread
+        const int64_t per = (nlines + nthreads - 1) / nthreads;
+        const int64_t i0 = t * per, i1 = (i0 + per < nlines) ? i0 + per : nlines;
+        for (int64_t i = i0; i < i1; i++) {
+            const char *p = buf + line_off[i], *e = buf + line_off[i + 1];
+            if (e > p && e[-1] == '\n') e--;
+            int16_t *row = rows + i * stride;
+            int col = 0;
+            int64_t k = 0;
+            bool ok = true, anynz = false;
+            if (name_off) { name_off[i] = 0; name_len[i] = 0; }
+            if (id_off) { id_off[i] = 0; id_len[i] = 0; }
+            const char *s = p;
+            while (true) {
+                const char *te = s;
+                if (col >= start_col) {                     // integer token, converted while looking for its end
+                    bool neg = false;
+                    if (te < e && (*te == '-' || *te == '+')) { neg = (*te == '-'); te++; }
+                    const char *d0 = te;
+                    int v = 0;
+                    while (te < e && (unsigned)(*te - '0') <= 9u) { if (v < 100000) v = v * 10 + (*te - '0'); te++; }
+                    const bool plain = te > d0 && (te == e || *te == '\t');
+                    if (!plain) { ok = false; while (te < e && *te != '\t') te++; }
+                    else {
+                        if (neg) v = -v;
+                        if (v < -32768 || v > 32767 || k >= stride) ok = false;
+                        else { row[k] = (int16_t)v; anynz = anynz || v != 0; }
+                        k++;
+                    }
+                } else {
+                    const char *q = (const char *)memchr(s, '\t', (size_t)(e - s));
+                    te = q ? q : e;
+                    if (col == 0 && name_off) { name_off[i] = s - buf; name_len[i] = (int32_t)(te - s); }
+                    if (col == 1 && id_off) { id_off[i] = s - buf; id_len[i] = (int32_t)(te - s); }
+                }
+                col++;
+                if (te >= e) break;
+                s = te + 1;
+            }
+            int32_t fl = 0;
+            if (col <= start_col) fl |= SK_TSV_SHORT;
+            else if (ok) fl |= SK_TSV_ALLINT;
+            else fl |= SK_TSV_SLOW;
+            if (anynz) fl |= SK_TSV_ANY;
+            nsamp[i] = (int32_t)(k < 0x7fffffff ? k : 0x7fffffff);
+            flags[i] = fl;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    return SK_OK;
+}
+
 } // extern "C"

@@ -75,6 +75,19 @@ class _Batcher:
         self.names.append((None, message))
         self.sigs.append(None)
 
+    def emit(self, name, miss, segs):
+        """What the reference does with one read's get_segs result (segmenter.py:211-227)."""
+        if not segs:
+            sys.stderr.write("no segments found: {}".format(miss))            # segmenter.py:213
+            return
+        if self.args.test:
+            segs = api.test_segs(segs, self.args)
+            if not segs:
+                if self.args.signal:
+                    sys.stderr.write("no segs for testing: {}".format(miss))   # :219 (TSV branch only)
+                return
+        print("\t".join([name, ",".join(str(v) for pair in segs for v in pair)]))
+
     def flush(self):
         if not self.sigs:
             return
@@ -84,18 +97,38 @@ class _Batcher:
             if sig is None:
                 sys.stderr.write(miss)
                 continue
-            segs = next(results)
-            if not segs:
-                sys.stderr.write("no segments found: {}".format(miss))        # segmenter.py:213
-                continue
-            if self.args.test:
-                segs = api.test_segs(segs, self.args)
-                if not segs:
-                    if self.args.signal:
-                        sys.stderr.write("no segs for testing: {}".format(miss))   # :219 (TSV branch only)
-                    continue
-            print("\t".join([name, ",".join(str(v) for pair in segs for v in pair)]))
+            self.emit(name, miss, next(results))
         self.names, self.sigs = [], []
+
+    def block(self, blk, path):
+        """A parsed TSV chunk (tsvio.TsvBlock): the integer lines go to the GPU as ONE int16 batch straight from
+        the tokenizer's rows; every other line takes the per-read route above, in its place."""
+        Num = self.args.Num
+        fast = (blk.flags & 27) == 3                                        # ALLINT | ANY, not SLOW / SHORT
+        idx = np.flatnonzero(fast)
+        res = {}
+        if idx.size:
+            ns = blk.nsamp[idx]
+            lens = (np.maximum(ns + Num, 0) if Num < 0 else np.minimum(ns, Num)).astype(np.int32)   # sig[:Num]
+            rows = blk.rows[idx] if idx.size != blk.n else blk.rows
+            segs, nsegs = api.segment_batch(rows, lens, self.params)
+            res = {int(i): k for k, i in enumerate(idx)}
+        for i in range(blk.n):
+            k = res.get(i)
+            if k is not None:
+                name = blk.name(i)
+                self.emit(name, name, segs[k, :nsegs[k]].tolist() if nsegs[k] else False)
+                continue
+            fl = int(blk.flags[i])
+            if (fl & 27) == 1:                                              # integers, all zero: segmenter.py:203-205
+                sys.stderr.write("No signal found in file: {} {}".format(path, blk.name(i)))
+                continue
+            name, sig = tsvio.parse_segmenter_line(blk.line(i).decode())    # the reference's own parse, exceptions included
+            if not sig.any():
+                sys.stderr.write("No signal found in file: {} {}".format(path, name))
+                continue
+            self.add(name, sig[:Num])
+            self.flush()                                                    # keeps the output in file order
 
 
 def main(argv=None):
@@ -122,17 +155,24 @@ def main(argv=None):
     out = _Batcher(args)
 
     if args.signal:
-        # native tokenizer; a line it cannot take verbatim (odd tokens, too few columns, a
-        # non-integer token in an "integer" line) is re-parsed exactly the reference's way
-        for name, _rid, vals, fl, raw in tsvio.iter_tsv_native(args.signal, 4):
-            if (fl & 24) or not (fl & 5):           # SLOW | SHORT, or neither FIRSTDOT nor ALLINT
-                name, sig = tsvio.parse_segmenter_line(raw.decode())
-            else:
-                sig = vals
-            if not sig.any():                       # segmenter.py:203-205
-                out.note("No signal found in file: {} {}".format(args.signal, name))
+        # native tokenizer (csrc/sk_tsv.cpp): integer lines arrive as int16 rows, one GPU batch per chunk of the
+        # file; a line it cannot take verbatim (odd tokens, decimals, too few columns) is parsed exactly the
+        # reference's way
+        for blk in tsvio.iter_tsv_blocks_i16(args.signal, 4):
+            if blk.mostly_integer():
+                out.block(blk, args.signal)
                 continue
-            out.add(name, sig[:args.Num])
+            out.flush()
+            for name, _rid, vals, fl, raw in blk.float_lines(4):      # pA (decimal) lines: float64 tokenizer
+                if (fl & 24) or not (fl & 5):       # SLOW | SHORT, or neither FIRSTDOT nor ALLINT
+                    name, sig = tsvio.parse_segmenter_line(raw.decode())
+                else:
+                    sig = vals
+                if not sig.any():                   # segmenter.py:203-205
+                    out.note("No signal found in file: {} {}".format(args.signal, name))
+                    continue
+                out.add(name, sig[:args.Num])
+            out.flush()
     elif args.blow5:
         from .blow5 import read_blow5, to_pA
         for rec in read_blow5(args.blow5):

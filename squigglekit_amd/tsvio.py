@@ -38,6 +38,38 @@ def parse_motifseq_line(line):
     return cols[0], cols[1], np.array([float(v) for v in cols[8:]])
 
 
+def _parse_block_float(buf, start_col, nthreads):
+    """One whole-line chunk through the float64 tokenizer (sk_tsv_parse): (name, read_id, values, flags, raw)."""
+    from . import _lib
+    L = _lib.load()
+    n = L.sk_tsv_count_lines(buf, len(buf))
+    if n <= 0:
+        return
+    ntok = np.zeros(n, dtype=np.int64)
+    _lib.check(L.sk_tsv_count_tokens(buf, len(buf), start_col, n, _lib.ptr(ntok), nthreads))
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(ntok, out=off[1:])
+    values = np.empty(max(1, int(off[-1])), dtype=np.float64)
+    name_off = np.zeros(n, dtype=np.int64)
+    name_len = np.zeros(n, dtype=np.int32)
+    id_off = np.zeros(n, dtype=np.int64)
+    id_len = np.zeros(n, dtype=np.int32)
+    flags = np.zeros(n, dtype=np.int32)
+    _lib.check(L.sk_tsv_parse(buf, len(buf), start_col, n, _lib.ptr(off), _lib.ptr(values),
+                              _lib.ptr(name_off), _lib.ptr(name_len), _lib.ptr(id_off),
+                              _lib.ptr(id_len), _lib.ptr(flags), nthreads))
+    pos = 0
+    for i in range(n):
+        nl = buf.find(b"\n", pos)
+        end = nl if nl >= 0 else len(buf)
+        fl = int(flags[i])
+        raw = buf[pos:end] if (fl & 24) or not (fl & 5) else None
+        yield (buf[name_off[i]:name_off[i] + name_len[i]].decode(),
+               buf[id_off[i]:id_off[i] + id_len[i]].decode(),
+               values[off[i]:off[i + 1]], fl, raw)
+        pos = end + 1
+
+
 def iter_tsv_native(path, start_col, chunk_bytes=64 << 20, nthreads=None):
     """Stream a SquigglePull TSV through the native tokenizer (csrc/sk_tsv.cpp).
 
@@ -47,11 +79,14 @@ def iter_tsv_native(path, start_col, chunk_bytes=64 << 20, nthreads=None):
       raw_line the undecoded line (bytes) -- only needed when flags & SLOW/SHORT tells the
                caller to re-parse it the reference's way.
     No GPU is involved; the library only has to be loadable."""
-    import ctypes as C
     import os
-    from . import _lib
-    L = _lib.load()
     nthreads = nthreads or min(32, os.cpu_count() or 1)
+    for buf in _line_blocks(path, chunk_bytes):
+        yield from _parse_block_float(buf, start_col, nthreads)
+
+
+def _line_blocks(path, chunk_bytes):
+    """Whole-line chunks of a (possibly gzipped) text file, as bytes."""
     opener = gzip.open if path.endswith(".gz") else open
     with opener(path, "rb") as fh:
         tail = b""
@@ -68,32 +103,66 @@ def iter_tsv_native(path, start_col, chunk_bytes=64 << 20, nthreads=None):
                 tail, buf = buf[cut + 1:], buf[:cut + 1]
             else:
                 tail = b""
-            n = L.sk_tsv_count_lines(buf, len(buf))
-            if n <= 0:
-                continue
-            ntok = np.zeros(n, dtype=np.int64)
-            _lib.check(L.sk_tsv_count_tokens(buf, len(buf), start_col, n, _lib.ptr(ntok), nthreads))
-            off = np.zeros(n + 1, dtype=np.int64)
-            np.cumsum(ntok, out=off[1:])
-            values = np.empty(max(1, int(off[-1])), dtype=np.float64)
-            name_off = np.zeros(n, dtype=np.int64)
-            name_len = np.zeros(n, dtype=np.int32)
-            id_off = np.zeros(n, dtype=np.int64)
-            id_len = np.zeros(n, dtype=np.int32)
-            flags = np.zeros(n, dtype=np.int32)
-            _lib.check(L.sk_tsv_parse(buf, len(buf), start_col, n, _lib.ptr(off), _lib.ptr(values),
-                                      _lib.ptr(name_off), _lib.ptr(name_len), _lib.ptr(id_off),
-                                      _lib.ptr(id_len), _lib.ptr(flags), nthreads))
-            pos = 0
-            for i in range(n):
-                nl = buf.find(b"\n", pos)
-                end = nl if nl >= 0 else len(buf)
-                fl = int(flags[i])
-                raw = buf[pos:end] if (fl & 24) or not (fl & 5) else None
-                yield (buf[name_off[i]:name_off[i] + name_len[i]].decode(),
-                       buf[id_off[i]:id_off[i] + id_len[i]].decode(),
-                       values[off[i]:off[i + 1]], fl, raw)
-                pos = end + 1
+            if buf:
+                yield buf
+
+
+class TsvBlock:
+    """One chunk of a TSV parsed by sk_tsv_parse_i16: lines whose data tokens are all plain integers that fit
+    int16 (flags & 1) sit ready in `rows` (int16 [n, stride], `nsamp` tokens each); the others (flags & 8: some
+    other token; & 16: no data column) are handed out as raw bytes by line(i) for the reference's own parse."""
+
+    def __init__(self, buf, rows, nsamp, flags, name_off, name_len, id_off, id_len, line_off):
+        self.buf, self.rows, self.nsamp, self.flags = buf, rows, nsamp, flags
+        self._no, self._nl, self._io, self._il, self._lo = name_off, name_len, id_off, id_len, line_off
+        self.n = len(flags)
+
+    def name(self, i):
+        return self.buf[self._no[i]:self._no[i] + self._nl[i]].decode()
+
+    def read_id(self, i):
+        return self.buf[self._io[i]:self._io[i] + self._il[i]].decode()
+
+    def line(self, i):
+        return self.buf[self._lo[i]:self._lo[i + 1]].rstrip(b"\n")
+
+    def mostly_integer(self):
+        """False for chunks of decimal (pA) lines: those go through the float64 tokenizer instead."""
+        return int(np.count_nonzero(self.flags & 8)) * 20 <= self.n
+
+    def float_lines(self, start_col, nthreads=None):
+        import os
+        return _parse_block_float(self.buf, start_col, nthreads or min(32, os.cpu_count() or 1))
+
+
+def iter_tsv_blocks_i16(path, start_col, chunk_bytes=48 << 20, nthreads=None):
+    """Stream a SquigglePull TSV as TsvBlock chunks (csrc/sk_tsv.cpp: sk_tsv_parse_i16): integer lines land in
+    int16 rows without a float64 detour or a Python object per read."""
+    import os
+    from . import _lib
+    L = _lib.load()
+    nthreads = nthreads or min(32, os.cpu_count() or 1)
+    for buf in _line_blocks(path, chunk_bytes):
+        n = L.sk_tsv_count_lines(buf, len(buf))
+        if n <= 0:
+            continue
+        ntok = np.zeros(n, dtype=np.int64)
+        _lib.check(L.sk_tsv_count_tokens(buf, len(buf), start_col, n, _lib.ptr(ntok), nthreads))
+        stride = max(8, (int(ntok.max()) + 7) // 8 * 8)
+        if n * stride * 2 > (3 << 30):               # one enormous line among short ones: not worth a dense block
+            stride = max(8, (int(np.percentile(ntok, 99)) + 7) // 8 * 8)   # (longer lines are flagged SLOW)
+        rows = np.zeros((n, stride), dtype=np.int16)
+        nsamp = np.zeros(n, dtype=np.int32)
+        flags = np.zeros(n, dtype=np.int32)
+        name_off = np.zeros(n, dtype=np.int64)
+        name_len = np.zeros(n, dtype=np.int32)
+        id_off = np.zeros(n, dtype=np.int64)
+        id_len = np.zeros(n, dtype=np.int32)
+        line_off = np.zeros(n + 1, dtype=np.int64)
+        _lib.check(L.sk_tsv_parse_i16(buf, len(buf), start_col, n, stride, _lib.ptr(rows), _lib.ptr(nsamp),
+                                      _lib.ptr(name_off), _lib.ptr(name_len), _lib.ptr(id_off), _lib.ptr(id_len),
+                                      _lib.ptr(flags), _lib.ptr(line_off), nthreads))
+        yield TsvBlock(buf, rows, nsamp, flags, name_off, name_len, id_off, id_len, line_off)
 
 
 # ----------------------------------------------------------------------------

@@ -117,6 +117,24 @@ def oracle_backend(monkeypatch, ora):
                 out[i]["flags"] = 1
         return out
 
+    def seg_batch(sig, lens=None, params=None, max_segs=64, devices=None):
+        params = params or _lib.SegParams()
+        op = ora.SegParams(params.error, params.corrector, params.window, params.seg_dist,
+                           params.std_scale, params.stall_len)
+        sig = np.ascontiguousarray(sig, dtype=np.int16)
+        lens = np.full(sig.shape[0], sig.shape[1], dtype=np.int32) if lens is None else np.asarray(lens, dtype=np.int32)
+        while True:
+            segs, nsegs = ora.segment_batch_i16(sig, lens, op, lo=params.lim_low, hi=params.lim_hi, max_segs=max_segs)
+            if nsegs.size == 0 or nsegs.max() <= max_segs:
+                return segs, nsegs
+            max_segs = int(nsegs.max()) + 8
+
+    def mot_batch(sig, lens, motifs, scale="medmad", lo=0, hi=1200):
+        reads = [np.asarray(sig[r, :lens[r]]) for r in range(sig.shape[0])]
+        return [mot_any(reads, m, scale, lo, hi) for m in motifs]
+
+    monkeypatch.setattr(api, "segment_batch", seg_batch)
+    monkeypatch.setattr(api, "motifseq_multi_batch", mot_batch, raising=False)
     monkeypatch.setattr(api, "segment_any", seg_any)
     monkeypatch.setattr(api, "motifseq_any", mot_any)
     monkeypatch.setattr(api, "motifseq_multi",
