@@ -368,9 +368,8 @@ def motifseq_roofline(a, w, prof, steps, mean_n):
 
 
 def segmenter_isolated(w, steps=3):
-    """Kernel times with the two kernels run one after the other (SK_SEG_CHUNKS=1): by default the walk of one
-    chunk runs beside the statistics of the next, which is what `value` measures but not what a per-kernel
-    roofline can be computed from."""
+    """Kernel times with the two kernels run one after the other (SK_SEG_CHUNKS=1, the default): with more chunks
+    the walk of one runs beside the statistics of the next, and a per-kernel roofline cannot be read off."""
     had = os.environ.get("SK_SEG_CHUNKS")
     os.environ["SK_SEG_CHUNKS"] = "1"
     try:
@@ -381,6 +380,13 @@ def segmenter_isolated(w, steps=3):
         else:
             os.environ["SK_SEG_CHUNKS"] = had
     return prof, steps
+
+
+def seg_kernel_prof(w, prof, steps):
+    """The timed steps' HIP-event sums, unless SK_SEG_CHUNKS > 1 overlapped the two kernels in them."""
+    if os.environ.get("SK_SEG_CHUNKS", "1") == "1":
+        return prof, steps
+    return segmenter_isolated(w)
 
 
 def segmenter_roofline(w, prof, steps):
@@ -396,8 +402,6 @@ def segmenter_roofline(w, prof, steps):
             "frac": achieved / HBM_PEAK_GBS, "traffic": per_read * R if per_read else None, "traffic_source": src,
             "kernel_ms": {"prep": prep_ms, "main": main_ms, "dominant_avg_launch": dom_ms},
             "algorithmic_bytes_per_launch": alg_bytes,
-            "kernel_ms_note": "the two kernels timed one after the other (SK_SEG_CHUNKS=1); `value` uses the "
-                              "default, where the walk of one chunk overlaps the statistics of the next",
             "both_kernels": {"achieved": both, "frac": both / HBM_PEAK_GBS}}
 
 
@@ -418,7 +422,7 @@ def extras_single_gpu(a, L, main):
                                 "unit": "reads/s", "ms_per_step": el / 5 * 1e3, "steps": 5, "warmup": 1,
                                 "config": {"workload": "segmenter C2-1M: %d reads x %d int16 samples, default flags"
                                                        % (w.R, w.M), "seed": w.seed},
-                                "roofline": segmenter_roofline(w, *segmenter_isolated(w)), "cpu_baseline": cpu,
+                                "roofline": segmenter_roofline(w, *seg_kernel_prof(w, prof, 5)), "cpu_baseline": cpu,
                                 "parity": par}
         finally:
             w.free()
@@ -521,7 +525,7 @@ def rank_body(a, comm, rank, world, shape):
         wl = "MotifSeq C4: %d reads x %d int16 samples %s, %d-pt motif, %s" % (
             a.reads, a.samples, "per GPU" if a.scaling == "weak" else "in total", a.motif, a.scale)
     else:
-        roofline = segmenter_roofline(w, *segmenter_isolated(w)) if use_comm is None else \
+        roofline = segmenter_roofline(w, *seg_kernel_prof(w, prof, a.steps)) if use_comm is None else \
             segmenter_roofline(w, prof, a.steps)
         name = "reads/sec segmenter (4k-sample read)"
         wl = "segmenter C2-1M: %d reads x %d int16 samples %s, default flags" % (

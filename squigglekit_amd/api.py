@@ -382,16 +382,33 @@ def motifseq_after_stall(reads, motif, scale="medmad", scale_low=0, scale_hi=120
     return motifseq_any([np.asarray(r)[c:] for r, c in zip(reads, cuts)], motif, scale, scale_low, scale_hi), cuts
 
 
-def motifseq_multi(reads, motifs, scale="medmad", scale_low=0, scale_hi=1200):
+def motifseq_multi_batch(sig, lens, motifs, scale="medmad", scale_low=0, scale_hi=1200):
+    """Every motif of `motifs` against every row of an int16 [R, stride] batch (one filter / statistics pass):
+    list (one per motif) of HIT_DTYPE arrays in read order.  The block form of motifseq_multi."""
+    sig = np.ascontiguousarray(sig, dtype=np.int16)
+    R = sig.shape[0]
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    if _too_wide_for_i16(scale_low, scale_hi):
+        return motifseq_multi([sig[r, :lens[r]] for r in range(R)], motifs, scale, scale_low, scale_hi)
+    return motifseq_multi([], motifs, scale, scale_low, scale_hi, _packed=(sig, lens))
+
+
+def motifseq_multi(reads, motifs, scale="medmad", scale_low=0, scale_hi=1200, _packed=None):
     """Every motif of `motifs` (list of float vectors) against every read: list (one per motif,
     in order) of HIT_DTYPE arrays in read order -- the double loop of MotifSeq.py:261-298,436.
     Integer reads share one filter/statistics pass across motifs."""
     L = _lib.ensure_init()
     motifs = [np.ascontiguousarray(m, dtype=np.float64) for m in motifs]
-    outs = [np.zeros(len(reads), dtype=HIT_DTYPE) for _ in motifs]
-    ints, arrs, flts = _split_int16(reads)
+    if _packed is not None:                                   # an int16 batch as it is (motifseq_multi_batch)
+        buf, lens = _packed
+        ints, flts = list(range(buf.shape[0])), []
+        outs = [np.zeros(len(ints), dtype=HIT_DTYPE) for _ in motifs]
+    else:
+        outs = [np.zeros(len(reads), dtype=HIT_DTYPE) for _ in motifs]
+        ints, arrs, flts = _split_int16(reads)
+        if ints and motifs:
+            buf, lens = pack_i16(arrs)
     if ints and motifs:
-        buf, lens = pack_i16(arrs)
         moff = np.zeros(len(motifs) + 1, dtype=np.int32)
         moff[1:] = np.cumsum([m.size for m in motifs])
         flat = np.ascontiguousarray(np.concatenate(motifs))

@@ -140,31 +140,69 @@ class _Batcher:
                 sys.stderr.write(read_id)
                 continue
             r = slot[i]
-            norm = None
-            for c, name in enumerate(self.order):                       # MotifSeq.py:436-449
-                h = hits[c][r]
-                if h["flags"] & 1:
-                    sys.stderr.write("MotifSeq: no sample of {} survived the outlier limits; skipped\n".format(read_id))
-                    break
-                if h["flags"] & 2:                                      # SK_FLAG_DEGENERATE
-                    sys.stderr.write("MotifSeq: the MAD of {} is 0 (medmad divides by it, MotifSeq.py:196-199); "
-                                     "skipped\n".format(read_id))
-                    break
-                dist, start, end = float(h["dist"]), int(h["start"]), int(h["end"])
-                mod_mean = (a.slope * self.lens[c]) + a.intercept
-                mod_stdev = mod_mean * a.std_const
-                z = (dist - mod_mean) / mod_stdev
-                p_value = norm_cdf(z)
-                hit_p = (1 - p_value) * 100
-                row = [fast5, read_id, name, start, end, end - start, dist, mod_mean, mod_stdev, z, p_value, hit_p]
-                if a.sig_extract:
-                    if norm is None:
-                        norm = api.normalise(self.sigs[i], a.scale, a.scale_low, a.scale_hi)
-                    row.append("\t".join(str(v) for v in norm[start:end]))
-                if cuts is not None:
-                    row.append(int(cuts[r]))
-                print("\t".join("{}".format(v) for v in row))
+            self.emit(fast5, read_id, [hits[c][r] for c in range(len(self.order))], self.sigs[i],
+                      None if cuts is None else int(cuts[r]))
         self.meta, self.sigs = [], []
+
+    def emit(self, fast5, read_id, hits, sig, cut):
+        """The rows of one read, one per motif (MotifSeq.py:436-449)."""
+        a = self.args
+        norm = None
+        for c, name in enumerate(self.order):
+            h = hits[c]
+            if h["flags"] & 1:
+                sys.stderr.write("MotifSeq: no sample of {} survived the outlier limits; skipped\n".format(read_id))
+                break
+            if h["flags"] & 2:                                      # SK_FLAG_DEGENERATE
+                sys.stderr.write("MotifSeq: the MAD of {} is 0 (medmad divides by it, MotifSeq.py:196-199); "
+                                 "skipped\n".format(read_id))
+                break
+            dist, start, end = float(h["dist"]), int(h["start"]), int(h["end"])
+            mod_mean = (a.slope * self.lens[c]) + a.intercept
+            mod_stdev = mod_mean * a.std_const
+            z = (dist - mod_mean) / mod_stdev
+            p_value = norm_cdf(z)
+            hit_p = (1 - p_value) * 100
+            row = [fast5, read_id, name, start, end, end - start, dist, mod_mean, mod_stdev, z, p_value, hit_p]
+            if a.sig_extract:
+                if norm is None:
+                    norm = api.normalise(sig, a.scale, a.scale_low, a.scale_hi)
+                row.append("\t".join(str(v) for v in norm[start:end]))
+            if cut is not None:
+                row.append(cut)
+            print("\t".join("{}".format(v) for v in row))
+
+    def block(self, blk):
+        """A parsed TSV chunk (tsvio.TsvBlock): its integer lines go to the GPU as ONE int16 batch straight from the
+        tokenizer's rows (every motif against them); any other line takes the per-read route, in its place."""
+        a = self.args
+        fast = (blk.flags & 27) == 3                                        # ALLINT | ANY, not SLOW / SHORT
+        if a.after_stall:
+            fast[:] = False                                                 # (needs the raw reads on the host)
+        idx = np.flatnonzero(fast)
+        res, hits = {}, None
+        if idx.size:
+            rows = blk.rows[idx] if idx.size != blk.n else blk.rows
+            hits = api.motifseq_multi_batch(rows, blk.nsamp[idx], [np.asarray(self.models[n], dtype=np.float64)
+                                                                    for n in self.order],
+                                            a.scale, a.scale_low, a.scale_hi)
+            res = {int(i): k for k, i in enumerate(idx)}
+        for i in range(blk.n):
+            k = res.get(i)
+            if k is not None:
+                sig = blk.rows[i, :blk.nsamp[i]] if a.sig_extract else None
+                self.emit(blk.name(i), blk.read_id(i), [hits[c][k] for c in range(len(self.order))], sig, None)
+                continue
+            fl = int(blk.flags[i])
+            if (fl & 27) == 1:                                              # integers, all zero: MotifSeq.py:271-273
+                sys.stderr.write("No Signal found - please check signal format\n")
+                continue
+            fast5, read_id, sig = tsvio.parse_motifseq_line(blk.line(i).decode())   # the reference's own parse
+            if not sig.any():
+                sys.stderr.write("No Signal found - please check signal format\n")
+                continue
+            self.add(fast5, read_id, sig)
+            self.flush()                                                    # keeps the output in file order
 
 
 def main(argv=None):
@@ -202,16 +240,24 @@ def main(argv=None):
         api.set_devices(range(args.gpus))
     out = _Batcher(args, models, order, lens)
     if args.signal:
-        for fast5, read_id, vals, fl, raw in tsvio.iter_tsv_native(args.signal, 8):
-            if fl & 8 or (fl & 16 and raw is not None and raw.count(b"\t") < 1):
-                # odd tokens (or not even a readID column): the reference's own parse, exceptions included
-                fast5, read_id, sig = tsvio.parse_motifseq_line(raw.decode())
-            else:
-                sig = vals
-            if not sig.any():                        # MotifSeq.py:271-273
-                out.note("No Signal found - please check signal format\n")
+        # native tokenizer (csrc/sk_tsv.cpp): integer lines arrive as int16 rows, one GPU batch per chunk of the
+        # file; decimal (pA) chunks go through the float64 tokenizer, odd lines through the reference's own parse
+        for blk in tsvio.iter_tsv_blocks_i16(args.signal, 8):
+            if blk.mostly_integer():
+                out.block(blk)
                 continue
-            out.add(fast5, read_id, sig)
+            out.flush()
+            for fast5, read_id, vals, fl, raw in blk.float_lines(8):
+                if fl & 8 or (fl & 16 and raw is not None and raw.count(b"\t") < 1):
+                    # odd tokens (or not even a readID column): the reference's own parse, exceptions included
+                    fast5, read_id, sig = tsvio.parse_motifseq_line(raw.decode())
+                else:
+                    sig = vals
+                if not sig.any():                        # MotifSeq.py:271-273
+                    out.note("No Signal found - please check signal format\n")
+                    continue
+                out.add(fast5, read_id, sig)
+            out.flush()
     else:
         if args.f5f:                                 # MotifSeq.py:165-184: first column = path
             with tsvio.open_text(args.f5f) as fh:

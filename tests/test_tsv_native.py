@@ -94,3 +94,63 @@ def test_streaming_order_across_chunks(tmp_path, gz):
     for i, (name, rid, vals, fl, raw) in enumerate(got):
         assert (name, rid) == ("r%d" % i, "id%d" % i)
         assert np.array_equal(vals, want[i].astype(float))
+
+
+def test_int16_block_parser_agrees_with_python(tmp_path):
+    """sk_tsv_parse_i16: integer lines land in int16 rows exactly as int() would give them; every line it does not
+    take (decimals, signs with spaces, underscores, empty tokens, CR, values outside int16, too few columns) is
+    flagged for the general path; names / ids / raw lines come back intact."""
+    from squigglekit_amd import tsvio
+    rng = np.random.default_rng(31)
+    lines, kinds = [], []
+    for i in range(400):
+        n = int(rng.integers(0, 60))
+        vals = [str(int(v)) for v in rng.integers(-300, 1300, n)]
+        kind = int(rng.integers(0, 12))
+        if kind == 0 and n:
+            vals[int(rng.integers(n))] = "%.2f" % rng.normal(90, 10)          # a decimal
+        elif kind == 1 and n:
+            vals[int(rng.integers(n))] = ["5_0", " 7", "", "0x1f", "1e3", "+-3", "nan"][int(rng.integers(7))]
+        elif kind == 2 and n:
+            vals[int(rng.integers(n))] = str(int(rng.choice([32768, -32769, 99999999999])))
+        elif kind == 3:
+            vals = ["0"] * n                                                   # all zero
+        elif kind == 4 and n:
+            vals[0] = "+" + vals[0].lstrip("-")
+            vals[-1] = "-0" if n > 1 else vals[-1]
+        elif kind == 5 and n:
+            vals[-1] = vals[-1] + "\r"
+        elif kind == 6:
+            vals = vals[:0]                                                    # no data column at all
+        head = ["f%d.fast5" % i, "id-%d" % i, "a", "b"]
+        if kind == 6 and rng.random() < 0.5:
+            head = head[:int(rng.integers(1, 4))]
+        lines.append("\t".join(head + vals))
+        kinds.append(kind)
+    p = tmp_path / "mix.tsv"
+    p.write_text("\n".join(lines) + ("\n" if rng.random() < 0.5 else ""))
+    seen = 0
+    for blk in tsvio.iter_tsv_blocks_i16(str(p), 4, chunk_bytes=4096, nthreads=3):
+        for i in range(blk.n):
+            line = lines[seen]
+            cols = line.split("\t")
+            assert blk.line(i).decode() == line
+            assert blk.name(i) == cols[0]
+            if len(cols) > 1:
+                assert blk.read_id(i) == cols[1]
+            data = cols[4:]
+            fl = int(blk.flags[i])
+            plain = all(t.lstrip("+-").isdigit() and t.isascii() and t.count("+") + t.count("-") <= 1
+                        and t[-1].isdigit() and (t[0].isdigit() or t[0] in "+-") for t in data)
+            fits = plain and all(-32768 <= int(t) <= 32767 for t in data)
+            if len(cols) <= 4:
+                assert fl & 16 and not (fl & 1)
+            elif fits:
+                assert (fl & 25) == 1, (line, fl)
+                assert blk.nsamp[i] == len(data)
+                assert blk.rows[i, :len(data)].tolist() == [int(t) for t in data]
+                assert bool(fl & 2) == any(int(t) != 0 for t in data)
+            else:
+                assert (fl & 9) == 8, (line, fl)
+            seen += 1
+    assert seen == len(lines)
