@@ -38,10 +38,12 @@ def parse_motifseq_line(line):
     return cols[0], cols[1], np.array([float(v) for v in cols[8:]])
 
 
-def _parse_block_float(buf, start_col, nthreads):
+def _parse_block_float(chunk, start_col, nthreads):
     """One whole-line chunk through the float64 tokenizer (sk_tsv_parse): (name, read_id, values, flags, raw)."""
     from . import _lib
     L = _lib.load()
+    src, start, end = chunk
+    buf = src[start:end] if not isinstance(src, bytes) or start or end != len(src) else src   # (bytes: the slow lines are sliced)
     n = L.sk_tsv_count_lines(buf, len(buf))
     if n <= 0:
         return
@@ -81,14 +83,34 @@ def iter_tsv_native(path, start_col, chunk_bytes=64 << 20, nthreads=None):
     No GPU is involved; the library only has to be loadable."""
     import os
     nthreads = nthreads or min(32, os.cpu_count() or 1)
-    for buf in _line_blocks(path, chunk_bytes):
-        yield from _parse_block_float(buf, start_col, nthreads)
+    for chunk in _line_blocks(path, chunk_bytes):
+        yield from _parse_block_float(chunk, start_col, nthreads)
 
 
 def _line_blocks(path, chunk_bytes):
-    """Whole-line chunks of a (possibly gzipped) text file, as bytes."""
-    opener = gzip.open if path.endswith(".gz") else open
-    with opener(path, "rb") as fh:
+    """Whole-line chunks of a text file as (buffer, start, end): for plain files a read-only memory map and byte
+    ranges into it (nothing is copied on the Python side), for .gz files decompressed bytes."""
+    if not path.endswith(".gz"):
+        import mmap
+        import os
+        size = os.path.getsize(path)
+        if size == 0:
+            return
+        with open(path, "rb") as fh:
+            mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+        pos = 0
+        while pos < size:
+            end = min(size, pos + chunk_bytes)
+            if end < size:
+                cut = mm.rfind(b"\n", pos, end)
+                while cut < 0 and end < size:                # one line longer than a chunk: extend
+                    end = min(size, end + chunk_bytes)
+                    cut = mm.rfind(b"\n", pos, end) if end < size else size - 1
+                end = cut + 1
+            yield mm, pos, end
+            pos = end
+        return
+    with gzip.open(path, "rb") as fh:
         tail = b""
         while True:
             block = fh.read(chunk_bytes)
@@ -104,7 +126,15 @@ def _line_blocks(path, chunk_bytes):
             else:
                 tail = b""
             if buf:
-                yield buf
+                yield buf, 0, len(buf)
+
+
+def _cptr(buf, start):
+    """C pointer to buf[start] for bytes or a read-only mmap (no copy)."""
+    import ctypes as C
+    if isinstance(buf, bytes):
+        return C.c_void_p(C.cast(C.c_char_p(buf), C.c_void_p).value + start)
+    return C.c_void_p(np.frombuffer(buf, dtype=np.uint8).ctypes.data + start)
 
 
 class TsvBlock:
@@ -112,19 +142,22 @@ class TsvBlock:
     int16 (flags & 1) sit ready in `rows` (int16 [n, stride], `nsamp` tokens each); the others (flags & 8: some
     other token; & 16: no data column) are handed out as raw bytes by line(i) for the reference's own parse."""
 
-    def __init__(self, buf, rows, nsamp, flags, name_off, name_len, id_off, id_len, line_off):
-        self.buf, self.rows, self.nsamp, self.flags = buf, rows, nsamp, flags
+    def __init__(self, chunk, rows, nsamp, flags, name_off, name_len, id_off, id_len, line_off):
+        self.buf, self.base, self.end = chunk                     # bytes or mmap; this chunk is buf[base:end]
+        self.rows, self.nsamp, self.flags = rows, nsamp, flags
         self._no, self._nl, self._io, self._il, self._lo = name_off, name_len, id_off, id_len, line_off
         self.n = len(flags)
 
     def name(self, i):
-        return self.buf[self._no[i]:self._no[i] + self._nl[i]].decode()
+        a = self.base + int(self._no[i])
+        return self.buf[a:a + int(self._nl[i])].decode()
 
     def read_id(self, i):
-        return self.buf[self._io[i]:self._io[i] + self._il[i]].decode()
+        a = self.base + int(self._io[i])
+        return self.buf[a:a + int(self._il[i])].decode()
 
     def line(self, i):
-        return self.buf[self._lo[i]:self._lo[i + 1]].rstrip(b"\n")
+        return self.buf[self.base + int(self._lo[i]):self.base + int(self._lo[i + 1])].rstrip(b"\n")
 
     def mostly_integer(self):
         """False for chunks of decimal (pA) lines: those go through the float64 tokenizer instead."""
@@ -132,7 +165,7 @@ class TsvBlock:
 
     def float_lines(self, start_col, nthreads=None):
         import os
-        return _parse_block_float(self.buf, start_col, nthreads or min(32, os.cpu_count() or 1))
+        return _parse_block_float((self.buf, self.base, self.end), start_col, nthreads or min(32, os.cpu_count() or 1))
 
 
 def iter_tsv_blocks_i16(path, start_col, chunk_bytes=48 << 20, nthreads=None):
@@ -142,16 +175,18 @@ def iter_tsv_blocks_i16(path, start_col, chunk_bytes=48 << 20, nthreads=None):
     from . import _lib
     L = _lib.load()
     nthreads = nthreads or min(32, os.cpu_count() or 1)
-    for buf in _line_blocks(path, chunk_bytes):
-        n = L.sk_tsv_count_lines(buf, len(buf))
+    for chunk in _line_blocks(path, chunk_bytes):
+        src, start, end = chunk
+        cp, clen = _cptr(src, start), end - start
+        n = L.sk_tsv_count_lines(cp, clen)
         if n <= 0:
             continue
         ntok = np.zeros(n, dtype=np.int64)
-        _lib.check(L.sk_tsv_count_tokens(buf, len(buf), start_col, n, _lib.ptr(ntok), nthreads))
+        _lib.check(L.sk_tsv_count_tokens(cp, clen, start_col, n, _lib.ptr(ntok), nthreads))
         stride = max(8, (int(ntok.max()) + 7) // 8 * 8)
         if n * stride * 2 > (3 << 30):               # one enormous line among short ones: not worth a dense block
             stride = max(8, (int(np.percentile(ntok, 99)) + 7) // 8 * 8)   # (longer lines are flagged SLOW)
-        rows = np.zeros((n, stride), dtype=np.int16)
+        rows = np.empty((n, stride), dtype=np.int16)
         nsamp = np.zeros(n, dtype=np.int32)
         flags = np.zeros(n, dtype=np.int32)
         name_off = np.zeros(n, dtype=np.int64)
@@ -159,10 +194,10 @@ def iter_tsv_blocks_i16(path, start_col, chunk_bytes=48 << 20, nthreads=None):
         id_off = np.zeros(n, dtype=np.int64)
         id_len = np.zeros(n, dtype=np.int32)
         line_off = np.zeros(n + 1, dtype=np.int64)
-        _lib.check(L.sk_tsv_parse_i16(buf, len(buf), start_col, n, stride, _lib.ptr(rows), _lib.ptr(nsamp),
+        _lib.check(L.sk_tsv_parse_i16(cp, clen, start_col, n, stride, _lib.ptr(rows), _lib.ptr(nsamp),
                                       _lib.ptr(name_off), _lib.ptr(name_len), _lib.ptr(id_off), _lib.ptr(id_len),
                                       _lib.ptr(flags), _lib.ptr(line_off), nthreads))
-        yield TsvBlock(buf, rows, nsamp, flags, name_off, name_len, id_off, id_len, line_off)
+        yield TsvBlock(chunk, rows, nsamp, flags, name_off, name_len, id_off, id_len, line_off)
 
 
 # ----------------------------------------------------------------------------
