@@ -5,9 +5,12 @@
 
 Used for the SQ pass of tools/profile_round.sh (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES,
 SQ_WAVES, SQ_INSTS_LDS, SQ_INSTS_SALU, SQ_WAIT_INST_ANY + GRBM_GUI_ACTIVE), collected with --kernel-trace only.
-Derived per kernel:  valu_per_wave = SQ_INSTS_VALU / SQ_WAVES;  valu_issue_cycles = 4 * SQ_ACTIVE_INST_VALU /
-SQ_INSTS_VALU (SQ_ACTIVE_* count quad-cycles, MI355X_MICROARCH.md);  valu_busy = 4 * SQ_ACTIVE_INST_VALU /
-(GRBM_GUI_ACTIVE * 1024 SIMDs) -- the share of all SIMD cycles of the launch that issued vector ALU work."""
+Derived per kernel:  valu_per_wave = SQ_INSTS_VALU / SQ_WAVES;  valu_busy_at_4_cycles = 4 * SQ_INSTS_VALU /
+(kernel cycles * 1024 SIMDs) with kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter comes back summed over the 8
+XCDs: 36.0 M for a 2.08 ms kernel) -- the share of all SIMD issue cycles the launch's vector instructions would
+fill at 4 cycles each (tools/ubench/valu_rate: 2.5-2.7 cycles for add / and / xor / bitop3 / mov, 4.2-4.6 for the
+rest), so a kernel made of the cheap ones can read above 1.  SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU on this
+stack (one count per instruction), so it says nothing about issue cycles."""
 import collections
 import csv
 import glob
@@ -35,10 +38,9 @@ def main():
         m["dispatches"] = max(len(v) for v in cs.values())
         if m.get("SQ_WAVES") and m.get("SQ_INSTS_VALU"):
             m["valu_per_wave"] = m["SQ_INSTS_VALU"] / m["SQ_WAVES"]
-        if m.get("SQ_ACTIVE_INST_VALU") and m.get("SQ_INSTS_VALU"):
-            m["valu_issue_cycles_per_inst"] = 4.0 * m["SQ_ACTIVE_INST_VALU"] / m["SQ_INSTS_VALU"]
-        if m.get("SQ_ACTIVE_INST_VALU") and m.get("GRBM_GUI_ACTIVE"):
-            m["valu_busy_frac_of_all_simd_cycles"] = 4.0 * m["SQ_ACTIVE_INST_VALU"] / (m["GRBM_GUI_ACTIVE"] * 1024.0)
+        if m.get("SQ_INSTS_VALU") and m.get("GRBM_GUI_ACTIVE"):
+            m["kernel_cycles"] = m["GRBM_GUI_ACTIVE"] / 8.0
+            m["valu_busy_at_4_cycles"] = 4.0 * m["SQ_INSTS_VALU"] / (m["kernel_cycles"] * 1024.0)
         out["kernels"][k] = m
     print(json.dumps(out, indent=1))
 
