@@ -8,8 +8,8 @@ while computing.  Two launch shapes:
   * one process, one host thread per GPU (`ThreadGroup`): what `api.*(devices=[...])`, the CLIs' `--gpus` and
     a plain `python bench.py --gpus N` use.  The library binds a device per thread; ctypes releases the GIL.
   * one process per GPU (`ProcessGroup`): what `python -m torch.distributed.run ... bench.py` gives.  Only the
-    launcher's environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_PORT) is read; rank 0's ncclUniqueId travels
-    through a small file store under $TMPDIR (one node), no torch import anywhere.
+    launcher's environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR / MASTER_PORT) is read; rank 0's ncclUniqueId
+    travels through a small file store under $TMPDIR (one node), no torch import anywhere.
 
 The gather is `ncclAllGather` inside the library (`sk_comm_*`, csrc/sk_comm.hip).  If librccl cannot be loaded
 or a communicator cannot be created, the same interface is served by host concatenation (`backend == "host"`).
@@ -60,33 +60,31 @@ def plan(gpus, environ=None):
 # ------------------------------------------------------------------------------------------------
 # a tiny file store: rendezvous for the process-per-GPU shape, and the host fallback exchange
 # ------------------------------------------------------------------------------------------------
-def _proc_start(pid):
-    try:
-        with open("/proc/%d/stat" % pid) as fh:
-            return fh.read().rsplit(")", 1)[1].split()[19]          # starttime (field 22)
-    except (OSError, IndexError):
-        return "0"
-
-
 def store_dir(environ=None):
-    """One directory per launch: keyed on the launcher process (pid + start time, shared by its workers),
-    the rendezvous port and the restart count, so a stale directory of an earlier launch is never read."""
+    """One directory per job on this node: keyed on what every rank of a launch shares whatever started it --
+    the rendezvous address and port (unique among the jobs running on a node) and the launcher's run id.  A stale
+    directory of an earlier job with the same key is harmless: nothing in it carries this job's session id
+    (FileStore.rendezvous)."""
     e = os.environ if environ is None else environ
     if e.get("SK_RDZV_DIR"):
         return e["SK_RDZV_DIR"]
-    ppid = os.getppid()
-    tag = "sk_rdzv_%d_%d_%s_%s_%s_%s" % (os.getuid(), ppid, _proc_start(ppid), e.get("MASTER_PORT", "0"),
-                                        e.get("TORCHELASTIC_RUN_ID", "none"), e.get("TORCHELASTIC_RESTART_COUNT", "0"))
+    tag = "sk_rdzv_%d_%s_%s_%s" % (os.getuid(), e.get("MASTER_ADDR", "local").replace("/", "_"),
+                                  e.get("MASTER_PORT", "0"), e.get("TORCHELASTIC_RUN_ID", "none").replace("/", "_"))
     return os.path.join(tempfile.gettempdir(), tag)
 
 
 class FileStore:
-    """Atomic small-file exchange between the ranks of one node."""
+    """Atomic small-file exchange between the ranks of one node.
+
+    rendezvous() first agrees on a session id so that files a crashed earlier job left under the same key are never
+    taken for this job's: every rank publishes a fresh nonce, rank 0 publishes {session, payload, the nonces it has
+    seen} and repeats that until every rank has acknowledged a version carrying its own current nonce."""
 
     def __init__(self, path, rank, world, timeout=300.0):
         self.path, self.rank, self.world, self.timeout = path, rank, world, timeout
         os.makedirs(path, exist_ok=True)
         self._seq = 0
+        self.session = None
 
     def put(self, key, data):
         tmp = os.path.join(self.path, ".%s.%d.tmp" % (key, self.rank))
@@ -94,31 +92,66 @@ class FileStore:
             fh.write(data)
         os.replace(tmp, os.path.join(self.path, key))
 
-    def get(self, key):
-        p = os.path.join(self.path, key)
+    def peek(self, key):
+        try:
+            with open(os.path.join(self.path, key), "rb") as fh:
+                return fh.read()
+        except FileNotFoundError:
+            return None
+
+    def get(self, key, accept=None):
         t0, nap = time.monotonic(), 0.0005
         while True:
-            try:
-                with open(p, "rb") as fh:
-                    return fh.read()
-            except FileNotFoundError:
+            data = self.peek(key)
+            if data is not None and (accept is None or accept(data)):
+                return data
+            if time.monotonic() - t0 > self.timeout:
+                raise TimeoutError("rank %d: nothing usable at %s/%s after %.0f s"
+                                   % (self.rank, self.path, key, self.timeout))
+            time.sleep(nap)
+            nap = min(nap * 2, 0.02)
+
+    def rendezvous(self, payload=b""):
+        """Agree on a session; rank 0's `payload` (e.g. the ncclUniqueId) reaches every rank.  Returns it."""
+        nonce = os.urandom(8).hex().encode()
+        self.put("hello.%d" % self.rank, nonce)
+        if self.rank == 0:
+            session = os.urandom(8).hex().encode()
+            t0 = time.monotonic()
+            while True:
+                seen = [self.peek("hello.%d" % r) or b"-" for r in range(self.world)]
+                self.put("session", b"|".join([session, payload.hex().encode()] + seen))
+                time.sleep(0.002)
+                acks = [self.peek("ack.%d" % r) for r in range(1, self.world)]
+                if all(a == session for a in acks):
+                    break
                 if time.monotonic() - t0 > self.timeout:
-                    raise TimeoutError("rank %d: nothing at %s after %.0f s" % (self.rank, p, self.timeout))
-                time.sleep(nap)
-                nap = min(nap * 2, 0.02)
+                    raise TimeoutError("rank 0: ranks %s never joined %s"
+                                       % ([r + 1 for r, a in enumerate(acks) if a != session], self.path))
+            self.session = session.decode()
+            return payload
+        blob = self.get("session", accept=lambda d: d.split(b"|")[2 + self.rank:3 + self.rank] == [nonce])
+        parts = blob.split(b"|")
+        self.put("ack.%d" % self.rank, parts[0])
+        self.session = parts[0].decode()
+        return bytes.fromhex(parts[1].decode())
 
     def allgather(self, payload):
+        if self.session is None:
+            self.rendezvous()
         self._seq += 1
-        self.put("ag%d.%d" % (self._seq, self.rank), payload)
-        return [self.get("ag%d.%d" % (self._seq, r)) for r in range(self.world)]
+        self.put("ag.%s.%d.%d" % (self.session, self._seq, self.rank), payload)
+        return [self.get("ag.%s.%d.%d" % (self.session, self._seq, r)) for r in range(self.world)]
 
     def close(self):
         """Every rank leaves a note; rank 0 waits for all of them (nobody reads the store any more), then removes
         the directory.  The other ranks wait for nothing, so the removal cannot strand them."""
-        self.put("bye.%d" % self.rank, b"")
+        if self.session is None:
+            return
+        self.put("bye.%s.%d" % (self.session, self.rank), b"")
         if self.rank == 0:
             for r in range(self.world):
-                self.get("bye.%d" % r)
+                self.get("bye.%s.%d" % (self.session, r))
             shutil.rmtree(self.path, ignore_errors=True)
 
 
@@ -252,31 +285,31 @@ class ProcessGroup:
         self.backend, self.why_host = "host", None
         if bind:
             _lib.init(local_rank)
-        if _want_rccl() and bind:
+        payload = b"\0"                                             # [0]: 1 = an ncclUniqueId follows
+        if _want_rccl() and bind and rank == 0:
             L = _lib.load()
             uid = C.create_string_buffer(UID_BYTES)
-            ok = 1
-            if rank == 0:
-                rc = L.sk_comm_unique_id(uid)
-                ok = 1 if rc == 0 else 0
-                if rc not in (0, -5):
-                    check(rc)
-                if not ok:
-                    self.why_host = L.sk_last_error().decode(errors="replace")
-                self.store.put("uid", bytes([ok]) + uid.raw)
-            blob = self.store.get("uid")
-            if blob[0] == 1:
-                rc = L.sk_comm_init_rank(blob[1:1 + UID_BYTES], world, rank)
-                mine = 1 if rc == 0 else 0
-                if not mine:
-                    self.why_host = L.sk_last_error().decode(errors="replace")
-                votes = self.store.allgather(bytes([mine]))           # all or nothing
-                if all(v == b"\x01" for v in votes):
-                    self.backend = "rccl"
-                elif mine:
-                    L.sk_comm_destroy()
-        elif not _want_rccl():
+            rc = L.sk_comm_unique_id(uid)
+            if rc == 0:
+                payload = b"\1" + uid.raw
+            elif rc == -5:                                           # SK_ERR_UNSUPPORTED: no RCCL here
+                self.why_host = L.sk_last_error().decode(errors="replace")
+            else:
+                check(rc)
+        blob = self.store.rendezvous(payload)
+        if not _want_rccl():
             self.why_host = "SK_COMM=host"
+        elif bind and blob[:1] == b"\1":
+            L = _lib.load()
+            rc = L.sk_comm_init_rank(blob[1:1 + UID_BYTES], world, rank)
+            mine = 1 if rc == 0 else 0
+            if not mine:
+                self.why_host = L.sk_last_error().decode(errors="replace")
+            votes = self.store.allgather(bytes([mine]))               # all or nothing
+            if all(v == b"\x01" for v in votes):
+                self.backend = "rccl"
+            elif mine:
+                L.sk_comm_destroy()
         self.comm = RankComm(rank, world, self.backend, self.store.allgather)
 
     def __enter__(self):

@@ -113,9 +113,18 @@ with multigpu.ProcessGroup(rank, local, world, bind=False) as comm:
 @pytest.mark.parametrize("total", [17, 32])
 def test_process_group_file_store_world2(total, tmp_path):
     """Two processes with the launcher's environment (as torch.distributed.run sets it), no torch: the rendezvous
-    directory, the exchange and the assembled result."""
+    directory, the exchange and the assembled result.  The directory starts out holding what a crashed earlier job
+    with the same address / port left behind: none of it may be taken for this job's."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
+    stale = tmp_path / ("sk_rdzv_%d_127.0.0.1_29%03d_none" % (os.getuid(), total + 100))
+    stale.mkdir()
+    (stale / "session").write_bytes(b"deadbeefdeadbeef|00|aaaaaaaaaaaaaaaa|bbbbbbbbbbbbbbbb")
+    (stale / "hello.0").write_bytes(b"aaaaaaaaaaaaaaaa")
+    (stale / "hello.1").write_bytes(b"bbbbbbbbbbbbbbbb")
+    (stale / "ack.1").write_bytes(b"deadbeefdeadbeef")
+    (stale / "ag.deadbeefdeadbeef.1.0").write_bytes(b"stale")
+    (stale / "ag.deadbeefdeadbeef.1.1").write_bytes(b"stale")
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
