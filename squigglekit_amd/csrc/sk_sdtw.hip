@@ -426,7 +426,9 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     // latency of one sweep, which is shorter with the read spread over 64 lanes (fewer rows per lane).
     // Measured at 163 points x 4 000 samples: 64 reads 1.12 -> 0.54 ms, 1 024 reads 0.52 -> 0.29 ms,
     // break-even near 4 096 reads.
-    if (L == 16 && N >= 32 && a->nreads <= 2048 && !getenv("SK_DTW_NO_SMALL")) { L = 64; R = (N + 63) / 64; }
+    int small_max = 2048;
+    if (const char *e = getenv("SK_DTW_SMALL_MAX")) { int v = atoi(e); if (v >= 0) small_max = v; }
+    if (L == 16 && N >= 32 && a->nreads <= small_max && !getenv("SK_DTW_NO_SMALL")) { L = 64; R = (N + 63) / 64; }
     const int P = L * R - N;                 // short lanes (own R-1 rows), always < L
 
     // The laid-out motif stays resident between calls; re-upload only when it changes.

@@ -20,7 +20,6 @@ to the next file, like the reference does when h5py throws.
         sig = f["Raw/Reads"][name]["Signal"][()]          # numpy array
         rid = f["Raw/Reads"][name].attrs["read_id"]       # bytes, like h5py
 """
-import struct
 import zlib
 
 import numpy as np
@@ -34,14 +33,6 @@ class Hdf5Unsupported(Exception):
 
 class Hdf5Error(Exception):
     pass
-
-
-class _Buf:
-    def __init__(self, data):
-        self.b = data
-
-    def u(self, off, size):
-        return int.from_bytes(self.b[off:off + size], "little")
 
 
 def _pad8(n):
