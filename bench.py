@@ -124,6 +124,7 @@ class Workload:
             self.d_out = alloc(max(1, self.pad) * 4)                  # nsegs: the fixed-size record gathered
             self.sp = SegParams()
         self.d_all = alloc(max(1, self.pad) * self.rec_bytes * world) if comm is not None else None
+        self.host_rec = None
 
     def _alloc(self, nbytes):
         from squigglekit_amd._lib import check
@@ -148,9 +149,17 @@ class Workload:
             else:
                 check(L.sk_segment_dev_i16(self.d_sig, self.stride, self.d_len, self.R, C.byref(self.sp),
                                            self.d_segs, self.d_out, MAX_SEGS))
-        if self.comm is not None:                   # the one exchange: gather of the result records (RCCL)
+        if self.comm is not None and self.comm.backend == "rccl":
+            # the one exchange: all-gather of the result records over RCCL, on the library's stream
             self.comm.allgather_dev(self.d_out, self.d_all, self.pad * self.rec_bytes)
         check(L.sk_sync())
+        if self.comm is not None and self.comm.backend != "rccl":
+            # RCCL could not be loaded / initialised: the same exchange by host concatenation
+            if self.host_rec is None:
+                self.host_rec = np.zeros(max(1, self.pad) * self.rec_bytes, dtype=np.uint8)
+            if self.R:
+                check(L.sk_dev_download(ptr(self.host_rec), self.d_out, self.R * self.rec_bytes))
+            self.comm.allgather_host(self.host_rec)
 
     def kernel_ms(self):
         from squigglekit_amd._lib import check
