@@ -60,17 +60,19 @@ def test_process_group_rccl_unique_id_one_rank(gpu, tmp_path, monkeypatch):
     assert not (tmp_path / "store").exists()
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_gather_path_bare_python(gpu, scaling):
-    """`python bench.py` run plainly (no launcher), with the per-step RCCL gather forced on at one rank."""
+@pytest.mark.parametrize("scaling,backend", [("weak", "rccl"), ("strong", "rccl"), ("weak", "host")])
+def test_bench_gather_path_bare_python(gpu, scaling, backend):
+    """`python bench.py` run plainly (no launcher), with the per-step gather forced on at one rank: over RCCL, and by
+    host concatenation (what a node without a usable librccl gets; SK_COMM=host)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-comm", "--reads", "20000", "--steps", "2",
            "--warmup", "1", "--cpu-seconds", "2", "--no-extras", "--scaling", scaling]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    env = dict(os.environ, SK_COMM=backend)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = p.stdout.strip().splitlines()
     assert lines[-1].startswith("{"), "the JSON line must be the last thing on stdout: %r" % lines[-3:]
     line = json.loads(lines[-1])
     assert line["n_gpus"] == 1 and line["scaling"] == scaling
-    assert line["config"]["gather_backend"] == "rccl" and line["config"]["ranks_seen"] == 1
+    assert line["config"]["gather_backend"] == backend and line["config"]["ranks_seen"] == 1
     assert line["parity"]["dist_bit_identical"] and line["parity"]["start_end_exact"]
     assert "torch" not in p.stderr
