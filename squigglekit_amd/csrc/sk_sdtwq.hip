@@ -154,6 +154,7 @@ void k_sdtw_q(const sdtw_kargs a)
         return ok ? qimg(v) : QINF;
     };
 
+    const unsigned smask = shortlane ? 0xffffffffu : 0u;
     unsigned *lastq = a.lastq + (int64_t)(r - a.read0) * a.lq_stride;
     // Per read group, in LDS: the sample images of the previous and the current block (lane l
     // needs sample t - l at step t: one ds_read with an immediate offset instead of a DPP shift
@@ -171,8 +172,9 @@ void k_sdtw_q(const sdtw_kargs a)
         const unsigned upq = (unsigned)__builtin_amdgcn_update_dpp(0, (int)botq, SHR, 0xF, 0xF, true);
         qcolumn<R>(old, nw, xq, yq, diagq, upq);
         diagq = upq;
-        if constexpr (R >= 2) botq = shortlane ? nw[R - 2] : nw[R - 1];
-        else                  botq = shortlane ? upq : nw[0];
+        // (a bit select, v_bitop3_b32: 2.6 cycles of issue against v_cndmask's 4.6)
+        if constexpr (R >= 2) asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(botq) : "v"(nw[R - 2]), "v"(nw[R - 1]), "v"(smask));
+        else                  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(botq) : "v"(upq), "v"(nw[0]), "v"(smask));
         *hslot = nw[R - 1];                         // (only lane L-1's lands in hbuf)
     };
     for (int blk = 0; blk < nblk; blk++) {
