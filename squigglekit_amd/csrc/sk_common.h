@@ -80,9 +80,10 @@ sk_ctx *sk_ctx_of(int device);              // context slot of a device (ready o
 int  sk_bound_device(void);                 // device the calling thread is bound to, or -1
 int  sk_fail(int code, const char *fmt, ...);
 int  sk_reserve(sk_ctx *c, sk_buf *b, size_t bytes);
-// Reads per chunk of a checkpointing DTW call: scratch budget (12 GB, or SK_DTW_SCRATCH_MB) / per_read, at
+// Reads per chunk of a checkpointing DTW call: scratch budget (64 GB, or SK_DTW_SCRATCH_MB) / per_read, at
 // least 1024 reads (64 when the budget was set by hand, so that tests can force many small chunks).
 int64_t sk_dtw_chunk_reads(size_t per_read, int64_t nreads);
+void    sk_dtw_scratch_shrink(int reset);   // halve the calling thread's scratch budget (reset != 0: back to the default)
 #define SK_HIP(call)                                                                    \
     do {                                                                                \
         hipError_t e_ = (call);                                                         \

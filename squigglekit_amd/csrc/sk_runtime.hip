@@ -53,14 +53,21 @@ int sk_reserve(sk_ctx *c, sk_buf *b, size_t bytes)
     return SK_OK;
 }
 
+static thread_local int g_dtw_shrink = 0;       // halvings of the scratch budget after a failed allocation
+void sk_dtw_scratch_shrink(int reset) { g_dtw_shrink = reset ? 0 : (g_dtw_shrink < 12 ? g_dtw_shrink + 1 : 12); }
+
 int64_t sk_dtw_chunk_reads(size_t per_read, int64_t nreads)
 {
-    size_t budget = (size_t)12 << 30;
+    // 64 GB of the 288: whole-chip "rounds" of equally long wavefronts make a launch's last, partly filled round
+    // pure loss, so few large chunks beat many small ones (C4, 1 M reads: 75.3 ms per step with 12 GB = 4 chunks,
+    // 72.9 ms with one chunk).  A caller short of memory gets smaller chunks (sk_dtw_scratch_shrink).
+    size_t budget = (size_t)64 << 30;
     int64_t floor_reads = 1024;
     if (const char *e = getenv("SK_DTW_SCRATCH_MB")) {
         const long v = atol(e);
         if (v > 0) { budget = (size_t)v << 20; floor_reads = 64; }
     }
+    budget >>= g_dtw_shrink;
     int64_t chunk = (int64_t)(budget / (per_read ? per_read : 1));
     if (chunk < floor_reads) chunk = floor_reads;
     if (chunk > nreads) chunk = nreads;

@@ -557,8 +557,14 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     }
     const int nck = (int)((maxlen + L - 1) / ck);          // checkpoints at steps ck, 2ck, ... <= last step
     const size_t per_read = (size_t)(nck > 0 ? nck : 1) * L * (R + 3) * sizeof(double);
-    const int64_t chunk = sk_dtw_chunk_reads(per_read, a->nreads);   // checkpoint scratch per chunk
-    if ((rc = sk_reserve(c, &c->ckpt, (size_t)chunk * per_read))) return rc;
+    int64_t chunk;                                         // checkpoint scratch per chunk
+    while (true) {
+        chunk = sk_dtw_chunk_reads(per_read, a->nreads);
+        rc = sk_reserve(c, &c->ckpt, (size_t)chunk * per_read);
+        if (rc != SK_ERR_NOMEM || chunk <= 1024) break;
+        sk_dtw_scratch_shrink(0);
+    }
+    if (rc) return rc;
     k.ckpt = (double *)c->ckpt.p; k.nck = nck; k.ck = ck; k.span = span;
     k.retry = cnt + 2; k.retry_cnt = cnt;
     // per-launch HIP events (pool grows on demand) so a profile can name each pass's duration

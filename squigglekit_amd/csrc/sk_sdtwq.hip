@@ -518,9 +518,15 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P,
     const size_t lq_stride = (size_t)((maxlen + 3) & ~(int64_t)3);
     const size_t per_read = (size_t)(nck > 0 ? nck : 1) * L * (R + 2) * sizeof(unsigned) +
                             lq_stride * sizeof(unsigned) + sizeof(int32_t);
-    const int64_t chunk = sk_dtw_chunk_reads(per_read, a->nreads);
-    if ((rc = sk_reserve(c, &c->ckpt, (size_t)chunk * (size_t)(nck > 0 ? nck : 1) * L * (R + 2) * sizeof(unsigned)))) return rc;
-    if ((rc = sk_reserve(c, &c->lastq, (size_t)chunk * lq_stride * sizeof(unsigned)))) return rc;
+    int64_t chunk;
+    while (true) {                                      // (a device short of memory: halve the budget and try again)
+        chunk = sk_dtw_chunk_reads(per_read, a->nreads);
+        rc = sk_reserve(c, &c->ckpt, (size_t)chunk * (size_t)(nck > 0 ? nck : 1) * L * (R + 2) * sizeof(unsigned));
+        if (!rc) rc = sk_reserve(c, &c->lastq, (size_t)chunk * lq_stride * sizeof(unsigned));
+        if (rc != SK_ERR_NOMEM || chunk <= 1024) break;
+        sk_dtw_scratch_shrink(0);
+    }
+    if (rc) return rc;
     if ((rc = sk_reserve(c, &c->qflag, (size_t)chunk * sizeof(int32_t)))) return rc;
     const bool tiers = span2 > span;
     if (tiers && (rc = sk_reserve(c, &c->wsoft, ((size_t)chunk + 1) * sizeof(int32_t)))) return rc;

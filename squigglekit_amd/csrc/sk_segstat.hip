@@ -115,7 +115,6 @@ struct SegStatArgs {
     uint4         *mask2;            // [nreads][row16] of {in band lo, hi, kept lo, hi}: 64 raw samples per entry
     int            row16;            // entries per read (8 per 512-sample tile)
     int32_t       *retry;            // [0] = count, [1 ..] = reads that could not be certified
-    int            touch;            // 1: prefetch the wave's next read into the L2
 };
 
 // NT: 512-sample tiles held in registers (one "window" of 512 NT samples)
@@ -174,14 +173,8 @@ void k_seg_stats(const SegStatArgs a)
     for (int r = blockIdx.x * WPB + w; r < a.nreads; r += nwaves) {
         const int M = __builtin_amdgcn_readfirstlane(min(max(a.len[r], 0), maxM));
         const int16_t *row = a.sig + (int64_t)r * a.stride;
-        // touch my NEXT read's row (one 4-byte load per 128-byte line, ahead of this read's loads): it is on its way
-        // into the L2 while this read is being worked on (SK_SEG_TOUCH=0 switches it off)
-        unsigned touch = 0u;
-        if (!LONG && a.touch) {
-            const int rn = r + nwaves;
-            if (rn < a.nreads && lane * 64 < maxM)
-                touch = *(const unsigned *)(a.sig + (int64_t)rn * a.stride + lane * 64);
-        }
+        // (measured and dropped: touching the wave's NEXT read with one 4-byte load per 128-byte line, to have it on
+        // its way into the L2 -- 2.34 ms against 2.00 ms per 1 M reads: the extra requests cost more than they hide)
         const int nwin = LONG ? (M + WIN - 1) / WIN : 1;
         const int tiles_total = (M + 511) >> 9;
 
@@ -328,7 +321,6 @@ void k_seg_stats(const SegStatArgs a)
                 a.mask2[(int64_t)r * a.row16 + wi * (8 * NT) + lane] = make_uint4(vi.x, vi.y, ~vd.x, ~vd.y);   // {in band, kept}
             }
         }
-        asm volatile("" :: "v"(touch));                    // (the touch's destination register stays reserved until here)
     }
 }
 
@@ -681,8 +673,6 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
     a.std_scale = p->std_scale; a.delta_scale = 1.0;
     if (const char *e = getenv("SK_SEG_DELTA_SCALE")) { const double v = atof(e); if (v > 0) a.delta_scale = v; }
     a.row16 = sk_segment_fast_row16(stride);
-    a.touch = 1;
-    if (const char *e = getenv("SK_SEG_TOUCH")) a.touch = atoi(e) != 0;
 
     WalkParams wp;
     wp.error = p->error; wp.corrector = p->corrector; wp.window = p->window; wp.seg_dist = p->seg_dist;

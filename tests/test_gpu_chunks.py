@@ -110,13 +110,21 @@ def _full_size(gpu, ora, R, M, N, seed, nsample, min_chunks):
         L.sk_dev_free(d_sig); L.sk_dev_free(d_len); L.sk_dev_free(d_out)
 
 
-def test_c4_full_size_1m_reads(gpu, ora):
-    """BASELINE configs[3] on one GPU: 1 000 000 x 4 000 int16 vs a 200-pt motif (4 chunks)."""
+@pytest.mark.parametrize("budget_mb", [None, 12288])
+def test_c4_full_size_1m_reads(gpu, ora, monkeypatch, budget_mb):
+    """BASELINE configs[3] on one GPU: 1 000 000 x 4 000 int16 vs a 200-pt motif -- with the default scratch budget
+    (64 GB: one chunk) and with 12 GB (4 chunks)."""
     from squigglekit_amd import synth
-    _full_size(gpu, ora, 1_000_000, 4000, 200, synth.SEED_C4, 2400, 3)
+    if budget_mb:
+        monkeypatch.setenv("SK_DTW_SCRATCH_MB", str(budget_mb))
+    _full_size(gpu, ora, 1_000_000, 4000, 200, synth.SEED_C4, 2400, 3 if budget_mb else 1)
 
 
-def test_c5_full_size_100k_long_reads(gpu, ora):
-    """BASELINE configs[4] on one GPU: 100 000 x 20 000 int16 vs a 500-pt motif (L = 64 kernels, chunked)."""
+@pytest.mark.parametrize("budget_mb", [None, 12288])
+def test_c5_full_size_100k_long_reads(gpu, ora, monkeypatch, budget_mb):
+    """BASELINE configs[4] on one GPU: 100 000 x 20 000 int16 vs a 500-pt motif (L = 64 kernels); one chunk by
+    default, 4 with a 12 GB scratch budget."""
     from squigglekit_amd import synth
-    _full_size(gpu, ora, 100_000, 20000, 500, synth.SEED_C5, 2000, 2)
+    if budget_mb:
+        monkeypatch.setenv("SK_DTW_SCRATCH_MB", str(budget_mb))
+    _full_size(gpu, ora, 100_000, 20000, 500, synth.SEED_C5, 2000, 2 if budget_mb else 1)
