@@ -694,7 +694,7 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
         SK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         for (int i = 0; i < 9; i++) SK_HIP(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
     }
-    int per_cu = 8, rounds = 4;
+    int per_cu = 8, rounds = 8;
     if (const char *e = getenv("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
     if (const char *e = getenv("SK_PREP_PERCU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }
 
@@ -712,7 +712,13 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
         int32_t *retry = d_retry + r0 + ci;
         a.sig = d_sig + (int64_t)r0 * stride; a.len = d_len + r0; a.nreads = nr;
         a.prep = d_prep + r0; a.mask2 = (uint4 *)d_mask2 + (int64_t)r0 * a.row16; a.retry = retry;
-        const long long g = (long long)c->num_cu * per_cu * rounds;
+        // persistent grid: a whole number of "rounds" of what the chip actually holds (6 workgroups per CU at 78
+        // VGPRs, not the 8 the thread limit allows) -- with 8 assumed the last round ran a third full
+        int resident = per_cu;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *)fn, 64 * WPB, 0) != hipSuccess || resident < 1)
+            resident = per_cu;
+        if (resident > per_cu) resident = per_cu;
+        const long long g = (long long)c->num_cu * resident * rounds;
         const long long need = ((long long)nr + WPB - 1) / WPB;
         const int grid = (int)(g > need ? need : g);
         hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * WPB), 0, c->stream, a);
