@@ -398,6 +398,12 @@ void k_sdtw_w(const sdtw_kargs a)
         y = fetch(tbase - 1 - l);                   // the sample this lane held after step tbase-1
     }
     double best = INF;  int bestS = -1, bestJ = -1;
+    // the running argmin is only wanted where lane L-1 sits on a candidate column -- the last few steps of the window:
+    // first step (relative to tbase) at which some read group of the wave needs it
+    int s0 = screened ? max(jlo - tbase + L - 1, 0) : 0x7fffffff;
+#pragma unroll
+    for (int d = L; d < 64; d <<= 1) s0 = min(s0, __shfl_xor(s0, d));
+    s0 = __builtin_amdgcn_readfirstlane(s0);
 
     double F = fetch(tbase + l);
     for (int blk = 0; blk < nblk; blk++) {
@@ -434,8 +440,10 @@ void k_sdtw_w(const sdtw_kargs a)
                 botD = shortlane ? upD : D[0];
                 botS = shortlane ? upS : S[0];
             }
-            const int j = t - l;
-            if (j >= jlo && j <= jhi && D[R - 1] < best) { best = D[R - 1]; bestS = S[R - 1]; bestJ = j; }
+            if (blk * L + q >= s0) {                       // (wave-uniform)
+                const int j = t - l;
+                if (j >= jlo && j <= jhi && D[R - 1] < best) { best = D[R - 1]; bestS = S[R - 1]; bestJ = j; }
+            }
         }
         F = Fnext;
     }

@@ -187,11 +187,31 @@ class _Batcher:
                                                                     for n in self.order],
                                             a.scale, a.scale_low, a.scale_hi)
             res = {int(i): k for k, i in enumerate(idx)}
+            # the scoring of MotifSeq.py:441-445 for the whole chunk at once (the same IEEE operations as the
+            # per-row arithmetic of emit(), so the same digits), then plain Python numbers for the formatting
+            cols = []
+            for c in range(len(self.order)):
+                h = hits[c]
+                mod_mean = (a.slope * self.lens[c]) + a.intercept
+                mod_stdev = mod_mean * a.std_const
+                with np.errstate(all="ignore"):
+                    z = (h["dist"] - mod_mean) / mod_stdev
+                    pv = norm_cdf(z)
+                    hp = (1 - pv) * 100
+                cols.append((h["flags"].tolist(), h["start"].tolist(), h["end"].tolist(), h["dist"].tolist(),
+                             mod_mean, mod_stdev, z.tolist(), pv.tolist(), hp.tolist()))
         for i in range(blk.n):
             k = res.get(i)
             if k is not None:
-                sig = blk.rows[i, :blk.nsamp[i]] if a.sig_extract else None
-                self.emit(blk.name(i), blk.read_id(i), [hits[c][k] for c in range(len(self.order))], sig, None)
+                if a.sig_extract or any(cols[c][0][k] & 3 for c in range(len(self.order))):
+                    sig = blk.rows[i, :blk.nsamp[i]] if a.sig_extract else None      # the general route: -x, flagged reads
+                    self.emit(blk.name(i), blk.read_id(i), [hits[c][k] for c in range(len(self.order))], sig, None)
+                    continue
+                fast5, read_id = blk.name(i), blk.read_id(i)
+                for c, name in enumerate(self.order):
+                    _, st, en, dist, mm, ms, z, pv, hp = cols[c]
+                    print("\t".join((fast5, read_id, name, str(st[k]), str(en[k]), str(en[k] - st[k]), repr(dist[k]),
+                                     str(mm), str(ms), repr(z[k]), repr(pv[k]), repr(hp[k]))))
                 continue
             fl = int(blk.flags[i])
             if (fl & 27) == 1:                                              # integers, all zero: MotifSeq.py:271-273
