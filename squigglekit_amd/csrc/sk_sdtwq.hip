@@ -421,11 +421,14 @@ void k_sdtw_w(const sdtw_kargs a)
             for (int k = 0; k < R; k++) {
                 const double lfD = D[k];  const int lfS = S[k];
                 const double c = fabs(x[k] - y);
+                // (no NaN can reach this pass -- pass Q sends reads with a non-finite or out-of-range sample to the
+                // exact single pass -- so v_min_f64 IS the ternary select of the reference's min3; written as a
+                // select the compiler spends two v_cndmask per double: 10 instructions per cell instead of 8)
                 const bool lt1 = lfD < dgD;
-                const double m1 = lt1 ? lfD : dgD;
+                const double m1 = vmin(lfD, dgD);
                 const int    s1 = lt1 ? lfS : dgS;
                 const bool lt2 = uD < m1;
-                const double m = lt2 ? uD : m1;
+                const double m = vmin(uD, m1);
                 const int    s = lt2 ? uS : s1;
                 const double nd = c + m;
                 dgD = lfD;  dgS = lfS;
