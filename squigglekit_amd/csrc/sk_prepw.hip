@@ -78,7 +78,8 @@ __device__ __forceinline__ int sample_of(const unsigned (&q)[4], int k)
 // Rank select on a histogram held in registers: lane l owns cnt[i] = count of bin l*4*NQ + i.
 // Every lane gets the bins holding ranks k1 <= k2.
 template <int NQ>
-__device__ __forceinline__ void rank2(const unsigned (&cnt)[4 * NQ], int lane, int k1, int k2, int &b1, int &b2)
+__device__ __forceinline__ void rank2(const unsigned (&cnt)[4 * NQ], int lane, int k1, int k2, int &b1, int &b2,
+                                      int *pre_out = nullptr)
 {
     const int b0 = lane * 4 * NQ;
     int local = 0;
@@ -86,6 +87,7 @@ __device__ __forceinline__ void rank2(const unsigned (&cnt)[4 * NQ], int lane, i
     for (int i = 0; i < 4 * NQ; i++) local += (int)cnt[i];
     const int inc = wave_incl_scan(local);
     const int pre = inc - local;
+    if (pre_out) *pre_out = pre;                            // samples in the bins below this lane's
     int i1 = b0, i2 = b0, acc = pre;
 #pragma unroll
     for (int i = 0; i < 4 * NQ; i++) {
@@ -205,27 +207,51 @@ void k_prepw_medmad(const int16_t *__restrict__ sig, int64_t stride, const int32
             if (hb0 + 4 * j < nb4) q = *(const uint4 *)(hist + hb0 + 4 * j);
             cnt[4 * j] = q.x; cnt[4 * j + 1] = q.y; cnt[4 * j + 2] = q.z; cnt[4 * j + 3] = q.w;
         }
-        int b1, b2;
-        rank2<NQ>(cnt, lane, (n - 1) / 2, n / 2, b1, b2);
+        int b1, b2, pre_med;
+        rank2<NQ>(cnt, lane, (n - 1) / 2, n / 2, b1, b2, &pre_med);
         const int med2 = (b1 + lo + 1) + (b2 + lo + 1);                    // 2 * median, exact
 
-        // ---- MAD = median of |x - med|: the histogram folded around the median ------------------------
-        // |2x - med2| takes the values 2t (med2 even) or 2t + 1 (odd); f(t) = count(left) + count(right)
+        // ---- MAD = median of |x - med| ---------------------------------------------------------------------------
+        // |2x - med2| takes the values 2t (med2 even) or 2t + 1 (odd), and the number of samples within deviation t is
+        //     C(t) = P[cr + t] - P[cl - t - 1]           P = inclusive prefix counts of the value histogram
+        // (cl / cr: the bins just below / above the median, equal when it is an integer).  The prefix counts replace
+        // the histogram in LDS (each lane has its bins' counts and the scan of the median select in registers); the
+        // smallest t with C(t) > k is then found for both middle ranks in two 64-way steps -- lane l probes the end
+        // of block l, then the lanes of each half probe one block's members -- instead of folding the histogram
+        // around the median bin by bin.
         const int odd = med2 & 1;
         const int cl = ((med2 - odd) >> 1) - (lo + 1);                     // bin just below / at the median
         const int cr = cl + odd;
-        unsigned f[4 * NQ];
+        {
+            int acc = pre_med;
 #pragma unroll
-        for (int i = 0; i < 4 * NQ; i++) {
-            const int t = hb0 + i;
-            const int bl = cl - t, br = cr + t;
-            unsigned c = 0u;
-            if (bl >= 0 && bl < nbins) c += hist[bl];
-            if (br >= 0 && br < nbins && (odd || t > 0)) c += hist[br];
-            f[i] = c;
+            for (int j = 0; j < NQ; j++) {
+                uint4 q;
+                acc += (int)cnt[4 * j];     q.x = (unsigned)acc;
+                acc += (int)cnt[4 * j + 1]; q.y = (unsigned)acc;
+                acc += (int)cnt[4 * j + 2]; q.z = (unsigned)acc;
+                acc += (int)cnt[4 * j + 3]; q.w = (unsigned)acc;
+                if (hb0 + 4 * j < nb4) *(uint4 *)(hist + hb0 + 4 * j) = q;
+            }
         }
-        int t1, t2;
-        rank2<NQ>(f, lane, (n - 1) / 2, n / 2, t1, t2);
+        auto within = [&](int t) -> int {                                  // C(t), t >= 0
+            const int hi_i = min(cr + t, nbins - 1), lo_i = cl - t - 1;
+            const int a = (int)hist[hi_i];
+            const int b = (lo_i >= 0) ? (int)hist[max(lo_i, 0)] : 0;
+            return a - b;
+        };
+        const int k1 = (n - 1) / 2, k2 = n / 2;
+        const int step = (nbins + 63) >> 6;                                // <= 32 (nbins <= 2048)
+        const int cend = within(lane * step + step - 1);                   // non-decreasing in the lane index
+        const unsigned long long ge1 = __ballot(cend > k1), ge2 = __ballot(cend > k2);
+        const int B1 = ge1 ? (int)__builtin_ctzll(ge1) : 63, B2 = ge2 ? (int)__builtin_ctzll(ge2) : 63;
+        const int half = lane >> 5, li = lane & 31;
+        const int tprobe = (half ? B2 : B1) * step + li;
+        const int cin = within(tprobe);
+        const unsigned long long hit = __ballot(li < step && cin > (half ? k2 : k1));
+        const unsigned h1 = (unsigned)hit, h2 = (unsigned)(hit >> 32);
+        const int t1 = B1 * step + (h1 ? (int)__builtin_ctz(h1) : step - 1);
+        const int t2 = B2 * step + (h2 ? (int)__builtin_ctz(h2) : step - 1);
         const double mad = (double)((2 * t1 + odd) + (2 * t2 + odd)) * 0.25;   // (d1/2 + d2/2) / 2, exact
         pr.center = (double)med2 * 0.5;
         pr.scale = mad * 1.4826;                                           // MotifSeq.py:196
