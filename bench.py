@@ -229,7 +229,11 @@ def parity_and_cpu(a, w, want_cpu):
         got_all = hits[rows]
         # the oracle goes through the sample in an order that is itself strided, so that whatever part of it the
         # CPU budget covers still spans the whole batch
-        order = np.concatenate([np.arange(k, len(rows), 16) for k in range(16)])
+        import math
+        step = max(1, int(len(rows) * 0.6180339887))                # golden-ratio stride, made coprime with the count:
+        while math.gcd(step, len(rows)) != 1:                        # every prefix of `order` is spread over the batch
+            step += 1
+        order = (np.arange(len(rows), dtype=np.int64) * step) % len(rows)
         n0 = min(len(rows), 128)
         t0 = time.perf_counter()
         want = [ora.motifseq_batch_i16(sample[order[:n0]], lens[order[:n0]], w.motif, scale_mode=w.mode)]
