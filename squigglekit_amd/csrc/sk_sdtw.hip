@@ -217,10 +217,15 @@ void k_sdtw(const sdtw_kargs a)
                 if constexpr (TRACK) {
                     const int lfS = S[k];
                     const bool lt1 = lfD < dgD;             // diag wins ties over left
-                    const double m1 = lt1 ? lfD : dgD;
+                    // int16 reads normalise to finite values (a degenerate read -- scale 0 -- is flagged and its
+                    // result unspecified), so there v_min_f64 is the select; written as a select on doubles the
+                    // compiler spends two v_cndmask each.  float64 input may carry NaN: keep the literal select.
+                    double m1;
+                    if constexpr (FEED == SK_FEED_I16) m1 = vmin(lfD, dgD); else m1 = lt1 ? lfD : dgD;
                     const int    s1 = lt1 ? lfS : dgS;
                     const bool lt2 = uD < m1;               // up only if strictly smaller
-                    const double m = lt2 ? uD : m1;
+                    double m;
+                    if constexpr (FEED == SK_FEED_I16) m = vmin(uD, m1); else m = lt2 ? uD : m1;
                     const int    s = lt2 ? uS : s1;
                     nd = c + m;
                     dgS = lfS;  S[k] = s;  uS = s;
