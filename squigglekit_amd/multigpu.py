@@ -52,6 +52,9 @@ def plan(gpus, environ=None):
     le = launch_env(environ)
     if le is not None:
         return ("process",) + le
+    e = os.environ if environ is None else environ
+    if e.get("SK_FORCE_PROCESS_SHAPE") == "1" and "RANK" in e:       # tests: the per-GPU-process shape with one rank
+        return ("process", int(e["RANK"]), int(e.get("LOCAL_RANK", "0")), max(1, int(e.get("WORLD_SIZE", "1"))))
     if gpus and int(gpus) > 1:
         return ("threads", 0, 0, int(gpus))
     return ("single", 0, 0, 1)

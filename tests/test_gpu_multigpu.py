@@ -76,3 +76,22 @@ def test_bench_gather_path_bare_python(gpu, scaling, backend):
     assert line["config"]["gather_backend"] == backend and line["config"]["ranks_seen"] == 1
     assert line["parity"]["dist_bit_identical"] and line["parity"]["start_end_exact"]
     assert "torch" not in p.stderr
+
+
+def test_bench_under_torch_distributed_run_one_rank(gpu):
+    """The driver's N > 1 launch line with one rank: `python -m torch.distributed.run ... bench.py`.  The launcher
+    only provides the environment; bench.py takes the process-per-GPU shape (forced here, WORLD_SIZE being 1), does
+    the ncclUniqueId rendezvous through the file store and gathers over RCCL -- without importing torch."""
+    pytest.importorskip("torch")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--reads", "20000",
+           "--steps", "2", "--warmup", "1", "--cpu-seconds", "2", "--no-extras", "--force-comm"]
+    env = dict(os.environ, SK_FORCE_PROCESS_SHAPE="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-1000:]
+    line = json.loads(lines[0])
+    assert line["config"]["launch"].startswith("one process per GPU")
+    assert line["config"]["gather_backend"] == "rccl" and line["config"]["ranks_seen"] == 1
+    assert line["parity"]["dist_bit_identical"]
