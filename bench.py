@@ -18,6 +18,12 @@ Two launch shapes give the same line (squigglekit_amd/multigpu.py):
 `--scaling weak` (default): --reads per GPU (C4 on every GPU); `--scaling strong`: --reads in total (C4 as
 BASELINE.json words it: 1 M reads sharded 1/2/4/8).  With N > 1 the weak run also reports a short strong run.
 
+Dry run of the N > 1 paths on a box with fewer GPUs than ranks: `--ranks-on-device D` (or SK_OVERSUBSCRIBE=1 under a
+per-GPU launcher) puts every rank on device D with its own context slot; the gather then runs on the host backend
+(RCCL wants one device per rank).  At N > 1 (and with --force-comm) rank 0 checks a strided sample of EVERY rank's
+shard, read out of the gathered buffer, against the oracle (`parity.ranks_checked`): the device generator is
+deterministic in (seed + rank, row), so rank 0 regenerates any rank's rows.
+
 Rank 0 prints ONE JSON line with the driver's contract plus `roofline` (HIP-event kernel time vs algorithmic
 bytes, and the VALU-issue view that actually binds this kernel -- DESIGN.md 4.3), `cpu_baseline` (the oracle
 timed on the host: the only place it is timed), `parity` (a sample strided over the whole batch, checked
@@ -59,6 +65,10 @@ def parse(argv=None):
                     help="threads of the all-cores CPU baseline (-1 = every host core, 0 = skip)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the N = 1 extras (secondary segmenter line, exact-only schemes, end-to-end ingest)")
+    ap.add_argument("--no-sensitivity", action="store_true",
+                    help="skip the N = 1 sensitivity block (real-signal windows, retry-fraction sweep)")
+    ap.add_argument("--ranks-on-device", type=int, default=None, metavar="D",
+                    help="dry run: all --gpus ranks share device D (own context slot each, host-backend gather)")
     ap.add_argument("--force-comm", action="store_true",
                     help="N = 1: still create the RCCL communicator and gather every step (exercises the N > 1 path)")
     return ap.parse_args(argv)
@@ -125,6 +135,7 @@ class Workload:
             self.sp = SegParams()
         self.d_all = alloc(max(1, self.pad) * self.rec_bytes * world) if comm is not None else None
         self.host_rec = None
+        self.host_all = None                                         # host backend: what the last gather returned
 
     def _alloc(self, nbytes):
         from squigglekit_amd._lib import check
@@ -159,7 +170,25 @@ class Workload:
                 self.host_rec = np.zeros(max(1, self.pad) * self.rec_bytes, dtype=np.uint8)
             if self.R:
                 check(L.sk_dev_download(ptr(self.host_rec), self.d_out, self.R * self.rec_bytes))
-            self.comm.allgather_host(self.host_rec)
+            self.host_all = self.comm.allgather_host(self.host_rec)
+
+    def gathered(self):
+        """The last step's gathered records as uint8 [world, pad * rec_bytes] (out of d_all, or the host concat)."""
+        from squigglekit_amd._lib import check, ptr
+        if self.comm is None:
+            return None
+        if self.comm.backend == "rccl":
+            out = np.empty((self.world, max(1, self.pad) * self.rec_bytes), dtype=np.uint8)
+            check(self.L.sk_dev_download(ptr(out), self.d_all, out.nbytes))
+            return out
+        return np.asarray(self.host_all).reshape(self.world, -1)
+
+    def regenerate(self, **opts):
+        """Refill d_sig from the device generator (opts: _lib.SynthOpts fields; none = the default batch)."""
+        from squigglekit_amd._lib import SynthOpts, check, ptr
+        o = SynthOpts(**opts)
+        check(self.L.sk_synth_variant_dev(self.d_sig, self.stride, self.R, self.M, self.seed, ptr(self.motif), self.N,
+                                          C.byref(o)))
 
     def kernel_ms(self):
         from squigglekit_amd._lib import check
@@ -314,12 +343,160 @@ def parity_and_cpu(a, w, want_cpu):
     return parity, cpu, float(w.M - 1)
 
 
+def regenerate_rows(w, seed, rows, run=8):
+    """Rows `rows` (sorted, made of runs of consecutive rows) of the batch the device generator makes under `seed`,
+    regenerated into a scratch buffer -- whatever rank holds that batch -- and downloaded."""
+    from squigglekit_amd._lib import SynthOpts, check, ptr
+    L = w.L
+    out = np.empty((len(rows), w.stride), dtype=np.int16)
+    d_tmp = L.sk_dev_alloc(4096 * w.stride * 2)
+    if not d_tmp:
+        check(-4)
+    try:
+        k = 0
+        while k < len(rows):
+            j = k
+            while j + 1 < len(rows) and rows[j + 1] == rows[j] + 1 and j + 1 - k < 4096:
+                j += 1
+            cnt = j + 1 - k
+            o = SynthOpts(row0=int(rows[k]))
+            check(L.sk_synth_variant_dev(d_tmp, w.stride, cnt, w.M, seed, ptr(w.motif), w.N, C.byref(o)))
+            view = out[k:j + 1]
+            check(L.sk_dev_download(ptr(view), d_tmp, view.nbytes))
+            k = j + 1
+    finally:
+        L.sk_dev_free(d_tmp)
+    return out
+
+
+def verify_gather(a, w, shard_sizes, per_rank=128):
+    """Rank 0, N > 1 (or --force-comm): a strided sample of EVERY rank's shard, taken out of the gathered buffer
+    (d_all after ncclAllGather, or the host concatenation), against the oracle on that rank's regenerated rows."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as ora
+    from squigglekit_amd._lib import HIT_DTYPE
+    blocks = w.gathered()
+    base_seed = w.seed - w.rank
+    T = max(1, min(16, os.cpu_count() or 1))
+    res = []
+    for r in range(w.world):
+        Rr = int(shard_sizes[r])
+        if Rr == 0:
+            res.append({"rank": r, "reads": 0, "ok": True})
+            continue
+        rows = strided_rows(Rr, min(Rr, per_rank))
+        sample = regenerate_rows(w, base_seed + r, rows)
+        lens = np.full(len(rows), w.M if w.kind == "motifseq" else w.M - 1, dtype=np.int32)
+        entry = {"rank": r, "reads": int(len(rows)), "rows": "%d..%d" % (int(rows[0]), int(rows[-1]))}
+        if r == w.rank:                                              # the generator slice IS what sits in HBM
+            resident = download_rows(w.L, w.d_sig, w.stride * 2, rows, np.int16, w.stride)
+            entry["regenerated_equals_resident"] = bool(np.array_equal(resident[:, :w.M], sample[:, :w.M]))
+        parts = [(i, min(len(rows), i + (len(rows) + T - 1) // T)) for i in range(0, len(rows), (len(rows) + T - 1) // T)]
+        if w.kind == "motifseq":
+            got = blocks[r][:Rr * HIT_BYTES].view(HIT_DTYPE)[rows]
+            with ThreadPoolExecutor(T) as ex:                        # the oracle's ctypes calls release the GIL
+                want = np.concatenate(list(ex.map(lambda ab: ora.motifseq_batch_i16(
+                    sample[ab[0]:ab[1]], lens[ab[0]:ab[1]], w.motif, scale_mode=w.mode), parts)))
+            entry["dist_bit_identical"] = bool(np.array_equal(got["dist"], want["dist"]))
+            entry["start_end_exact"] = bool(np.array_equal(got["start"], want["start"])
+                                            and np.array_equal(got["end"], want["end"]))
+            entry["ok"] = entry["dist_bit_identical"] and entry["start_end_exact"] and \
+                entry.get("regenerated_equals_resident", True)
+        else:
+            got = blocks[r][:Rr * 4].view(np.int32)[rows]
+            _, onsegs = ora.segment_batch_i16(sample, lens, max_segs=MAX_SEGS)
+            entry["segment_counts_exact"] = bool(np.array_equal(got, onsegs))
+            entry["ok"] = entry["segment_counts_exact"] and entry.get("regenerated_equals_resident", True)
+        res.append(entry)
+    return {"ranks_checked": len(res), "every_rank_ok": bool(all(e["ok"] for e in res)),
+            "source": "gathered buffer: %s" % ("d_all after ncclAllGather" if w.comm.backend == "rccl"
+                                               else "host concatenation of the ranks' records"),
+            "per_rank": res}
+
+
+def e2e_all_ranks(a, w, comm):
+    """N > 1, every rank: host arrays in -> sk_motifseq_batch_i16 (sub-batched H2D under the kernels) -> host
+    records out, one feeder thread / process per GPU with pinned memory, all ranks at once between barriers.
+    Returns (reads, seconds of the slowest rank) on every rank."""
+    from squigglekit_amd import api
+    from squigglekit_amd._lib import HIT_DTYPE, check, ptr
+    L = w.L
+    Rh = min(w.R, 200_000)
+    hits = np.zeros(max(1, Rh), dtype=HIT_DTYPE)
+    host = api.pinned_empty((max(1, Rh), w.stride), np.int16)
+    lens = w.lens[:Rh]
+    if Rh:
+        check(L.sk_dev_download(ptr(host), w.d_sig, Rh * w.stride * 2))
+    best = None
+    for it in range(3):
+        comm.barrier()
+        t0 = time.perf_counter()
+        if Rh:
+            check(L.sk_motifseq_batch_i16(ptr(host), w.stride, ptr(lens), Rh, ptr(w.motif), w.N, w.mode, 0, 1200,
+                                          ptr(hits)))
+        dt = time.perf_counter() - t0
+        dt = float(comm.allgather_host(np.array([dt], dtype=np.float64)).max())
+        if it and (best is None or dt < best):
+            best = dt
+    del host
+    return Rh, best
+
+
+def sensitivity_block(a, L, main):
+    """N = 1, after everything else: what the headline is worth on less friendly data.  (i) reads that are windows of
+    the one measured squiggle the reference ships (example/slow5/0.blow5, 36 978 samples; copy under tests/golden)
+    plus N(0, 3) noise, against the example model (163 points) and the synthetic 200-point motif; (ii) the C4 batch
+    with a fraction of the reads carrying a 4x time-stretched motif, whose path is too wide for the window pass, so
+    they take the exact retry.  Three steps each, best taken."""
+    from squigglekit_amd import blow5
+    from squigglekit_amd._lib import check, ptr
+    out = {"reads": main.R, "note": "HBM-resident, kernels only (as the headline); ms = best of 3 steps"}
+
+    def run(motif):
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            check(L.sk_motifseq_dev_i16(main.d_sig, main.stride, main.d_len, main.R, ptr(motif), motif.size,
+                                        main.mode, 0, 1200, main.d_out))
+            check(L.sk_sync())
+            ts.append(time.perf_counter() - t0)
+        return {"reads_per_s": main.R / min(ts), "ms": min(ts) * 1e3, "retried_reads": int(L.sk_last_dtw_retries()),
+                "second_tier_reads": int(L.sk_last_dtw_tier2())}
+
+    try:
+        read = next(blow5.read_blow5(os.path.join(ROOT, "tests", "golden", "example_0.blow5")))
+        raw = np.asarray(read["signal"], dtype=np.int16)
+        import gzip
+        with gzip.open(os.path.join(ROOT, "tests", "golden", "motifseq_cli.json.gz"), "rt") as fh:
+            model163 = np.array(json.load(fh)["model_expanded"]["values"], dtype=np.float64)
+        main.regenerate(tmpl=raw, tmpl_noise=3.0)
+        out["real_signal_windows"] = {
+            "source": "tests/golden/example_0.blow5 (%d samples): random %d-sample windows + N(0,3) noise" % (raw.size, main.M),
+            "vs_example_model_163pt": run(model163),
+            "vs_synthetic_%dpt_motif" % main.N: run(main.motif)}
+    except Exception as e:                                            # noqa: BLE001 -- report, keep the line
+        out["real_signal_windows"] = {"error": repr(e)}
+    sweep = {}
+    for pm in (0, 10, 100, 500):
+        main.regenerate(stretch_permille=pm, stretch=4)
+        sweep["%g%%" % (pm / 10.0)] = run(main.motif)
+    out["retry_fraction_sweep"] = {"what": "C4 batch, this share of the reads also carries the motif stretched 4x in "
+                                           "time (800 samples): uncertifiable by the window pass -> exact retry",
+                                   "by_share": sweep}
+    main.regenerate()                                                 # the default batch again
+    return out
+
+
 def traffic_from_profiles(workload, pattern):
     """HBM bytes per read of one kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, collected
     separately with rocprofv3 --pmc: a bench run cannot read hardware counters itself)."""
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
     try:
         tj = json.load(open(tpath))
+        if pattern is None:                                          # every kernel of the step together
+            tot = sum(kk["fetch_bytes_total"] + kk["write_bytes_total"] for kk in tj["kernels"].values())
+            per_read = tot / (tj["reads_per_call"] * max(1, tj.get("calls", 1)))
+            return per_read, "profiles/traffic_%s.json: all kernels, %.0f B/read measured" % (workload, per_read)
         key = [k for k in tj["kernels"] if pattern in k]
         if key and tj.get("reads_per_call"):
             kk = tj["kernels"][key[0]]
@@ -370,9 +547,12 @@ def motifseq_roofline(a, w, prof, steps, mean_n):
                     "in 32-bit fixed point (2 integer ops), only the certified window in f64")
     per_read, src = traffic_from_profiles("motifseq", "k_sdtw_q")
     traffic = per_read * (alg_bytes / (2 * M + HIT_BYTES)) if per_read else None
+    step_read, step_src = traffic_from_profiles("motifseq", None)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+            "traffic_ratio": (traffic / alg_bytes) if traffic else None,
+            "traffic_ratio_whole_step": (step_read / (2 * M + HIT_BYTES)) if step_read else None,
             "kernel_ms": {"prep": prep_ms, "main": main_ms, "dominant_avg_launch": dom_ms},
             "algorithmic_bytes_per_launch": alg_bytes,
             "dominant_kernel_dtype": "u32 fixed-point screening, f64 certified window",
@@ -406,13 +586,14 @@ def segmenter_roofline(w, prof, steps):
     R, M = w.R, w.M
     prep_ms, main_ms = prof["prep_ms"] / steps, prof["main_ms"] / steps
     alg_bytes = R * (2 * M + 4 + 8 * 2)
-    dominant, dom_ms = ("k_seg_stats (filter + statistics + in-band mask)", prep_ms) if prep_ms >= main_ms \
-        else ("k_segment_walk", main_ms)
-    per_read, src = traffic_from_profiles("segmenter", "k_seg_stats" if prep_ms >= main_ms else "k_seg_walk2")
+    dominant, dom_ms = ("k_seg_stats (filter + statistics + in-band / kept masks)", prep_ms) if prep_ms >= main_ms \
+        else ("k_seg_walk3 (run-hopping get_segs walk)", main_ms)
+    per_read, src = traffic_from_profiles("segmenter", "k_seg_stats" if prep_ms >= main_ms else "k_seg_walk")
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
     both = alg_bytes / ((prep_ms + main_ms) * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": per_read * R if per_read else None, "traffic_source": src,
+            "traffic_ratio": (per_read * R / alg_bytes) if per_read else None,
             "kernel_ms": {"prep": prep_ms, "main": main_ms, "dominant_avg_launch": dom_ms},
             "algorithmic_bytes_per_launch": alg_bytes,
             "both_kernels": {"achieved": both, "frac": both / HBM_PEAK_GBS}}
@@ -433,8 +614,8 @@ def extras_single_gpu(a, L, main):
             par, cpu, _ = parity_and_cpu(sa, w, True)
             out["secondary"] = {"metric": "reads/sec segmenter (4k-sample read)", "value": w.R * 5 / el,
                                 "unit": "reads/s", "ms_per_step": el / 5 * 1e3, "steps": 5, "warmup": 1,
-                                "config": {"workload": "segmenter C2-1M: %d reads x %d int16 samples, default flags"
-                                                       % (w.R, w.M), "seed": w.seed},
+                                "config": {"workload": workload_name("segmenter", w.R, w.M, None, "weak"),
+                                           "seed": w.seed},
                                 "roofline": segmenter_roofline(w, *seg_kernel_prof(w, prof, 5)), "cpu_baseline": cpu,
                                 "parity": par}
         finally:
@@ -498,6 +679,18 @@ def extras_single_gpu(a, L, main):
 # ----------------------------------------------------------------------------------------------------
 # one rank
 # ----------------------------------------------------------------------------------------------------
+def workload_name(kind, reads, samples, motif, scaling, scale="medmad"):
+    """BASELINE.json's config label when the sizes are one of its configs, "custom" otherwise."""
+    per = "per GPU" if scaling == "weak" else "in total"
+    if kind == "motifseq":
+        tag = {(1_000_000, 4000, 200): "C4", (10_000, 4000, 163): "C3", (100_000, 20_000, 500): "C5"}.get(
+            (reads, samples, motif), "custom")
+        return "MotifSeq %s: %d reads x %d int16 samples %s, %d-pt motif, %s" % (tag, reads, samples, per, motif, scale)
+    tag = {(10_000, 4000): "C2", (1_000_000, 4000): "C2-1M"}.get((reads, samples), "custom")
+    return "segmenter %s: %d reads x %d int16 samples %s, default flags" % (tag, reads, samples, per)
+
+
+
 def rank_body(a, comm, rank, world, shape):
     """Runs on the rank's own thread / process with its device bound.  Returns the JSON line on rank 0."""
     from squigglekit_amd import _lib, sharding
@@ -508,6 +701,7 @@ def rank_body(a, comm, rank, world, shape):
     else:
         R = pad = a.reads
     use_comm = comm if (world > 1 or a.force_comm) else None
+    shard_sizes = sharding.shard_sizes(a.reads, world) if a.scaling == "strong" else [a.reads] * world
     w = Workload(a, L, rank, world, R, comm=use_comm, gather_pad=pad)
     elapsed, prof = timed(w, use_comm, a.steps, a.warmup)
     ranks_seen = use_comm.ranks_seen() if use_comm is not None else 1
@@ -523,6 +717,9 @@ def rank_body(a, comm, rank, world, shape):
         strong = {"scaling": "strong", "total_reads": a.reads, "value": a.reads * a.steps / el_s, "unit": "reads/s",
                   "ms_per_step": el_s / a.steps * 1e3, "steps": a.steps}
         w.step()                                                # every rank: d_out holds its full shard again
+    e2e_multi = None
+    if world > 1 and a.workload == "motifseq" and not a.no_extras:
+        e2e_multi = e2e_all_ranks(a, w, use_comm)               # (every rank takes part)
     if rank != 0:
         w.free()
         return None
@@ -532,17 +729,22 @@ def rank_body(a, comm, rank, world, shape):
     value = total_reads * a.steps / elapsed
     want_cpu = world == 1 and a.cpu_seconds > 0          # the CPU baseline is timed at N = 1 only
     parity, cpu, mean_n = parity_and_cpu(a, w, want_cpu)
+    if use_comm is not None:
+        # what did the gather gather?  a sample of every rank's shard out of the gathered buffer, against the oracle
+        gv = verify_gather(a, w, shard_sizes)
+        parity.update(gv)
+        for key in ("dist_bit_identical", "start_end_exact", "segments_bit_exact"):
+            if key in parity:
+                parity[key] = bool(parity[key] and gv["every_rank_ok"])
     if a.workload == "motifseq":
         roofline = motifseq_roofline(a, w, prof, a.steps, mean_n)
         name = "reads/sec MotifSeq DTW (4k-sample read x 200-sample motif)"
-        wl = "MotifSeq C4: %d reads x %d int16 samples %s, %d-pt motif, %s" % (
-            a.reads, a.samples, "per GPU" if a.scaling == "weak" else "in total", a.motif, a.scale)
+        wl = workload_name("motifseq", a.reads, a.samples, a.motif, a.scaling, a.scale)
     else:
         roofline = segmenter_roofline(w, *seg_kernel_prof(w, prof, a.steps)) if use_comm is None else \
             segmenter_roofline(w, prof, a.steps)
         name = "reads/sec segmenter (4k-sample read)"
-        wl = "segmenter C2-1M: %d reads x %d int16 samples %s, default flags" % (
-            a.reads, a.samples, "per GPU" if a.scaling == "weak" else "in total")
+        wl = workload_name("segmenter", a.reads, a.samples, None, a.scaling)
     line = {"metric": name, "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "f64" if a.workload == "motifseq" else "int16/f64",
@@ -558,12 +760,22 @@ def rank_body(a, comm, rank, world, shape):
                        "launch": {"single": "one process, one GPU", "threads": "one process, one host thread per GPU",
                                   "process": "one process per GPU (launcher environment), torch-free"}[shape],
                        "gather_backend": use_comm.backend if use_comm is not None else None,
-                       "ranks_seen": ranks_seen},
+                       "ranks_seen": ranks_seen,
+                       "oversubscribed": ("every rank on device %d (dry run of the N > 1 path)" % a.ranks_on_device)
+                       if a.ranks_on_device is not None else None},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity}
     if strong:
         line["strong_scaling"] = strong
+    if e2e_multi is not None:
+        Rh, dt = e2e_multi
+        line["end_to_end"] = {"reads_per_gpu": Rh, "motifseq_pinned_reads_per_s": world * Rh / dt if dt else None,
+                              "note": "every rank at once: pinned host arrays -> sk_motifseq_batch_i16 (H2D of one "
+                                      "sub-batch under the kernels of the previous one) -> host records; one feeder "
+                                      "thread / process per GPU, slowest rank's wall clock, best of 2 after a warm-up"}
     if world == 1 and not a.no_extras:
         line.update(extras_single_gpu(a, L, w))
+        if a.workload == "motifseq" and not a.no_sensitivity:
+            line["sensitivity"] = sensitivity_block(a, L, w)
     w.free()
     return line
 
@@ -573,13 +785,18 @@ def main(argv=None):
     os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # RCCL logs to stdout by default: the JSON line stands alone
     from squigglekit_amd import _lib, multigpu
     _lib.load()
+    if a.ranks_on_device is not None:
+        os.environ["SK_OVERSUBSCRIBE"] = "d%d" % a.ranks_on_device
+    elif multigpu.oversubscribed() is not None:
+        a.ranks_on_device = multigpu.oversubscribed()
     shape, rank, local, world = multigpu.plan(a.gpus)
     a.gpus = world
     if shape == "process":
         with multigpu.ProcessGroup(rank, local, world) as comm:
             line = rank_body(a, comm, rank, world, shape)
     elif shape == "threads" or a.force_comm:
-        g = multigpu.ThreadGroup(list(range(world)))
+        devs = list(range(world)) if a.ranks_on_device is None or world == 1 else [a.ranks_on_device] * world
+        g = multigpu.ThreadGroup(devs, oversubscribe=a.ranks_on_device is not None)
         try:
             line = g.run(lambda comm: rank_body(a, comm, comm.rank, world, shape))[0]
         finally:

@@ -83,6 +83,10 @@ const char *sk_version(void);
 const char *sk_last_error(void);
 int  sk_device_count(void);                 /* >= 0, or negative sk_status                */
 int  sk_init(int device);                   /* bind the calling thread to `device`        */
+/* The same with an explicit context slot (0..15; sk_init uses slot == device).  Every slot has its own stream and
+ * scratch, so several host threads (or ranks) can share one GPU: how the sharded multi-GPU paths are exercised on
+ * a one-GPU box.  The RCCL entry points still need one device per rank. */
+int  sk_init_slot(int slot, int device);
 int  sk_shutdown(void);                     /* free every per-device context              */
 int  sk_sync(void);                         /* wait for the bound device's stream         */
 int  sk_device_name(char *buf, int cap);    /* marketing/gcn name of the bound device     */
@@ -252,6 +256,9 @@ int sk_last_kernel_ms(float *prep_ms, float *main_ms);
 /* Reads of the most recent DTW call whose optimal path was longer than the two-pass
  * look-back window and were therefore recomputed by the exact single pass (diagnostic). */
 int sk_last_dtw_retries(void);
+/* Reads of the most recent DTW call whose path crossed the window pass's first (short) look-back and were redone
+ * by its second tier (diagnostic; 0 when the call did not use the screening scheme). */
+int sk_last_dtw_tier2(void);
 /* Per-launch view of the most recent two-pass DTW call: summed HIP-event time and launch count
  * of the distance pass (k_sdtw<..,DIST>) and of the start pass (k_sdtw<..,START>), and the reads
  * covered by the largest launch.  *dist_launches == 0 means the call used the single pass. */
@@ -261,6 +268,20 @@ int sk_last_dtw_profile(float *dist_ms, int *dist_launches, float *start_ms, int
  * function): fills d_sig[nreads][nsamples] int16 deterministically from seed. */
 int sk_synth_squiggles_dev(int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
                            uint64_t seed, const double *motif, int32_t nmotif);
+/* Variants of the generator for bench.py's sensitivity runs and its multi-rank parity check (not reference
+ * functions either).  Row r of a call is row row0 + r of the seed's batch, so any slice of any rank's batch can be
+ * regenerated anywhere.  Defaults {0, 500, 0, 1, NULL, 0, 0} reproduce sk_synth_squiggles_dev. */
+typedef struct sk_synth_opts {
+    int64_t        row0;             /* first row of the seed's batch this call generates                      */
+    int32_t        hit_permille;     /* reads carrying an exact copy of the motif (default 500)                */
+    int32_t        stretch_permille; /* reads carrying the motif with every point repeated `stretch` times     */
+    int32_t        stretch;          /* (their optimal path is that much wider: they take the exact retry)     */
+    const int16_t *tmpl;             /* HOST pointer or NULL.  Non-NULL: every read is a window of this        */
+    int32_t        ntmpl;            /* measured squiggle (ntmpl samples) at a random offset, plus rounded     */
+    double         tmpl_noise;       /* N(0, tmpl_noise) noise; no plateaus / implants / spikes               */
+} sk_synth_opts;
+int sk_synth_variant_dev(int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples, uint64_t seed,
+                         const double *motif, int32_t nmotif, const sk_synth_opts *o);
 
 #ifdef __cplusplus
 }

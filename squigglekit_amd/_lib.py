@@ -67,6 +67,18 @@ class RollParams(C.Structure):
         super().__init__(w, seg_dist, hi_thresh, lo_thresh, shift, std_scale, lim_low, lim_hi)
 
 
+class SynthOpts(C.Structure):
+    """sk_synth_opts (bench tooling): slice / variant of the device generator's batch."""
+    _fields_ = [("row0", C.c_int64), ("hit_permille", C.c_int32), ("stretch_permille", C.c_int32),
+                ("stretch", C.c_int32), ("tmpl", C.c_void_p), ("ntmpl", C.c_int32), ("tmpl_noise", C.c_double)]
+
+    def __init__(self, row0=0, hit_permille=500, stretch_permille=0, stretch=1, tmpl=None, tmpl_noise=0.0):
+        self._keep = None if tmpl is None else np.ascontiguousarray(tmpl, dtype=np.int16)
+        super().__init__(row0, hit_permille, stretch_permille, stretch,
+                         None if tmpl is None else self._keep.ctypes.data, 0 if tmpl is None else self._keep.size,
+                         tmpl_noise)
+
+
 class Hit(C.Structure):
     _fields_ = [("dist", C.c_double), ("start", C.c_int32), ("end", C.c_int32),
                 ("n", C.c_int32), ("flags", C.c_int32)]
@@ -83,6 +95,7 @@ ABI = {
     "sk_last_error": (C.c_char_p, []),
     "sk_device_count": (C.c_int, []),
     "sk_init": (C.c_int, [C.c_int]),
+    "sk_init_slot": (C.c_int, [C.c_int, C.c_int]),
     "sk_shutdown": (C.c_int, []),
     "sk_sync": (C.c_int, []),
     "sk_device_name": (C.c_int, [C.c_char_p, C.c_int]),
@@ -126,8 +139,10 @@ ABI = {
     "sk_comm_destroy": (C.c_int, []),
     "sk_last_kernel_ms": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sk_last_dtw_retries": (C.c_int, []),
+    "sk_last_dtw_tier2": (C.c_int, []),
     "sk_last_dtw_profile": (C.c_int, [C.POINTER(C.c_float), _i32p, C.POINTER(C.c_float), _i32p, _i32p]),
     "sk_synth_squiggles_dev": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, _vp, C.c_int32]),
+    "sk_synth_variant_dev": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, _vp, C.c_int32, _vp]),
 }
 
 
@@ -168,12 +183,16 @@ def check(rc):
 _tls = threading.local()      # the library binds a device per host thread (thread_local in sk_runtime.hip)
 
 
-def init(device=None):
-    """Bind the calling thread to a GPU (default: $SK_DEVICE, else LOCAL_RANK, else 0)."""
+def init(device=None, slot=None):
+    """Bind the calling thread to a GPU (default: $SK_DEVICE, else LOCAL_RANK, else 0).  `slot`: an explicit
+    context slot (sk_init_slot) -- several threads sharing one GPU each need their own."""
     L = load()
     if device is None:
         device = int(os.environ.get("SK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-    check(L.sk_init(int(device)))
+    if slot is None:
+        check(L.sk_init(int(device)))
+    else:
+        check(L.sk_init_slot(int(slot), int(device)))
     _tls.device = int(device)
     return _tls.device
 

@@ -705,4 +705,39 @@ int sk_synth_squiggles_dev(int16_t *d_sig, int64_t stride, int32_t nreads, int32
     return SK_OK;
 }
 
+int sk_synth_variant_dev(int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples, uint64_t seed,
+                         const double *motif, int32_t nmotif, const sk_synth_opts *o)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (!d_sig || !o || stride < nsamples || nreads < 0 || nsamples < 0 || o->row0 < 0)
+        return sk_fail(SK_ERR_INVALID, "bad arguments");
+    int rc;
+    if (o->tmpl && o->ntmpl > 0) {                       // windows of a measured squiggle + noise
+        if ((rc = sk_reserve(c, &c->misc, (size_t)o->ntmpl * 2))) return rc;
+        SK_HIP(hipMemcpyAsync(c->misc.p, o->tmpl, (size_t)o->ntmpl * 2, hipMemcpyHostToDevice, c->stream));
+        SK_HIP(hipStreamSynchronize(c->stream));
+        rc = sk_launch_synth_windows(c, d_sig, stride, nreads, nsamples, seed, o->row0, (const int16_t *)c->misc.p,
+                                     o->ntmpl, (float)o->tmpl_noise);
+    } else {
+        const int16_t *d_m = nullptr;
+        if (motif && nmotif > 0) {
+            std::vector<int16_t> mi((size_t)nmotif);
+            for (int i = 0; i < nmotif; i++) {
+                double v = rint(motif[i] * 93.4 + 511.0);
+                mi[i] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+            }
+            if ((rc = sk_reserve(c, &c->misc, mi.size() * 2))) return rc;
+            SK_HIP(hipMemcpyAsync(c->misc.p, mi.data(), mi.size() * 2, hipMemcpyHostToDevice, c->stream));
+            SK_HIP(hipStreamSynchronize(c->stream));
+            d_m = (const int16_t *)c->misc.p;
+        }
+        rc = sk_launch_synth(c, d_sig, stride, nreads, nsamples, seed, d_m, nmotif, o->row0, o->hit_permille,
+                             o->stretch_permille, o->stretch);
+    }
+    if (rc) return rc;
+    SK_HIP(hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
+
 } // extern "C"

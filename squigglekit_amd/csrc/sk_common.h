@@ -165,4 +165,7 @@ int sk_launch_segment_walk(sk_ctx *c, const uint64_t *d_mask, int64_t mask_strid
 
 // ---- synth (sk_synth.hip) ----
 int sk_launch_synth(sk_ctx *c, int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
-                    uint64_t seed, const int16_t *d_motif_i16, int32_t nmotif);
+                    uint64_t seed, const int16_t *d_motif_i16, int32_t nmotif, int64_t row0 = 0,
+                    int hit_pm = 500, int stretch_pm = 0, int stretch = 1);
+int sk_launch_synth_windows(sk_ctx *c, int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
+                            uint64_t seed, int64_t row0, const int16_t *d_tmpl, int32_t ntmpl, float sigma);

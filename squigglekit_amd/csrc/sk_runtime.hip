@@ -1,7 +1,8 @@
 // sk_runtime.hip -- device contexts, error reporting, device memory.
-// One context per device, created by sk_init(); each host thread is bound to
-// one device (thread_local), so a multi-GPU host drives one thread per GPU or,
-// as bench.py does, one process per GPU.
+// One context per SLOT, created by sk_init() (slot == device) or sk_init_slot(); each host
+// thread is bound to one slot (thread_local), so a multi-GPU host drives one thread per GPU
+// or, as bench.py also does, one process per GPU.  Several slots may serve the same device
+// (sk_init_slot): that is how the N > 1 code paths are exercised on a one-GPU box.
 #include "sk_common.h"
 #include <mutex>
 #include <stdio.h>
@@ -28,8 +29,8 @@ sk_ctx *sk_cur(void)
         sk_fail(SK_ERR_NO_DEVICE, "no device bound: call sk_init(device) first (no CPU fallback exists)");
         return nullptr;
     }
-    if (hipSetDevice(g_cur) != hipSuccess) {
-        sk_fail(SK_ERR_NO_DEVICE, "hipSetDevice(%d) failed", g_cur);
+    if (hipSetDevice(g_ctx[g_cur].device) != hipSuccess) {
+        sk_fail(SK_ERR_NO_DEVICE, "hipSetDevice(%d) failed", g_ctx[g_cur].device);
         return nullptr;
     }
     return &g_ctx[g_cur];
@@ -90,14 +91,20 @@ int sk_device_count(void)
     return n;
 }
 
-int sk_init(int device)
+int sk_init(int device) { return sk_init_slot(device, device); }
+
+int sk_init_slot(int slot, int device)
 {
     int n = sk_device_count();
     if (n <= 0) return sk_fail(SK_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
     if (device < 0 || device >= n || device >= SK_MAX_DEVICES)
         return sk_fail(SK_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    if (slot < 0 || slot >= SK_MAX_DEVICES)
+        return sk_fail(SK_ERR_INVALID, "context slot %d out of range (0..%d)", slot, SK_MAX_DEVICES - 1);
     std::lock_guard<std::mutex> lk(g_mu);
-    sk_ctx *c = &g_ctx[device];
+    sk_ctx *c = &g_ctx[slot];
+    if (c->ready && c->device != device)
+        return sk_fail(SK_ERR_INVALID, "context slot %d already serves device %d", slot, c->device);
     SK_HIP(hipSetDevice(device));
     if (!c->ready) {
         hipDeviceProp_t prop;
@@ -111,7 +118,7 @@ int sk_init(int device)
         for (int i = 0; i < 4; i++) SK_HIP(hipEventCreate(&c->ev[i]));
         c->ready = true;
     }
-    g_cur = device;
+    g_cur = slot;
     return SK_OK;
 }
 
@@ -123,7 +130,7 @@ int sk_shutdown(void)
     for (int d = 0; d < SK_MAX_DEVICES; d++) {
         sk_ctx *c = &g_ctx[d];
         if (!c->ready) continue;
-        (void)hipSetDevice(d);
+        (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         sk_buf *bufs[] = {&c->sig, &c->len, &c->off, &c->comp, &c->prep, &c->mask,
                           &c->motif, &c->out, &c->out2, &c->misc, &c->ckpt, &c->retry, &c->motifq, &c->lastq, &c->qflag,
@@ -253,6 +260,18 @@ int sk_last_dtw_retries(void)
         c->last_retry = n;
     }
     return c->last_retry;
+}
+
+int sk_last_dtw_tier2(void)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (!(c->retry_dev && c->dtwcnt.p)) return 0;
+    int32_t n = 0;
+    if (hipMemcpyAsync(&n, (const int32_t *)c->dtwcnt.p + 1, sizeof n, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return sk_fail(SK_ERR_HIP, "reading the second-tier count failed");
+    return n;
 }
 
 } // extern "C"

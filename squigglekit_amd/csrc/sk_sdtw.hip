@@ -519,7 +519,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     if ((rc = sk_reserve(c, &c->dtwcnt, 64))) return rc;
     int32_t *cnt = (int32_t *)c->retry.p;                  // [0] = counter, [2..] = read indices
     SK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), c->stream));
-    if (!a->accumulate) SK_HIP(hipMemsetAsync(c->dtwcnt.p, 0, sizeof(int32_t), c->stream));
+    if (!a->accumulate) SK_HIP(hipMemsetAsync(c->dtwcnt.p, 0, 2 * sizeof(int32_t), c->stream));   // [0] retried, [1] second tier
     c->retry_dev = true;
     auto launch_retry = [&]() -> int {
         sdtw_kargs kr = k;

@@ -235,6 +235,7 @@ void k_sdtw_w(const sdtw_kargs a)
     int nreads = a.nreads;
     if (a.wl_count) {                               // second tier: the list length is only known on the device
         nreads = min(*a.wl_count, a.nreads);
+        if (a.total_ptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.total_ptr, nreads);   // (diagnostic)
         if (nreads <= 0) return;                    // (block-uniform)
     }
     const bool live = slot < nreads;
@@ -579,9 +580,11 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P,
             hipLaunchKernelGGL(fw, dim3(grid), dim3(256), 0, c->stream, k);
             SK_HIP(hipGetLastError());
             k.span = span2; k.wl_list = soft + 1; k.wl_count = soft; k.soft = nullptr; k.soft_cnt = nullptr;
+            k.total_ptr = (int32_t *)c->dtwcnt.p + 1;       // reads that needed the second tier (sk_last_dtw_tier2)
         }
         hipLaunchKernelGGL(fw, dim3(grid), dim3(256), 0, c->stream, k);
         SK_HIP(hipGetLastError());
+        k.total_ptr = nullptr;
         SK_HIP(hipEventRecord(ev[2], c->stream));
         c->prof_reads[c->prof_chunks < 64 ? c->prof_chunks : 63] = k.nreads;
         c->prof_chunks++;

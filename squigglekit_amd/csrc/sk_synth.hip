@@ -40,21 +40,55 @@ struct Rng {
     }
 };
 
+// Real-signal mode (bench sensitivity runs): read r = a window of M samples of one measured squiggle (tmpl, T
+// samples) at a random offset, plus rounded N(0, sigma) noise -- no plateaus, implants or spikes.
 __global__ __launch_bounds__(64)
-void k_synth(int16_t *__restrict__ sig, int64_t stride, int nreads, int M, uint64_t seed,
-             const int16_t *__restrict__ motif, int N)
+void k_synth_windows(int16_t *__restrict__ sig, int64_t stride, int nreads, int M, uint64_t seed, int64_t row0,
+                     const int16_t *__restrict__ tmpl, int T, float sigma)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nreads) return;
     Rng g;
-    g.key = mix64(seed ^ mix64((uint64_t)r + 0x1234567ull));
+    g.key = mix64(seed ^ mix64((uint64_t)(row0 + r) + 0x7654321ull));
+    g.ctr = 0;
+    const int off = (T > M) ? g.below(T - M + 1) : 0;
+    int16_t *row = sig + (int64_t)r * stride;
+    for (int i = 0; i < M; i++) {
+        const int t = tmpl[(off + i) % T];
+        int q = t + (int)rintf(sigma * g.gauss());
+        row[i] = (int16_t)min(32767, max(-32768, q));
+    }
+}
+
+// hit_pm / stretch_pm: per-mille of reads that carry the motif as it is / repeated `stretch` times per point
+// (a time-stretched copy: its optimal path is `stretch` times wider than the motif, so the windowed DTW pass
+// cannot certify the read and it takes the exact retry).  row0: index of the first generated row in the stream
+// (row r of this launch is row row0 + r of the seed's batch, whatever the launch covers).
+__global__ __launch_bounds__(64)
+void k_synth(int16_t *__restrict__ sig, int64_t stride, int nreads, int M, uint64_t seed,
+             const int16_t *__restrict__ motif, int N, int64_t row0, int hit_pm, int stretch_pm, int stretch)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nreads) return;
+    Rng g;
+    g.key = mix64(seed ^ mix64((uint64_t)(row0 + r) + 0x1234567ull));
     g.ctr = 0;
     const int scale = max(1, M / 4000);
     const int s0 = g.below(60), l0 = 100 + g.below(500);
     const bool has2 = g.uni() < 0.5f;
     const int s1 = 1200 * scale + g.below(2200 * scale), l1 = 160 + g.below(340);
-    const bool hit = (motif != nullptr) && (N > 0) && (N < M) && (g.uni() < 0.5f);
+    const bool hit = (motif != nullptr) && (N > 0) && (N < M) && (g.uni() < 0.001f * (float)hit_pm);
     const int moff = (N < M) ? g.below(M - N) : 0;
+    // (drawn from a second stream, so that the default batch -- stretch_pm == 0 -- is unchanged by the option)
+    bool wide = false;
+    int woff = 0;
+    if (stretch_pm > 0 && motif != nullptr && N * stretch < M) {
+        Rng g2;
+        g2.key = mix64(g.key ^ 0x5bd1e995ull);
+        g2.ctr = 0;
+        wide = g2.uni() < 0.001f * (float)stretch_pm;
+        woff = g2.below(M - N * stretch);
+    }
     int spos[4], sval[4];
     const int spikes[4] = {-5, 0, 950, 1100};
     for (int k = 0; k < 4; k++) { spos[k] = g.below(M); sval[k] = spikes[g.below(4)]; }
@@ -76,6 +110,7 @@ void k_synth(int16_t *__restrict__ sig, int64_t stride, int nreads, int M, uint6
             int q = (int)rintf(x);
             q = min(32767, max(-32768, q));
             if (hit && i >= moff && i < moff + N) q = motif[i - moff];
+            if (wide && i >= woff && i < woff + N * stretch) q = motif[(i - woff) / stretch];
 #pragma unroll
             for (int s = 0; s < 4; s++) if (i == spos[s]) q = sval[s];
             v[k] = q;
@@ -96,12 +131,24 @@ void k_synth(int16_t *__restrict__ sig, int64_t stride, int nreads, int M, uint6
 } // namespace
 
 int sk_launch_synth(sk_ctx *c, int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
-                    uint64_t seed, const int16_t *d_motif_i16, int32_t nmotif)
+                    uint64_t seed, const int16_t *d_motif_i16, int32_t nmotif, int64_t row0,
+                    int hit_pm, int stretch_pm, int stretch)
 {
     if (nreads <= 0 || nsamples <= 0) return SK_OK;
     const int grid = (nreads + 63) / 64;
     hipLaunchKernelGGL(k_synth, dim3(grid), dim3(64), 0, c->stream, d_sig, stride, nreads, nsamples, seed,
-                       d_motif_i16, nmotif);
+                       d_motif_i16, nmotif, row0, hit_pm, stretch_pm, stretch < 1 ? 1 : stretch);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
+}
+
+int sk_launch_synth_windows(sk_ctx *c, int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
+                            uint64_t seed, int64_t row0, const int16_t *d_tmpl, int32_t ntmpl, float sigma)
+{
+    if (nreads <= 0 || nsamples <= 0) return SK_OK;
+    const int grid = (nreads + 63) / 64;
+    hipLaunchKernelGGL(k_synth_windows, dim3(grid), dim3(64), 0, c->stream, d_sig, stride, nreads, nsamples, seed,
+                       row0, d_tmpl, ntmpl, sigma);
     SK_HIP(hipGetLastError());
     return SK_OK;
 }

@@ -77,7 +77,8 @@ def norm_cdf(z):
         return ndtr(z)
     except ImportError:                              # pragma: no cover
         import math
-        return np.float64(0.5 * math.erfc(-z / math.sqrt(2.0)))
+        # (arrays too: the chunk-wide scoring of _Batcher.block hands one in)
+        return 0.5 * np.vectorize(math.erfc, otypes=[np.float64])(-np.asarray(z, dtype=np.float64) / math.sqrt(2.0))
 
 
 def load_models(args):
@@ -214,6 +215,20 @@ class _Batcher:
                                      str(mm), str(ms), repr(z[k]), repr(pv[k]), repr(hp[k]))))
                 continue
             fl = int(blk.flags[i])
+            if a.after_stall:
+                # nothing of this chunk was printed directly, so the batcher alone keeps the file order: reads queue
+                # up to --batch per GPU call (segment + search) instead of one call per read
+                if (fl & 27) == 1:
+                    self.note("No Signal found - please check signal format\n")
+                elif (fl & 27) == 3:
+                    self.add(blk.name(i), blk.read_id(i), blk.rows[i, :blk.nsamp[i]].astype(np.float64))
+                else:
+                    fast5, read_id, sig = tsvio.parse_motifseq_line(blk.line(i).decode())
+                    if sig.any():
+                        self.add(fast5, read_id, sig)
+                    else:
+                        self.note("No Signal found - please check signal format\n")
+                continue
             if (fl & 27) == 1:                                              # integers, all zero: MotifSeq.py:271-273
                 sys.stderr.write("No Signal found - please check signal format\n")
                 continue

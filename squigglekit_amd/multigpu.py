@@ -41,8 +41,11 @@ def launch_env(environ=None):
         return None
     if world <= 1 or "RANK" not in e:
         return None
-    rank = int(e["RANK"])
-    return rank, int(e.get("LOCAL_RANK", rank)), world
+    try:
+        rank = int(e["RANK"])
+        return rank, int(e.get("LOCAL_RANK", rank)), world
+    except ValueError:
+        return None
 
 
 def plan(gpus, environ=None):
@@ -54,7 +57,10 @@ def plan(gpus, environ=None):
         return ("process",) + le
     e = os.environ if environ is None else environ
     if e.get("SK_FORCE_PROCESS_SHAPE") == "1" and "RANK" in e:       # tests: the per-GPU-process shape with one rank
-        return ("process", int(e["RANK"]), int(e.get("LOCAL_RANK", "0")), max(1, int(e.get("WORLD_SIZE", "1"))))
+        try:
+            return ("process", int(e["RANK"]), int(e.get("LOCAL_RANK", "0")), max(1, int(e.get("WORLD_SIZE", "1"))))
+        except ValueError:
+            pass
     if gpus and int(gpus) > 1:
         return ("threads", 0, 0, int(gpus))
     return ("single", 0, 0, 1)
@@ -63,6 +69,20 @@ def plan(gpus, environ=None):
 # ------------------------------------------------------------------------------------------------
 # a tiny file store: rendezvous for the process-per-GPU shape, and the host fallback exchange
 # ------------------------------------------------------------------------------------------------
+def oversubscribed(environ=None):
+    """The device every rank shares when SK_OVERSUBSCRIBE is set (SK_OVERSUBSCRIBE=1: device 0; =dN: device N),
+    else None.  Oversubscription is the dry run of the N > 1 paths on a box with fewer GPUs than ranks: every rank
+    gets its own context slot (stream, scratch) on the shared device; the gather runs on the host backend because
+    RCCL wants one device per rank."""
+    e = os.environ if environ is None else environ
+    v = e.get("SK_OVERSUBSCRIBE", "")
+    if not v or v == "0":
+        return None
+    if v[:1] == "d" and v[1:].isdigit():
+        return int(v[1:])
+    return 0
+
+
 def store_dir(environ=None):
     """One directory per job on this node: keyed on what every rank of a launch shares whatever started it --
     the rendezvous address and port (unique among the jobs running on a node) and the launcher's run id.  A stale
@@ -85,7 +105,16 @@ class FileStore:
 
     def __init__(self, path, rank, world, timeout=300.0):
         self.path, self.rank, self.world, self.timeout = path, rank, world, timeout
-        os.makedirs(path, exist_ok=True)
+        # the directory sits in a shared $TMPDIR under a predictable name: it must be ours, private and not a link
+        try:
+            os.makedirs(path, mode=0o700, exist_ok=True)
+            st = os.lstat(path)
+        except OSError as e:
+            raise RuntimeError("rendezvous directory %s cannot be used: %s" % (path, e))
+        import stat as _stat
+        if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            raise RuntimeError("rendezvous directory %s is not a private directory of uid %d (set SK_RDZV_DIR)"
+                               % (path, os.getuid()))
         self._seq = 0
         self.session = None
 
@@ -179,6 +208,11 @@ class RankComm:
             return n.value
         return len(self._hx(b"x"))
 
+    def all_ok(self, ok):
+        """True when every rank reports ok.  Always a host-side exchange (thread barrier / file store), so it can be
+        called right before a device collective: a rank that failed must not leave the others inside ncclAllGather."""
+        return all(p == b"\x01" for p in self._hx(b"\x01" if ok else b"\x00"))
+
     def allgather_host(self, arr):
         a = np.ascontiguousarray(arr)
         if self.backend == "rccl":
@@ -212,16 +246,23 @@ class ThreadGroup:
     """One process driving `devices`, one host thread each.  run(fn) calls fn(comm) on every rank's thread
     (bound to its device) and returns the results in rank order."""
 
-    def __init__(self, devices, rccl=True, bind=True):
+    def __init__(self, devices, rccl=True, bind=True, oversubscribe=False):
         self.bind = bind                                             # False: host logic only (CPU tests)
         rccl = rccl and bind
         self.devices = [int(d) for d in devices]
-        if len(set(self.devices)) != len(self.devices) or not self.devices:
-            raise ValueError("devices must be distinct and non-empty")
+        if not self.devices:
+            raise ValueError("devices must be non-empty")
+        self.shared = len(set(self.devices)) != len(self.devices)
+        if self.shared and not oversubscribe:
+            raise ValueError("devices must be distinct (oversubscribe=True lets ranks share one: dry runs)")
         n = len(self.devices)
+        if self.shared and n > 16:
+            raise ValueError("at most 16 ranks can share devices (one context slot each)")
         self.world = n
         self.backend, self.why_host = "host", None
-        if not rccl:
+        if self.shared:
+            self.why_host = "ranks share a device (oversubscribed dry run): RCCL needs one device per rank"
+        elif not rccl:
             self.why_host = "not requested"
         elif _want_rccl():
             L = _lib.load()
@@ -254,7 +295,9 @@ class ThreadGroup:
         def body(rank):
             try:
                 if self.bind:
-                    _lib.init(self.devices[rank])
+                    # ranks sharing a device each take their own context slot, counted down from the top so that
+                    # they never collide with a plain sk_init(device) (slot == device)
+                    _lib.init(self.devices[rank], slot=(15 - rank) if self.shared else None)
                 res[rank] = fn(RankComm(rank, n, self.backend, self._exchange(rank)))
             except BaseException as e:                               # noqa: BLE001 -- re-raised below
                 err[rank] = e
@@ -265,6 +308,8 @@ class ThreadGroup:
             t.start()
         for t in ts:
             t.join()
+        if any(e is not None for e in err):
+            self._bar.reset()                                        # an aborted barrier stays broken otherwise
         first = [e for e in err if e is not None and not isinstance(e, threading.BrokenBarrierError)]
         if first:
             raise first[0]
@@ -286,10 +331,14 @@ class ProcessGroup:
         self.rank, self.local_rank, self.world = rank, local_rank, world
         self.store = FileStore(store_dir(environ), rank, world)
         self.backend, self.why_host = "host", None
+        shared = oversubscribed(environ) if world > 1 else None      # every rank on one device (dry run)
         if bind:
-            _lib.init(local_rank)
+            _lib.init(local_rank if shared is None else shared)
+        want = _want_rccl() and shared is None
+        if shared is not None:
+            self.why_host = "ranks share device %d (oversubscribed dry run): RCCL needs one device per rank" % shared
         payload = b"\0"                                             # [0]: 1 = an ncclUniqueId follows
-        if _want_rccl() and bind and rank == 0:
+        if want and bind and rank == 0:
             L = _lib.load()
             uid = C.create_string_buffer(UID_BYTES)
             rc = L.sk_comm_unique_id(uid)
@@ -300,7 +349,9 @@ class ProcessGroup:
             else:
                 check(rc)
         blob = self.store.rendezvous(payload)
-        if not _want_rccl():
+        if shared is not None:
+            pass
+        elif not _want_rccl():
             self.why_host = "SK_COMM=host"
         elif bind and blob[:1] == b"\1":
             L = _lib.load()
@@ -336,15 +387,27 @@ _groups_mu = threading.Lock()
 
 def group_for(devices, rccl=False):
     """The (cached) ThreadGroup of a device list; created with RCCL communicators when `rccl` is asked for
-    (an RCCL group also serves the host-gather calls)."""
+    (an RCCL group also serves the host-gather calls).  A list naming a device twice is only accepted under
+    SK_OVERSUBSCRIBE (dry runs of the sharded path on a box with fewer GPUs than ranks)."""
     key = tuple(int(d) for d in devices)
     with _groups_mu:
         g = _groups.get(key)
         if g is not None and rccl and g.backend != "rccl" and g.why_host == "not requested":
             g = None                                                 # upgrade: build the communicators now
         if g is None:
-            g = _groups[key] = ThreadGroup(key, rccl=rccl)
+            g = _groups[key] = ThreadGroup(key, rccl=rccl, oversubscribe=oversubscribed() is not None)
         return g
+
+
+def drop_group(g):
+    """Forget a group whose run failed: its communicators are destroyed and the next call builds a fresh one."""
+    with _groups_mu:
+        for k in [k for k, v in _groups.items() if v is g]:
+            del _groups[k]
+    try:
+        g.close()
+    except Exception:                                               # noqa: BLE001 -- already failing
+        pass
 
 
 def close_groups():
@@ -363,7 +426,11 @@ def run_sharded(devices, total, fn, rccl=False):
         lo, hi = sharding.shard_bounds(total, comm.rank, comm.world)
         return fn(lo, hi, comm)
 
-    g.run(body)
+    try:
+        g.run(body)
+    except BaseException:
+        drop_group(g)
+        raise
     return g
 
 
@@ -389,13 +456,24 @@ def motifseq_sharded(sig, lens, motif, scale_mode, scale_low, scale_hi, devices,
         d_out = L.sk_dev_alloc(max(1, pad) * hb)
         d_all = L.sk_dev_alloc(max(1, pad) * hb * comm.world) if use_rccl else None
         try:
-            if not d_sig or not d_len or not d_out or (use_rccl and not d_all):
-                check(-4)
-            if n:
-                check(L.sk_dev_upload(d_sig, ptr(sig[lo:hi]), n * stride * 2))
-                check(L.sk_dev_upload(d_len, ptr(lens[lo:hi]), n * 4))
-                check(L.sk_motifseq_dev_i16(d_sig, stride, d_len, n, ptr(motif), motif.size, scale_mode,
-                                            int(scale_low), int(scale_hi), d_out))
+            failed = None
+            try:
+                if not d_sig or not d_len or not d_out or (use_rccl and not d_all):
+                    check(-4)
+                if n:
+                    check(L.sk_dev_upload(d_sig, ptr(sig[lo:hi]), n * stride * 2))
+                    check(L.sk_dev_upload(d_len, ptr(lens[lo:hi]), n * 4))
+                    check(L.sk_motifseq_dev_i16(d_sig, stride, d_len, n, ptr(motif), motif.size, scale_mode,
+                                                int(scale_low), int(scale_hi), d_out))
+                    check(L.sk_sync())                               # a kernel error surfaces here, not in the gather
+            except Exception as e:                                   # noqa: BLE001 -- re-raised after the vote
+                failed = e
+            if use_rccl and not comm.all_ok(failed is None):
+                # some rank failed before the collective: nobody enters ncclAllGather (it would never return)
+                raise failed if failed is not None else _lib.SquiggleKitError(
+                    -3, "another rank failed before the gather; rank %d skipped the collective" % comm.rank)
+            if failed is not None:
+                raise failed
             if use_rccl:
                 comm.allgather_dev(d_out, d_all, pad * hb)
                 check(L.sk_sync())

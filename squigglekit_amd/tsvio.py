@@ -90,14 +90,25 @@ def iter_tsv_native(path, start_col, chunk_bytes=64 << 20, nthreads=None):
 def _line_blocks(path, chunk_bytes):
     """Whole-line chunks of a text file as (buffer, start, end): for plain files a read-only memory map and byte
     ranges into it (nothing is copied on the Python side), for .gz files decompressed bytes."""
+    mm = None
     if not path.endswith(".gz"):
         import mmap
         import os
-        size = os.path.getsize(path)
-        if size == 0:
-            return
-        with open(path, "rb") as fh:
-            mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+        import stat
+        # a memory map only for regular files: a pipe, /dev/stdin or a process substitution (`-s <(zcat x.gz)`)
+        # reports size 0 and cannot be mapped -- those are streamed like the .gz branch below, as the reference's
+        # line iteration would read them
+        try:
+            st = os.stat(path)
+            if stat.S_ISREG(st.st_mode):
+                if st.st_size == 0:
+                    return
+                with open(path, "rb") as fh:
+                    mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+        except (OSError, ValueError):
+            mm = None
+    if mm is not None:
+        size = len(mm)
         pos = 0
         while pos < size:
             end = min(size, pos + chunk_bytes)
@@ -110,7 +121,7 @@ def _line_blocks(path, chunk_bytes):
             yield mm, pos, end
             pos = end
         return
-    with gzip.open(path, "rb") as fh:
+    with (gzip.open(path, "rb") if path.endswith(".gz") else open(path, "rb")) as fh:
         tail = b""
         while True:
             block = fh.read(chunk_bytes)

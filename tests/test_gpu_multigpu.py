@@ -75,7 +75,82 @@ def test_bench_gather_path_bare_python(gpu, scaling, backend):
     assert line["n_gpus"] == 1 and line["scaling"] == scaling
     assert line["config"]["gather_backend"] == backend and line["config"]["ranks_seen"] == 1
     assert line["parity"]["dist_bit_identical"] and line["parity"]["start_end_exact"]
+    assert line["parity"]["ranks_checked"] == 1 and line["parity"]["every_rank_ok"]       # read out of the gather
     assert "torch" not in p.stderr
+
+
+def _check_multi_rank_line(line, world):
+    assert line["n_gpus"] == world and line["config"]["ranks_seen"] == world
+    assert line["config"]["gather_backend"] == "host" and line["config"]["oversubscribed"]
+    par = line["parity"]
+    assert par["ranks_checked"] == world and par["every_rank_ok"], par
+    assert par["dist_bit_identical"] and par["start_end_exact"]
+    assert [e["rank"] for e in par["per_rank"]] == list(range(world))
+    assert all(e["reads"] >= 64 and e["dist_bit_identical"] and e["start_end_exact"] for e in par["per_rank"])
+    assert par["per_rank"][0]["regenerated_equals_resident"]
+    assert "gathered buffer" in par["source"]
+
+
+@pytest.mark.parametrize("world,scaling,reads", [(2, "weak", 20000), (3, "strong", 30001)])
+def test_bench_world_gt1_oversubscribed_threads(gpu, world, scaling, reads):
+    """bench.py's world > 1 code on the one-GPU box: `--gpus N --ranks-on-device 0` (one host thread per rank, every
+    rank its own context slot on device 0, host-backend gather).  rank_body's shard split, the padded gather, the
+    weak run's strong re-slice, the every-rank end-to-end leg -- and rank 0 checks a sample of EVERY rank's shard
+    out of the gathered buffer against the oracle."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--ranks-on-device", "0", "--reads",
+           str(reads), "--steps", "2", "--warmup", "1", "--cpu-seconds", "2", "--scaling", scaling]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    _check_multi_rank_line(line, world)
+    assert line["scaling"] == scaling and line["config"]["launch"].startswith("one process, one host thread")
+    if scaling == "weak":
+        assert line["config"]["total_reads"] == reads * world and line["strong_scaling"]["total_reads"] == reads
+    else:
+        assert line["config"]["total_reads"] == reads
+        assert sum(e["reads"] for e in line["parity"]["per_rank"]) >= 3 * 64
+    assert line["end_to_end"]["motifseq_pinned_reads_per_s"] > 0
+    assert "sensitivity" not in line and "secondary" not in line          # N = 1 extras stay out
+
+
+def test_bench_world2_oversubscribed_process_per_rank(gpu):
+    """The driver's N > 1 launch line, two ranks on the one GPU (SK_OVERSUBSCRIBE=1): process-per-GPU shape, file-store
+    rendezvous, host-backend gather, every rank's sample checked by rank 0."""
+    pytest.importorskip("torch")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "20000",
+           "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"]
+    env = dict(os.environ, SK_OVERSUBSCRIBE="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-1000:]
+    line = json.loads(lines[0])
+    _check_multi_rank_line(line, 2)
+    assert line["config"]["launch"].startswith("one process per GPU")
+    assert line["strong_scaling"]["total_reads"] == 20000
+
+
+def test_product_api_two_ranks_on_one_device(gpu, ora, monkeypatch):
+    """api.motifseq_batch(devices=[0, 0]) under SK_OVERSUBSCRIBE: the sharded product path with two feeder threads."""
+    from squigglekit_amd import api, multigpu, synth
+    monkeypatch.setenv("SK_OVERSUBSCRIBE", "1")
+    multigpu.close_groups()
+    motif = synth.synthetic_motif(150, seed=4)
+    sig = synth.squiggle_batch(501, 3000, 97531, motif=motif)
+    lens = np.full(501, 3000, dtype=np.int32)
+    lens[::5] = 2222
+    plain = api.motifseq_batch(sig, lens, motif)
+    got = api.motifseq_batch(sig, lens, motif, devices=[0, 0])
+    assert got.tobytes() == plain.tobytes()
+    got3, info = multigpu.motifseq_sharded(sig, lens, motif, 0, 0, 1200, [0, 0, 0], gather="rccl")
+    assert info["shards"] == [167, 167, 167] and info["backend"] == "host" and info["gather"].startswith("host")
+    assert got3.tobytes() == plain.tobytes()
+    segs, nsegs = api.segment_batch(sig, lens - 1, devices=[0, 0])
+    segs1, nsegs1 = api.segment_batch(sig, lens - 1)
+    assert np.array_equal(segs, segs1) and np.array_equal(nsegs, nsegs1)
+    multigpu.close_groups()
+    gpu.init(0)                                                       # back to the plain binding for later tests
 
 
 def test_bench_under_torch_distributed_run_one_rank(gpu):

@@ -55,8 +55,46 @@ def test_thread_group_host_exchange_and_errors():
     g2 = multigpu.ThreadGroup([0, 1], rccl=False, bind=False)
     with pytest.raises(ValueError, match="rank 1 failed"):
         g2.run(boom)
+    assert g2.run(lambda comm: comm.allgather_host(np.array([comm.rank])).ravel().tolist()) == [[0, 1], [0, 1]], \
+        "a failed run must leave the group usable (the aborted barrier is reset)"
     with pytest.raises(ValueError):
         multigpu.ThreadGroup([0, 0], rccl=False, bind=False)
+
+
+def test_oversubscribed_group_and_vote():
+    """Ranks sharing one device (the dry run of the N > 1 path on a one-GPU box): own context slot each, host backend;
+    all_ok() is the vote taken before a device collective so that a failed rank strands nobody inside it."""
+    from squigglekit_amd import multigpu
+    assert multigpu.oversubscribed({}) is None and multigpu.oversubscribed({"SK_OVERSUBSCRIBE": "0"}) is None
+    assert multigpu.oversubscribed({"SK_OVERSUBSCRIBE": "1"}) == 0
+    assert multigpu.oversubscribed({"SK_OVERSUBSCRIBE": "d5"}) == 5
+    g = multigpu.ThreadGroup([0, 0, 0], bind=False, oversubscribe=True)
+    assert g.shared and g.backend == "host" and "share" in g.why_host
+
+    def body(comm):
+        a = comm.all_ok(True)
+        b = comm.all_ok(comm.rank != 2)
+        return a, b, comm.ranks_seen()
+    assert g.run(body) == [(True, False, 3)] * 3
+    assert multigpu.launch_env({"WORLD_SIZE": "2", "RANK": "zero"}) is None
+    assert multigpu.plan(2, {"SK_FORCE_PROCESS_SHAPE": "1", "RANK": "x"}) == ("threads", 0, 0, 2)
+
+
+def test_file_store_refuses_a_directory_others_can_write(tmp_path):
+    from squigglekit_amd import multigpu
+    bad = tmp_path / "open"
+    bad.mkdir()
+    os.chmod(bad, 0o777)
+    with pytest.raises(RuntimeError, match="private"):
+        multigpu.FileStore(str(bad), 0, 1)
+    target = tmp_path / "real"
+    target.mkdir()
+    link = tmp_path / "link"
+    os.symlink(target, link)
+    with pytest.raises(RuntimeError, match="private"):
+        multigpu.FileStore(str(link), 0, 1)
+    ok = multigpu.FileStore(str(tmp_path / "fresh"), 0, 1)
+    assert (os.stat(ok.path).st_mode & 0o077) == 0
 
 
 def test_sharded_host_gather_equals_unsharded(ora):
