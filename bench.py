@@ -446,8 +446,9 @@ def sensitivity_block(a, L, main):
     """N = 1, after everything else: what the headline is worth on less friendly data.  (i) reads that are windows of
     the one measured squiggle the reference ships (example/slow5/0.blow5, 36 978 samples; copy under tests/golden)
     plus N(0, 3) noise, against the example model (163 points) and the synthetic 200-point motif; (ii) the C4 batch
-    with a fraction of the reads carrying a 4x time-stretched motif, whose path is too wide for the window pass, so
-    they take the exact retry.  Three steps each, best taken."""
+    with a given share of the reads forced through the exact retry (what a retry rate of x % costs); (iii) the C4
+    batch with half of the reads also carrying the motif stretched 2 / 3 / 4 times in time (wide optimal paths: second
+    tier of the window pass, then the retry).  Three steps each, best taken."""
     from squigglekit_amd import blow5
     from squigglekit_amd._lib import check, ptr
     out = {"reads": main.R, "note": "HBM-resident, kernels only (as the headline); ms = best of 3 steps"}
@@ -476,13 +477,29 @@ def sensitivity_block(a, L, main):
             "vs_synthetic_%dpt_motif" % main.N: run(main.motif)}
     except Exception as e:                                            # noqa: BLE001 -- report, keep the line
         out["real_signal_windows"] = {"error": repr(e)}
+    # (ii) what a retry costs: a given share of the reads is sent to the exact single pass whatever the window pass
+    # found (SK_DTW_FORCE_RETRY_PM, a switch of the window kernel for exactly this measurement) -- on the C4 batch
+    main.regenerate()
     sweep = {}
     for pm in (0, 10, 100, 500):
-        main.regenerate(stretch_permille=pm, stretch=4)
-        sweep["%g%%" % (pm / 10.0)] = run(main.motif)
-    out["retry_fraction_sweep"] = {"what": "C4 batch, this share of the reads also carries the motif stretched 4x in "
-                                           "time (800 samples): uncertifiable by the window pass -> exact retry",
-                                   "by_share": sweep}
+        os.environ["SK_DTW_FORCE_RETRY_PM"] = str(pm)
+        try:
+            sweep["%g%%" % (pm / 10.0)] = run(main.motif)
+        finally:
+            del os.environ["SK_DTW_FORCE_RETRY_PM"]
+    base = sweep["0%"]["reads_per_s"]
+    for v in sweep.values():
+        v["vs_no_retries"] = v["reads_per_s"] / base
+    out["forced_retry_sweep"] = {"what": "C4 batch; this share of the reads (by hash of the read index) takes the exact "
+                                         "single-pass retry regardless of what the window pass certified",
+                                 "by_share": sweep}
+    # (iii) data that produces wide paths by itself: half of the reads also carry the motif stretched k times in
+    # time (k x N samples); a match wider than the first look-back goes to the second tier, wider than that to the retry
+    wide = {}
+    for k in (2, 3, 4):
+        main.regenerate(stretch_permille=500, stretch=k)
+        wide["x%d" % k] = run(main.motif)
+    out["stretched_motif_in_half_of_the_reads"] = wide
     main.regenerate()                                                 # the default batch again
     return out
 

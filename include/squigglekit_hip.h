@@ -259,6 +259,10 @@ int sk_last_dtw_retries(void);
 /* Reads of the most recent DTW call whose path crossed the window pass's first (short) look-back and were redone
  * by its second tier (diagnostic; 0 when the call did not use the screening scheme). */
 int sk_last_dtw_tier2(void);
+/* Shader clock (GHz) the screening pass of the most recent DTW call ran at: its first wavefront counts shader cycles
+ * (s_memtime) against the constant 100 MHz reference (s_memrealtime) over its whole sweep.  0 when the call did not
+ * use the screening scheme.  bench.py prices the VALU-issue roofline at this clock instead of a nominal one. */
+int sk_last_dtw_clock(double *ghz);
 /* Per-launch view of the most recent two-pass DTW call: summed HIP-event time and launch count
  * of the distance pass (k_sdtw<..,DIST>) and of the start pass (k_sdtw<..,START>), and the reads
  * covered by the largest launch.  *dist_launches == 0 means the call used the single pass. */

@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libsquigglekit_hip.so")
+SO_PATH = os.environ.get("SK_LIB_PATH") or os.path.join(_HERE, "libsquigglekit_hip.so")   # (override: A/B builds)
 CSRC = os.path.join(_HERE, "csrc")
 
 
@@ -140,6 +140,7 @@ ABI = {
     "sk_last_kernel_ms": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sk_last_dtw_retries": (C.c_int, []),
     "sk_last_dtw_tier2": (C.c_int, []),
+    "sk_last_dtw_clock": (C.c_int, [_dp]),
     "sk_last_dtw_profile": (C.c_int, [C.POINTER(C.c_float), _i32p, C.POINTER(C.c_float), _i32p, _i32p]),
     "sk_synth_squiggles_dev": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, _vp, C.c_int32]),
     "sk_synth_variant_dev": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, _vp, C.c_int32, _vp]),

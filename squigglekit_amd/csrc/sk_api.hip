@@ -142,17 +142,25 @@ int motifseq_dev(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t 
     if ((rc = sk_reserve(c, &c->comp, (size_t)nreads * (size_t)stride * sizeof(int16_t)))) return rc;
     if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
 
+    // medmad with the usual limits: filter + statistics ride in the screening pass as its prologue (sk_sdtwq.hip);
+    // sk_launch_sdtw runs them as a kernel of their own when it does not take the screening scheme
+    sk_prep_fuse fz;
+    fz.raw = d_sig; fz.len = d_len; fz.lo = scale_low; fz.hi = scale_hi;
+    const bool fuse = scale_mode == SK_SCALE_MEDMAD && sk_sdtw_fuse_ok(scale_low, scale_hi);
     SK_HIP(hipEventRecord(c->ev[0], c->stream));
-    rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nreads, scale_low, scale_hi,
-                            scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE, 0.0,
-                            (int16_t *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
-    if (rc) return rc;
+    if (!fuse) {
+        rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nreads, scale_low, scale_hi,
+                                scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE, 0.0,
+                                (int16_t *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
+        if (rc) return rc;
+    }
     SK_HIP(hipEventRecord(c->ev[1], c->stream));
 
     sk_sdtw_args a;
     a.feed = SK_FEED_I16; a.samples = c->comp.p; a.stride = stride; a.off = nullptr;
     a.prep = (const sk_prep *)c->prep.p; a.nreads = nreads; a.motif = motif; a.nmotif = nmotif;
     a.out = d_out; a.last_row = nullptr; a.max_len = stride; a.force_single = 0; a.accumulate = accumulate;
+    a.fuse = fuse ? &fz : nullptr;
     rc = sk_launch_sdtw(c, &a);
     if (rc) return rc;
     c->ev_valid = true;

@@ -58,6 +58,12 @@ struct sk_ctx {
     sk_buf lastq;     // screening pass: last-row costs per column
     sk_buf qflag;     // screening pass: per-read "left the fixed-point range" flags
     sk_buf wsoft;     // window pass: reads of the chunk that go to its second tier ([0] = count)
+    sk_buf lsum;      // screening pass: last-row minima per checkpoint interval and lane
+    sk_buf wstate;    // window pass: restart state per read (pass P -> pass W)
+    sk_buf wrec;      // window pass: restart point per read {tbase, jlo, jhi, flags}
+    sk_buf motifw;    // the motif (doubles) in the screening scheme's own per-lane layout
+    std::vector<double> motifw_host;
+    int    motifq_L = 0;   // lanes per read of the layouts in motifq / motifw
     sk_buf retry;     // DTW retry list: [0] = count, [1] = pad, [2 ..] = reads (segmenter: [0] = count, [1 ..] = reads)
     sk_buf dtwcnt;    // [0] = reads retried by the exact pass, summed over the launches of one API call (device)
     bool   retry_dev = false;   // the last DTW call left its retry count on the device (read lazily)
@@ -117,6 +123,16 @@ int sk_launch_prep_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int
 enum sk_feed { SK_FEED_I16 = 0,      // int16 filtered samples + (center, scale) from sk_prep
                SK_FEED_F64_NORM = 1, // float64 filtered samples + (center, scale) from sk_prep
                SK_FEED_F64_RAW = 2 };// float64 already normalised (mlpy boundary), ragged
+// int16 MotifSeq calls with medmad: filter + statistics can run as the prologue of the screening pass
+// (sk_sdtwq.hip) instead of as a kernel of their own; sk_launch_sdtw falls back to the kernel when its
+// screening scheme does not apply to the call.
+struct sk_prep_fuse {
+    const int16_t *raw = nullptr;   // device, rows of `stride` samples (sk_sdtw_args::stride)
+    const int32_t *len = nullptr;   // device
+    int32_t lo = 0, hi = 0;         // scale_outliers limits
+};
+bool sk_sdtw_fuse_ok(int32_t lo, int32_t hi);   // limits inside the fused prologue's histogram range?
+
 struct sk_sdtw_args {
     int           feed;
     const void   *samples;     // int16* or double*
@@ -131,10 +147,12 @@ struct sk_sdtw_args {
     int64_t       max_len;     // upper bound of any read's filtered length (chooses 1 vs 2 passes)
     int           force_single;// 1: always the single FULL pass
     int           accumulate = 0;  // 1: a further launch set of the same API call (keep the retry total)
+    const sk_prep_fuse *fuse = nullptr;   // non-null: samples / prep are NOT filled yet (see sk_prep_fuse); they are
+                                          // the writable c->comp / c->prep buffers
 };
 int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a);
 // fixed-point screening + certified window over all reads (sk_sdtwq.hip); leaves the retry list on the device
-int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P, int ck, int span, int span2,
+int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, int span2,
                           int32_t *d_retry_cnt, int32_t *d_retry);
 
 // ---- dRNA --signal branch (rolling mean): statistics + masks (sk_prep.hip), scan (sk_segment.hip) ----

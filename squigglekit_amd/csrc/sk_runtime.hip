@@ -134,7 +134,7 @@ int sk_shutdown(void)
         (void)hipStreamSynchronize(c->stream);
         sk_buf *bufs[] = {&c->sig, &c->len, &c->off, &c->comp, &c->prep, &c->mask,
                           &c->motif, &c->out, &c->out2, &c->misc, &c->ckpt, &c->retry, &c->motifq, &c->lastq, &c->qflag,
-                          &c->motif64, &c->commbuf, &c->dtwcnt, &c->wsoft};
+                          &c->motif64, &c->commbuf, &c->dtwcnt, &c->wsoft, &c->wstate, &c->wrec, &c->motifw, &c->lsum};
         for (sk_buf *b : bufs) free_buf(b);
         for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev[i]);
         for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
@@ -260,6 +260,21 @@ int sk_last_dtw_retries(void)
         c->last_retry = n;
     }
     return c->last_retry;
+}
+
+int sk_last_dtw_clock(double *ghz)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (!ghz) return sk_fail(SK_ERR_INVALID, "NULL pointer");
+    *ghz = 0.0;
+    if (!(c->retry_dev && c->dtwcnt.p)) return SK_OK;
+    unsigned long long t[2] = {0, 0};
+    if (hipMemcpyAsync(t, (const char *)c->dtwcnt.p + 16, sizeof t, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return sk_fail(SK_ERR_HIP, "reading the clock sample failed");
+    if (t[1]) *ghz = (double)t[0] / ((double)t[1] / 100e6) / 1e9;
+    return SK_OK;
 }
 
 int sk_last_dtw_tier2(void)

@@ -418,11 +418,47 @@ static int launch_chained(sk_ctx *c, const sk_sdtw_args *a)
 }
 
 // Host side: lay the motif out per lane, pick (L, R), choose one or two passes, launch.
-int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
+// (the fused prologue is instantiated for histograms of 1 025 .. 1 280 bins: the default limits 0 / 1 200)
+bool sk_sdtw_fuse_ok(int32_t lo, int32_t hi)
 {
+    const int64_t nbins = (int64_t)hi - lo - 1;
+    return nbins > 1024 && nbins <= 1280 && !getenv("SK_PREP_BLOCK") && !getenv("SK_DTW_NOFUSE");
+}
+
+// will this call take the screening scheme (sk_sdtwq.hip)?  (the look-back / checkpoint numbers as in sk_launch_sdtw)
+static bool screens(const sk_sdtw_args *a, int span, int ck)
+{
+    const int N = a->nmotif;
+    if (N > 64 * 16 || a->last_row || a->force_single || a->nreads < 256) return false;
+    if (a->max_len < 4 * (int64_t)(span + ck)) return false;
+    if (const char *e = getenv("SK_DTW_SCHEME")) if (strcmp(e, "full") == 0 || strcmp(e, "exact2") == 0) return false;
+    for (int i = 0; i < N; i++) if (!(fabs(a->motif[i]) < QLIM)) return false;
+    return true;
+}
+
+int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
+{
+    const sk_sdtw_args *a = a_in;
+    sk_sdtw_args a_unfused;
     const int N = a->nmotif;
     if (N <= 0) return sk_fail(SK_ERR_INVALID, "empty motif");
     if (a->nreads <= 0) return SK_OK;
+    if (a->fuse) {
+        int ck0 = 128, span0 = N + N / 8 + 8;
+        if (const char *e = getenv("SK_DTW_CK")) { int v = atoi(e); if (v >= 64 && v % 64 == 0) ck0 = v; }
+        if (const char *e = getenv("SK_DTW_SPAN")) { int v = atoi(e); if (v > 0) span0 = v; }
+        if (!screens(a, span0, ck0) || !sk_sdtw_fuse_ok(a->fuse->lo, a->fuse->hi)) {
+            // no screening pass to carry the prologue: filter + statistics as their own kernel, now
+            SK_HIP(hipEventRecord(c->ev[0], c->stream));
+            int rc0 = sk_launch_prep_i16(c, a->fuse->raw, a->stride, a->fuse->len, a->nreads, a->fuse->lo, a->fuse->hi,
+                                         SK_PREP_MEDMAD, 0.0, (int16_t *)a->samples, (sk_prep *)a->prep, nullptr, 0);
+            if (rc0) return rc0;
+            SK_HIP(hipEventRecord(c->ev[1], c->stream));
+            a_unfused = *a;
+            a_unfused.fuse = nullptr;
+            a = &a_unfused;
+        }
+    }
     int L, R;
     if (N <= 16 * 16)      { L = 16; R = (N + 15) / 16; }
     else if (N <= 64 * 16) { L = 64; R = (N + 63) / 64; }
@@ -487,6 +523,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     const bool two_pass = !a->last_row && !a->force_single && maxlen >= 4 * (int64_t)(span + ck) &&
                           a->nreads >= 256 && !(scheme && strcmp(scheme, "full") == 0);
     SK_HIP(hipEventRecord(c->ev[2], c->stream));
+    if (a->fuse && !two_pass) return sk_fail(SK_ERR_INVALID, "internal: fused prologue without a screening pass");
     if (!two_pass) {
         c->last_retry = 0;
         c->retry_dev = false;
@@ -519,7 +556,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
     if ((rc = sk_reserve(c, &c->dtwcnt, 64))) return rc;
     int32_t *cnt = (int32_t *)c->retry.p;                  // [0] = counter, [2..] = read indices
     SK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), c->stream));
-    if (!a->accumulate) SK_HIP(hipMemsetAsync(c->dtwcnt.p, 0, 2 * sizeof(int32_t), c->stream));   // [0] retried, [1] second tier
+    if (!a->accumulate) SK_HIP(hipMemsetAsync(c->dtwcnt.p, 0, 32, c->stream));   // [0] retried, [1] second tier, +16: clock
     c->retry_dev = true;
     auto launch_retry = [&]() -> int {
         sdtw_kargs kr = k;
@@ -554,8 +591,9 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a)
         kr.nreads = a->nreads;
         return launch(c, ff, kr, L);
     };
+    if (a->fuse && !qok) return sk_fail(SK_ERR_INVALID, "internal: fused prologue without a screening pass");
     if (qok) {
-        if ((rc = sk_launch_sdtw_screen(c, a, L, R, P, ck, span_q, span2, cnt, cnt + 2))) return rc;
+        if ((rc = sk_launch_sdtw_screen(c, a, ck, span_q, span2, cnt, cnt + 2))) return rc;
         if ((rc = launch_retry())) return rc;
         SK_HIP(hipEventRecord(c->ev[3], c->stream));
         return SK_OK;

@@ -73,6 +73,15 @@ struct sdtw_kargs {
     int32_t       *qflag;       // [slot]: screening minimum of the read; QINF = a sample left the fixed-point range
     unsigned       qerr;        // E: bound (in units) on |screening cost - exact cost| of any cell
     int            wmax;        // widest candidate-column range the window pass accepts
+    unsigned      *lsum;        // [slot][nck+1][L]: minimum of the last-row columns a lane stored per checkpoint interval
+    unsigned      *wstate;      // [slot][L][R+2]: restart state of the window pass (pass P -> pass W)
+    void          *wrec;        // [slot] {tbase, jlo, jhi, flags}
+    // pass Q with the filter + medmad statistics fused in as a prologue (int16 reads): the wave preps its own reads
+    const int16_t *fz_raw;      // raw rows (same stride), or nullptr: prep / samples were filled by an earlier kernel
+    const int32_t *fz_len;
+    int            fz_lo, fz_hi, fz_vec;
+    unsigned long long *clk;    // pass Q: {shader cycles, 100 MHz reference ticks} of the first wave's sweep, or nullptr
+    int            force_retry; // sensitivity runs: reads whose hash (10 bits) is below this take the exact retry
     // window pass, second tier: the reads of one chunk whose path crossed the first (short) look-back
     const int32_t *wl_list;     // reads to process (nullptr: all of the chunk); wl_count: their number (device)
     const int32_t *wl_count;

@@ -1,32 +1,55 @@
 // sk_sdtwq.hip -- subsequence DTW by fixed-point screening + a certified exact window.
 //
-// The exact FP64 recurrence costs 16 VALU cycles per cell (28 with start tracking), and it has to
+// The exact FP64 recurrence costs 16 VALU cycles per cell (32 with start tracking), and it has to
 // be exact: MotifSeq prints the distance with 17 digits and the path's start/end columns
 // (/root/reference/MotifSeq.py:437-449).  But almost all of those cells only serve to show that
 // they do NOT hold the minimum.  So:
 //
 //  pass Q  (k_sdtw_q)   the same wave-systolic sweep in 32-bit fixed point (1 unit = 2^-22):
-//          v_min3_u32 + v_sad_u32(clamp) = 2 instructions, 4 cycles per cell.  Its cost matrix Dq
+//          v_min3_u32 + v_sad_u32(clamp) = 2 instructions, 8 cycles per cell.  Its cost matrix Dq
 //          differs from the exact one by at most E = N + n + 2 units in any cell (each local cost
 //          |q(x)-q(y)| is within one unit of |x-y|, a path has at most N + n cells, FP64 rounding
 //          is 10^-10 of a unit).  It stores the last row and, every CK steps, its systolic state.
-//  pass W  (k_sdtw_w)   per read: columns whose screening cost is within 2E of the screening
-//          minimum are the only ones that can hold the exact minimum [jlo..jhi].  Restart from the
-//          checkpoint `span` columns before jlo with every restored cell set to a LOWER BOUND of
-//          its exact value ((Dq - E) units) and S = -1, run the exact FP64 recurrence with start
-//          tracking up to jhi, take the first exact argmin inside [jlo, jhi].
+//  pass P  (k_sdtw_p)   per read: the columns whose screening cost is within 2E of the screening
+//          minimum are the only ones that can hold the exact minimum [jlo..jhi]; pick the
+//          checkpoint `span` columns before jlo and advance it IN FIXED POINT over the whole blocks
+//          up to the restart column (the checkpoints are CK steps apart: those on average CK/2
+//          columns would cost four times as much in the exact recurrence).  Leaves the restart
+//          state and {tbase, jlo, jhi} of every read for pass W.
+//  pass W  (k_sdtw_w)   restart with every restored cell set to a LOWER BOUND of its exact value
+//          ((Dq - E) units) and S = -1, run the exact FP64 recurrence with start tracking up to
+//          jhi, take the first exact argmin inside [jlo, jhi].
 //          Certificate: every cell computed from lower bounds is itself a lower bound (the
 //          recurrence is monotone, also after rounding).  If the tie-ordered back-trace of the
 //          winning cell never touches a restored cell (S >= 0), then along it lower bound == exact
 //          value, cell by cell from row 0 up, and every rejected predecessor is rejected in the
 //          exact matrix too -- so distance, end and start are the reference's, bit for bit.
 //          Otherwise (S = -1), or if the range is too wide, a sample left the fixed-point range,
-//          or the minimum may have saturated: the read goes to the retry list.
+//          or the minimum may have saturated: the read goes to the next tier / the retry list.
 //  retry   the exact single pass (k_sdtw FULL) on the listed reads only.
+//
+// Lane layout (round 3): a read is spread over L = 8 lanes for motifs of up to 256 points (8 reads per
+// wavefront, R = ceil(N / 8) <= 32 rows per lane), L = 16 up to 512 points, L = 64 beyond.  Per step a lane runs
+// 2R cell instructions plus a fixed handful (the neighbour's row by DPP, the short-lane select, LDS traffic), so
+// fewer, longer lanes spend a larger share of the issue slots on cells -- and N = 200 fills 8 x 25 slots exactly
+// where 16 x 13 leaves 8 of 208 empty.  Groups of 8 lanes share a DPP row of 16: the shift that hands lane l-1's
+// bottom row to lane l is a v_and_b32_dpp with a per-lane mask that zeroes what lane 8 would pick up from lane 7.
+// Samples reach the lanes through a small LDS ring per read group in all three kernels (one ds_read with an
+// immediate offset per step): the vector ALU is the bottleneck, the LDS pipe is idle.
+//
+// This file is compiled once per sample feed (sk_sdtwq_f64.hip / sk_sdtwq_raw.hip include it with
+// SK_SDTWQ_FEED set), so that the three sets of template instantiations build in parallel.
 #include "sk_sdtw_dev.h"
+#include "sk_prepw_dev.h"
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
+
+#ifndef SK_SDTWQ_FEED
+#define SK_SDTWQ_FEED 0          /* SK_FEED_I16 */
+#define SK_SDTWQ_MAIN 1
+#endif
 
 namespace {
 
@@ -73,16 +96,45 @@ __device__ __forceinline__ unsigned qimg(double v)
     return (unsigned)((int)rint(v * QSCALE)) + 0x80000000u;
 }
 
+// lane l <- lane l-1 of the same read group, 0 into the group's lane 0.  notfirst = 0 in a group's lane 0, ~0
+// elsewhere (only looked at for L = 8, where two groups share a DPP row; the s_nop covers the
+// VALU-write -> DPP-read hazard the compiler cannot see inside the statement).
+template <int L>
+__device__ __forceinline__ unsigned shr0(unsigned v, unsigned notfirst)
+{
+    if constexpr (L >= 16) {
+        (void)notfirst;
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, (L == 16) ? DPP_ROW_SHR1 : DPP_WAVE_SHR1, 0xF, 0xF, true);
+    } else {
+        unsigned r;
+        asm("s_nop 1\n\t"
+            "v_and_b32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+            : "=v"(r) : "v"(v), "v"(notfirst));
+        return r;
+    }
+}
+
+// the restart point of one read, handed from pass P to pass W
+struct wrec {
+    int32_t tbase;      // first step of the exact recurrence
+    int32_t jlo, jhi;   // candidate columns
+    int32_t flags;      // 1: screened (a window exists)  2: the state was restored from a checkpoint
+};
+
 // ---------------------------------------------------------------------------------------------
 // pass Q
 // ---------------------------------------------------------------------------------------------
+#ifndef SK_Q_WAVES
+#define SK_Q_WAVES(R) ((R) >= 22 && (R) <= 25 ? 5 : 1)
+#endif
 template <int L, int R, int FEED>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SK_Q_WAVES(R), 8)))
 void k_sdtw_q(const sdtw_kargs a)
 {
+    static_assert(L == 8 || L == 16 || L == 64, "lanes per read");
     constexpr int G = 64 / L;
-    constexpr int SHR = (L == 16) ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
     constexpr int CKW = R + 2;
+    constexpr int U = (L < 16) ? 4 : 16;            // steps per unrolled run (y values prefetched from LDS)
 
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -91,14 +143,40 @@ void k_sdtw_q(const sdtw_kargs a)
     const bool live = slot < a.nreads;
     if (!live) slot = a.nreads - 1;
     const int r = a.read0 + slot;
+    // the clock this launch runs at (DVFS: it depends on what the chip is doing): the first wave times its own sweep
+    // with the shader-cycle counter and the 100 MHz reference counter (sk_last_dtw_clock)
+    const bool timer = a.clk && blockIdx.x == 0 && threadIdx.x < 64;
+    unsigned long long tc0 = 0, tr0 = 0;
+    if (timer) { tc0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
 
     int n;
     double center = 0.0, scale = 1.0;
     const int16_t *s16 = nullptr;
     const double  *s64 = nullptr;
     if constexpr (FEED == SK_FEED_I16) {
-        const sk_prep pr = a.prep[r];
-        n = pr.n; center = pr.center; scale = pr.scale;
+        if (a.fz_raw) {
+            // Fused prologue: scale_outliers + medmad of this wave's G reads, one after the other on the whole wave
+            // (sk_prepw_dev.h: compacted samples -> a.samples, statistics -> a.prep, both also read by the later
+            // passes).  Latency-bound work that the sweeps of the SIMD's other waves hide; as a kernel of its own it
+            // cost 4 ms per 1 M reads.
+            extern __shared__ __align__(16) unsigned char lds_dyn[];
+            const int nb4 = ((a.fz_hi - a.fz_lo - 1) + 3) & ~3;
+            const prepw_env E = prepw_setup<5>((unsigned *)lds_dyn + (size_t)(threadIdx.x >> 6) * nb4, lane,
+                                               a.fz_lo, a.fz_hi, a.fz_vec);
+            n = 0;
+            for (int gg = 0; gg < G; gg++) {
+                if (wave * G + gg >= a.nreads) break;           // (wave-uniform)
+                const sk_prep pr = prepw_read<5>(E, a.fz_raw, a.stride, a.fz_len, a.read0 + wave * G + gg, lane,
+                                                 (int16_t *)a.samples, (sk_prep *)a.prep);
+                if (g == gg) { n = pr.n; center = pr.center; scale = pr.scale; }
+            }
+            // the sweep below reads what other lanes of this wave just stored
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            const sk_prep pr = a.prep[r];
+            n = pr.n; center = pr.center; scale = pr.scale;
+        }
         s16 = (const int16_t *)a.samples + (int64_t)r * a.stride;
     } else if constexpr (FEED == SK_FEED_F64_NORM) {
         const sk_prep pr = a.prep[r];
@@ -121,6 +199,7 @@ void k_sdtw_q(const sdtw_kargs a)
 #pragma unroll
     for (int k = 0; k < R; k++) xq[k] = a.xlayq[l * R + k];
     const bool shortlane = l < a.P;
+    const unsigned notfirst = (l == 0) ? 0u : 0xffffffffu;
 
     unsigned Da[R], Db[R];                          // ping-pong: a column reads one, writes the other
 #pragma unroll
@@ -132,6 +211,7 @@ void k_sdtw_q(const sdtw_kargs a)
         if (live && (a.prep[r].flags & SK_FLAG_RECENTRE)) bad = 1;
     }
     unsigned qmin = QINF;                           // minimum of the last row so far
+    unsigned smin = QINF;                           // ... of this lane's last-row values since the last summary
 
     // the sample feed in two halves, so that the load for the next block is in flight during this
     // block's L steps and only converted afterwards
@@ -169,10 +249,10 @@ void k_sdtw_q(const sdtw_kargs a)
     unsigned F = toq(loadraw(l), l);
     // one step: lane l-1's bottom row comes in by DPP, run the column old -> nw
     auto step = [&](const unsigned (&old)[R], unsigned (&nw)[R], unsigned yq, unsigned *hslot) {
-        const unsigned upq = (unsigned)__builtin_amdgcn_update_dpp(0, (int)botq, SHR, 0xF, 0xF, true);
+        const unsigned upq = shr0<L>(botq, notfirst);
         qcolumn<R>(old, nw, xq, yq, diagq, upq);
         diagq = upq;
-        // (a bit select, v_bitop3_b32: 2.6 cycles of issue against v_cndmask's 4.6)
+        // (a bit select, v_bitop3_b32: 2 cycles of issue against v_cndmask's 4)
         if constexpr (R >= 2) asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(botq) : "v"(nw[R - 2]), "v"(nw[R - 1]), "v"(smask));
         else                  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(botq) : "v"(upq), "v"(nw[0]), "v"(smask));
         *hslot = nw[R - 1];                         // (only lane L-1's lands in hbuf)
@@ -185,26 +265,44 @@ void k_sdtw_q(const sdtw_kargs a)
 #pragma unroll
             for (int k = 0; k < R; k++) cp[k] = Da[k];
             cp[R] = botq; cp[R + 1] = diagq;
+            // summary of the last row: the minimum over the columns this lane handed to lastq during the ck steps
+            // before this one (columns == l + 1 mod L of one window of ck columns) -- pass P looks at the
+            // (nck + 1) * L summaries of a read instead of all its columns
+            a.lsum[((int64_t)(r - a.read0) * (a.nck + 1) + (t0 / a.ck - 1)) * L + l] = smin;
+            smin = QINF;
         }
         const unsigned *yr;
         if (blk & 1) { ybuf[L + l] = F; yr = ybuf + L - l; }
         else         { ybuf[l] = F; ybuf[2 * L + l] = F; yr = ybuf + 2 * L - l; }
 #pragma unroll 1
-        for (int qq = 0; qq < L; qq += 16) {
-            unsigned yv[16];
+        for (int qq = 0; qq < L; qq += U) {
+            unsigned yv[U];
 #pragma unroll
-            for (int q = 0; q < 16; q++) yv[q] = yr[qq + q];
+            for (int q = 0; q < U; q++) yv[q] = yr[qq + q];
 #pragma unroll
-            for (int q = 0; q < 16; q += 2) {       // after two steps the ping-pong roles are back
+            for (int q = 0; q < U; q += 2) {        // after two steps the ping-pong roles are back
                 step(Da, Db, yv[q], hw + qq + q);
                 step(Db, Da, yv[q + 1], hw + qq + q + 1);
             }
         }
         F = toq(rawnext, (blk + 1) * L + l);
         const int j = t0 + l - (L - 1);             // lane L-1's column at step t0 + l
-        if (j >= 0 && j < n) { const unsigned hv = hbuf[l]; lastq[j] = hv; qmin = min(qmin, hv); }
+        if (j >= 0 && j < n) { const unsigned hv = hbuf[l]; lastq[j] = hv; smin = min(smin, hv); }
     }
-    // the read's screening minimum for pass W; a sample outside the fixed-point range anywhere in the
+    // the columns after the last checkpoint
+    {
+        const int cl = nblk > 0 ? min((nblk * L - 1) / a.ck, a.nck) : 0;   // checkpoints this wave passed (wave-uniform)
+        if (live) a.lsum[((int64_t)(r - a.read0) * (a.nck + 1) + cl) * L + l] = smin;
+        // (summaries of intervals the read never reached)
+        for (int cc = cl + 1; cc <= a.nck; cc++)
+            if (live) a.lsum[((int64_t)(r - a.read0) * (a.nck + 1) + cc) * L + l] = QINF;
+    }
+    // the read's screening minimum = the smallest summary
+    if (live) {
+        const unsigned *ls = a.lsum + (int64_t)(r - a.read0) * (a.nck + 1) * L + l;
+        for (int cc = 0; cc <= a.nck; cc++) qmin = min(qmin, ls[(int64_t)cc * L]);
+    }
+    // the read's screening minimum for pass P; a sample outside the fixed-point range anywhere in the
     // read disqualifies the screening (reported as an infinite minimum)
 #pragma unroll
     for (int d = 1; d < L; d <<= 1) {
@@ -212,21 +310,21 @@ void k_sdtw_q(const sdtw_kargs a)
         qmin = min(qmin, (unsigned)__shfl_xor((int)qmin, d));
     }
     if (live && l == 0) a.qflag[r - a.read0] = (int32_t)(bad ? QINF : qmin);
+    if (timer && lane == 0) {
+        a.clk[0] = __builtin_amdgcn_s_memtime() - tc0;
+        a.clk[1] = __builtin_amdgcn_s_memrealtime() - tr0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// pass W
+// pass P: candidate columns, restart point, fixed-point pre-roll
 // ---------------------------------------------------------------------------------------------
-// (four waves per SIMD: the two phases together want ~140 VGPRs; capping at 96 spills into the loops)
 template <int L, int R, int FEED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R <= 13 ? 4 : 3, 8)))
-void k_sdtw_w(const sdtw_kargs a)
+__global__ __launch_bounds__(256)
+void k_sdtw_p(const sdtw_kargs a)
 {
     constexpr int G = 64 / L;
-    constexpr int SHR = (L == 16) ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
-    constexpr int ROL = (L == 16) ? DPP_ROW_ROL1 : DPP_WAVE_ROL1;
     constexpr int CKW = R + 2;
-    const double INF = __builtin_huge_val();
 
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -236,6 +334,176 @@ void k_sdtw_w(const sdtw_kargs a)
     if (a.wl_count) {                               // second tier: the list length is only known on the device
         nreads = min(*a.wl_count, a.nreads);
         if (a.total_ptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.total_ptr, nreads);   // (diagnostic)
+        if (nreads <= 0) return;                    // (block-uniform)
+    }
+    const bool live = slot < nreads;
+    if (!live) slot = nreads - 1;
+    const int r = a.wl_list ? a.wl_list[slot] : a.read0 + slot;
+
+    int n;
+    double center = 0.0, scale = 1.0;
+    const int16_t *s16 = nullptr;
+    const double  *s64 = nullptr;
+    if constexpr (FEED == SK_FEED_I16) {
+        const sk_prep pr = a.prep[r];
+        n = pr.n; center = pr.center; scale = pr.scale;
+        s16 = (const int16_t *)a.samples + (int64_t)r * a.stride;
+    } else if constexpr (FEED == SK_FEED_F64_NORM) {
+        const sk_prep pr = a.prep[r];
+        n = pr.n; center = pr.center; scale = pr.scale;
+        s64 = (const double *)a.samples + a.off[r];
+    } else {
+        n = (int)(a.off[r + 1] - a.off[r]);
+        s64 = (const double *)a.samples + a.off[r];
+    }
+    if (!live) n = 0;
+
+    // ---- candidate columns: screening cost within 2E of the screening minimum ----------------
+    // Pass Q left, per checkpoint interval c and lane l', the minimum over the last-row columns
+    // c * ck + q * L + l' - (L - 1), q = 0 .. ck / L - 1: only intervals whose summary is within the threshold can
+    // hold a candidate, so a read costs (nck + 1) * L summary words here instead of its whole last row.
+    const unsigned *lastq = a.lastq + (int64_t)(r - a.read0) * a.lq_stride;
+    const unsigned *ls = a.lsum + (int64_t)(r - a.read0) * (a.nck + 1) * L + l;
+    const unsigned b = (unsigned)a.qflag[r - a.read0];   // the screening minimum (pass Q), QINF: not usable
+    const unsigned thr = (b > QINF - 2u * a.qerr) ? QINF : b + 2u * a.qerr;
+    int jlo = 0x7fffffff, jhi = -1;
+    if (n > 0 && b < QSAFE) {
+        for (int cc = 0; cc <= a.nck; cc++) {
+            if (ls[(int64_t)cc * L] > thr) continue;
+            const int j0 = cc * a.ck + l - (L - 1);
+            for (int q = 0; q < a.ck / L; q++) {
+                const int j = j0 + q * L;
+                if (j >= 0 && j < n && lastq[j] <= thr) { jlo = min(jlo, j); jhi = max(jhi, j); }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < L; d <<= 1) { jlo = min(jlo, __shfl_xor(jlo, d)); jhi = max(jhi, __shfl_xor(jhi, d)); }
+    const bool screened = (n > 0) && (b < QSAFE) && (jhi >= jlo) && (jhi - jlo <= a.wmax);
+
+    int tbase = 0, c0 = 0, npre = 0;
+    if (screened) {
+        const int tx = max(0, jlo - a.span);        // where the exact recurrence has to start
+        c0 = tx / a.ck;
+        if (c0 > a.nck) c0 = a.nck;
+        tbase = c0 * a.ck;
+        if (c0 > 0) npre = (tx - tbase) / L;        // whole blocks between the checkpoint and tx
+    }
+    const bool shortlane = l < a.P;
+    const unsigned notfirst = (l == 0) ? 0u : 0xffffffffu;
+
+    // ---- pre-roll: from the checkpoint to the block that holds tx, in fixed point --------------
+    // Groups of one wave need different numbers of blocks: a group loads its checkpoint in the
+    // iteration in which its turn starts (what it computed before on never-initialised state is
+    // overwritten), so all groups finish together.
+    unsigned Qs[R];                                 // screening state: R cells, lane l-1's row, diagonal
+    unsigned botq = QINF, diagq = QINF;
+#pragma unroll
+    for (int k = 0; k < R; k++) Qs[k] = QINF;
+    const unsigned *cp = a.ckq + (((int64_t)(r - a.read0) * a.nck + (c0 > 0 ? c0 - 1 : 0)) * L + l) * CKW;
+    auto load_ckpt = [&]() {
+#pragma unroll
+        for (int k = 0; k < R; k++) Qs[k] = cp[k];
+        botq = cp[R]; diagq = cp[R + 1];
+    };
+    int maxpre = npre;
+#pragma unroll
+    for (int d = L; d < 64; d <<= 1) maxpre = max(maxpre, __shfl_xor(maxpre, d));
+    maxpre = __builtin_amdgcn_readfirstlane(maxpre);
+    if (maxpre > 0) {
+        const double inv_scale = 1.0 / scale;
+        const int nlast = max(n - 1, 0);
+        if (n == 0) { s16 = (const int16_t *)a.xlayq; s64 = (const double *)a.xlayq; }   // any valid address
+        auto toq = [&](int idx) -> unsigned {       // the screening pass's image of sample idx
+            const int ci = min(max(idx, 0), nlast);
+            double v;
+            if constexpr (FEED == SK_FEED_I16)           v = ((double)s16[ci] - center) * inv_scale;
+            else if constexpr (FEED == SK_FEED_F64_NORM) v = (s64[ci] - center) * inv_scale;
+            else                                         v = s64[ci];
+            return (idx >= 0 && idx < n && fabs(v) < QLIM) ? qimg(v) : QINF;
+        };
+        unsigned xq[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) xq[k] = a.xlayq[l * R + k];
+        unsigned Qn[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) Qn[k] = QINF;
+        const unsigned smask = shortlane ? 0xffffffffu : 0u;
+        __shared__ unsigned lds_p[4][3 * 64];       // the sample ring of pass Q (no last-row buffer here)
+        unsigned *ybuf = lds_p[threadIdx.x >> 6] + g * 3 * L;
+        unsigned Fq = QINF;
+        const int startblk = maxpre - npre;         // my group's first block
+        auto qstep = [&](const unsigned (&old)[R], unsigned (&nw)[R], unsigned yq) {
+            const unsigned upq = shr0<L>(botq, notfirst);
+            qcolumn<R>(old, nw, xq, yq, diagq, upq);
+            diagq = upq;
+            if constexpr (R >= 2) asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(botq) : "v"(nw[R - 2]), "v"(nw[R - 1]), "v"(smask));
+            else                  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(botq) : "v"(upq), "v"(nw[0]), "v"(smask));
+        };
+        for (int pb = 0; pb < maxpre; pb++) {
+            const int t0 = tbase + (pb - startblk) * L;
+            if (pb == startblk && npre > 0) {
+                load_ckpt();
+                const unsigned prev = toq(t0 - L + l);   // the block before: lane l needs sample t - l
+                if (pb & 1) ybuf[l] = prev; else ybuf[L + l] = prev;
+                Fq = toq(t0 + l);
+            }
+            const unsigned Fnext = toq(t0 + L + l);
+            const unsigned *yr;
+            if (pb & 1) { ybuf[L + l] = Fq; yr = ybuf + L - l; }
+            else        { ybuf[l] = Fq; ybuf[2 * L + l] = Fq; yr = ybuf + 2 * L - l; }
+#pragma unroll 1
+            for (int q = 0; q < L; q += 2) {        // L is even: after two steps the roles are back
+                const unsigned y0 = yr[q], y1 = yr[q + 1];
+                qstep(Qs, Qn, y0);
+                qstep(Qn, Qs, y1);
+            }
+            Fq = Fnext;
+        }
+    }
+    if (c0 > 0 && npre == 0) load_ckpt();
+    tbase += npre * L;
+
+    if (live) {
+        if (c0 > 0) {
+            unsigned *ws = a.wstate + ((int64_t)slot * L + l) * CKW;
+#pragma unroll
+            for (int k = 0; k < R; k++) ws[k] = Qs[k];
+            ws[R] = botq; ws[R + 1] = diagq;
+        }
+        if (l == 0) {
+            wrec w;
+            w.tbase = tbase; w.jlo = jlo; w.jhi = jhi;
+            w.flags = (screened ? 1 : 0) | (c0 > 0 ? 2 : 0);
+            ((wrec *)a.wrec)[slot] = w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass W: the exact window
+// ---------------------------------------------------------------------------------------------
+// (R > 16: the lane's motif rows stay in LDS -- one ds_read_b64 per cell on the idle LDS pipe -- instead of 2R more
+// VGPRs, which would leave two waves per SIMD; the 8 lanes of a group read 8 addresses R doubles apart, all groups
+// the same ones: no bank conflict)
+template <int L, int R, int FEED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R <= 13 ? 4 : (R <= 26 ? 3 : 2), 8)))
+void k_sdtw_w(const sdtw_kargs a)
+{
+    constexpr int G = 64 / L;
+    constexpr bool XLDS = R > 16;
+    constexpr int SHR = (L == 64) ? DPP_WAVE_SHR1 : DPP_ROW_SHR1;
+    constexpr int CKW = R + 2;
+    constexpr int U = (L < 16) ? L : 8;             // steps per unrolled run (samples prefetched from LDS)
+    const double INF = __builtin_huge_val();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int g = lane / L, l = lane % L;
+    int slot = wave * G + g;
+    int nreads = a.nreads;
+    if (a.wl_count) {                               // second tier: the list length is only known on the device
+        nreads = min(*a.wl_count, a.nreads);
         if (nreads <= 0) return;                    // (block-uniform)
     }
     const bool live = slot < nreads;
@@ -261,105 +529,15 @@ void k_sdtw_w(const sdtw_kargs a)
     }
     if (!live) n = 0;
 
-    // ---- candidate columns: screening cost within 2E of the screening minimum ----------------
-    const unsigned *lastq = a.lastq + (int64_t)(r - a.read0) * a.lq_stride;
-    // (rows are 16-byte aligned and padded to a multiple of 4 columns: four columns per load)
-    const uint4 *lq4 = (const uint4 *)lastq;
-    const int n4 = (n + 3) >> 2;
-    const unsigned b = (unsigned)a.qflag[r - a.read0];   // the screening minimum (pass Q), QINF: not usable
-    const unsigned thr = (b > QINF - 2u * a.qerr) ? QINF : b + 2u * a.qerr;
-    int jlo = 0x7fffffff, jhi = -1;
-    for (int q4 = l; q4 < n4; q4 += L) {
-        const uint4 v = lq4[q4];
-        const int j = q4 * 4;
-        if (v.x <= thr) { jlo = min(jlo, j); jhi = max(jhi, j); }
-        if (j + 1 < n && v.y <= thr) { jlo = min(jlo, j + 1); jhi = max(jhi, j + 1); }
-        if (j + 2 < n && v.z <= thr) { jlo = min(jlo, j + 2); jhi = max(jhi, j + 2); }
-        if (j + 3 < n && v.w <= thr) { jlo = min(jlo, j + 3); jhi = max(jhi, j + 3); }
-    }
-#pragma unroll
-    for (int d = 1; d < L; d <<= 1) { jlo = min(jlo, __shfl_xor(jlo, d)); jhi = max(jhi, __shfl_xor(jhi, d)); }
-    const bool screened = (n > 0) && (b < QSAFE) && (jhi >= jlo) &&
-                          (jhi - jlo <= a.wmax);
-
-    int tbase = 0, tlast = -1, c0 = 0, npre = 0;
-    if (screened) {
-        const int tx = max(0, jlo - a.span);        // where the exact recurrence has to start
-        c0 = tx / a.ck;
-        if (c0 > a.nck) c0 = a.nck;
-        tbase = c0 * a.ck;
-        tlast = jhi + L - 1;
-        if (c0 > 0) npre = (tx - tbase) / L;        // whole blocks between the checkpoint and tx
-    }
+    const wrec rec = ((const wrec *)a.wrec)[slot];
+    const bool screened = live && (rec.flags & 1);
+    const bool restored = screened && (rec.flags & 2);
+    const int tbase = screened ? rec.tbase : 0;
+    const int jlo = rec.jlo, jhi = rec.jhi;
+    const int tlast = screened ? jhi + L - 1 : -1;
     const bool shortlane = l < a.P;
-
-    // ---- pre-roll: from the checkpoint to the block that holds tx in fixed point -------------------
-    // The checkpoints are ck steps apart; running the remaining (on average ck/2) steps with the
-    // exact FP64 recurrence would cost four times what the screening recurrence does, so the
-    // systolic state is first advanced in fixed point.  Groups of one wave need different numbers of
-    // blocks: a group loads its checkpoint in the iteration in which its turn starts (what it
-    // computed before on never-initialised state is overwritten), so all groups finish together.
-    unsigned Qs[R];                                 // screening state: R cells, lane l-1's row, diagonal
-    unsigned botq = QINF, diagq = QINF;
-#pragma unroll
-    for (int k = 0; k < R; k++) Qs[k] = QINF;
-    const unsigned *cp = a.ckq + (((int64_t)(r - a.read0) * a.nck + (c0 > 0 ? c0 - 1 : 0)) * L + l) * CKW;
-    auto load_ckpt = [&]() {
-#pragma unroll
-        for (int k = 0; k < R; k++) Qs[k] = cp[k];
-        botq = cp[R]; diagq = cp[R + 1];
-    };
-    int maxpre = npre;
-#pragma unroll
-    for (int d = L; d < 64; d <<= 1) maxpre = max(maxpre, __shfl_xor(maxpre, d));
-    maxpre = __builtin_amdgcn_readfirstlane(maxpre);
-    if (maxpre > 0) {
-        const double inv_scale = 1.0 / scale;
-        const int nlast = max(n - 1, 0);
-        auto toq = [&](int idx) -> unsigned {       // the screening pass's image of sample idx
-            if (idx < 0 || idx >= n) return QINF;
-            double v;
-            if constexpr (FEED == SK_FEED_I16)           v = ((double)s16[min(idx, nlast)] - center) * inv_scale;
-            else if constexpr (FEED == SK_FEED_F64_NORM) v = (s64[min(idx, nlast)] - center) * inv_scale;
-            else                                         v = s64[min(idx, nlast)];
-            return (fabs(v) < QLIM) ? qimg(v) : QINF;
-        };
-        unsigned xq[R];
-#pragma unroll
-        for (int k = 0; k < R; k++) xq[k] = a.xlayq[l * R + k];
-        unsigned Qn[R];
-#pragma unroll
-        for (int k = 0; k < R; k++) Qn[k] = QINF;
-        unsigned yq = QINF, Fq = QINF;
-        const int startblk = maxpre - npre;         // my group's first block
-        auto qstep = [&](const unsigned (&old)[R], unsigned (&nw)[R]) {
-            yq = (unsigned)dpp_i32<SHR>((int)Fq, (int)yq);
-            Fq = (unsigned)dpp_i32<ROL>((int)Fq, (int)Fq);
-            const unsigned upq = (unsigned)__builtin_amdgcn_update_dpp(0, (int)botq, SHR, 0xF, 0xF, true);
-            qcolumn<R>(old, nw, xq, yq, diagq, upq);
-            diagq = upq;
-            if constexpr (R >= 2) botq = shortlane ? nw[R - 2] : nw[R - 1];
-            else                  botq = shortlane ? upq : nw[0];
-        };
-        for (int pb = 0; pb < maxpre; pb++) {
-            const int t0 = tbase + (pb - startblk) * L;
-            if (pb == startblk && npre > 0) {
-                load_ckpt();
-                yq = toq(t0 - 1 - l);               // the sample this lane held after step t0 - 1
-                Fq = toq(t0 + l);
-            }
-            const unsigned Fnext = toq(t0 + L + l);
-#pragma unroll 1
-            for (int q = 0; q < L; q += 2) {        // L is even: after two steps the roles are back
-                qstep(Qs, Qn);
-                qstep(Qn, Qs);
-            }
-            Fq = Fnext;
-        }
-    }
-    if (c0 > 0 && npre == 0) load_ckpt();
-    tbase += npre * L;
-    asm volatile("" ::: "memory");                  // keep the exact phase's loads (and registers) below
+    const unsigned notfirst = (l == 0) ? 0u : 0xffffffffu;
+    const unsigned first = ~notfirst;
 
     int nsteps = tlast - tbase + 1;
     if (nsteps < 0) nsteps = 0;
@@ -368,15 +546,27 @@ void k_sdtw_w(const sdtw_kargs a)
     nsteps = __builtin_amdgcn_readfirstlane(nsteps);
     const int nblk = (nsteps + L - 1) / L;
 
-    double x[R];
+    double x[XLDS ? 1 : R];
+    __shared__ double lds_x[XLDS ? L * R : 1];
+    if constexpr (XLDS) {
+        for (int i = threadIdx.x; i < L * R; i += blockDim.x) lds_x[i] = a.xlay[i];
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int k = 0; k < R; k++) x[k] = a.xlay[l * R + k];
+        for (int k = 0; k < R; k++) x[k] = a.xlay[l * R + k];
+    }
+    const double *xl = lds_x + (XLDS ? l * R : 0);
 
+    const int nlast = max(n - 1, 0);
+    if (n == 0) { s16 = (const int16_t *)a.xlay; s64 = (const double *)a.xlay; }       // any valid address
+    // (unconditional load from a clamped index: a load under a branch is waited for at the join)
     auto fetch = [&](int idx) -> double {
-        if (idx < 0 || idx >= n) return INF;
-        if constexpr (FEED == SK_FEED_I16)           return ((double)s16[idx] - center) / scale;
-        else if constexpr (FEED == SK_FEED_F64_NORM) return (s64[idx] - center) / scale;
-        else                                         return s64[idx];
+        const int ci = min(max(idx, 0), nlast);
+        double v;
+        if constexpr (FEED == SK_FEED_I16)           v = ((double)s16[ci] - center) / scale;
+        else if constexpr (FEED == SK_FEED_F64_NORM) v = (s64[ci] - center) / scale;
+        else                                         v = s64[ci];
+        return (idx < 0 || idx >= n) ? INF : v;
     };
     // lower bound (in signal units) of a cell whose screening cost is q
     auto lb = [&](unsigned q) -> double { return (double)(q > a.qerr ? q - a.qerr : 0u) * QUNIT; };
@@ -389,14 +579,13 @@ void k_sdtw_w(const sdtw_kargs a)
     int    botS = (R == 1 && l == 0 && shortlane) ? 0 : -1;
     double diagD = (l == 0) ? 0.0 : INF;
     int    diagS = (l == 0) ? tbase : -1;
-    double y = INF;
-    if (c0 > 0) {
+    if (restored) {
+        const unsigned *ws = a.wstate + ((int64_t)slot * L + l) * CKW;
 #pragma unroll
-        for (int k = 0; k < R; k++) D[k] = lb(Qs[k]);
-        botD = lb(botq);
-        if (l > 0) diagD = lb(diagq);               // lane 0's diag is the virtual row: exactly 0
+        for (int k = 0; k < R; k++) D[k] = lb(ws[k]);
+        botD = lb(ws[R]);
+        if (l > 0) diagD = lb(ws[R + 1]);           // lane 0's diag is the virtual row: exactly 0
         if (R == 1 && l == 0 && shortlane) { botD = 0.0; botS = tbase; }   // forwards the virtual row
-        y = fetch(tbase - 1 - l);                   // the sample this lane held after step tbase-1
     }
     double best = INF;  int bestS = -1, bestJ = -1;
     // the running argmin is only wanted where lane L-1 sits on a candidate column -- the last few steps of the window:
@@ -406,47 +595,69 @@ void k_sdtw_w(const sdtw_kargs a)
     for (int d = L; d < 64; d <<= 1) s0 = min(s0, __shfl_xor(s0, d));
     s0 = __builtin_amdgcn_readfirstlane(s0);
 
+    // The normalised samples go through an LDS ring per read group, as in pass Q (doubles here):
+    //   ybuf[0,L) even blocks | ybuf[L,2L) odd blocks | ybuf[2L,3L) copy of [0,L)
+    __shared__ double lds_w[4][3 * 64];
+    double *ybuf = lds_w[threadIdx.x >> 6] + g * 3 * L;
+    ybuf[L + l] = fetch(tbase - L + l);             // the block before the first: lane l starts on column tbase - l
     double F = fetch(tbase + l);
     for (int blk = 0; blk < nblk; blk++) {
         const double Fnext = fetch(tbase + (blk + 1) * L + l);
-#pragma unroll 2
-        for (int q = 0; q < L; q++) {
-            const int t = tbase + blk * L + q;
-            y = dpp_f64<SHR>(F, y);
-            F = dpp_f64<ROL>(F, F);
-            const double upD = dpp_f64<SHR>(0.0, botD);
-            const int    upS = dpp_i32<SHR>(t + 1, botS);
-            double dgD = diagD;  int dgS = diagS;
-            double uD = upD;     int uS = upS;
+        const double *yr;
+        if (blk & 1) { ybuf[L + l] = F; yr = ybuf + L - l; }
+        else         { ybuf[l] = F; ybuf[2 * L + l] = F; yr = ybuf + 2 * L - l; }
+#pragma unroll 1
+        for (int qq = 0; qq < L; qq += U) {
+            double yv[U];
 #pragma unroll
-            for (int k = 0; k < R; k++) {
-                const double lfD = D[k];  const int lfS = S[k];
-                const double c = fabs(x[k] - y);
-                // (no NaN can reach this pass -- pass Q sends reads with a non-finite or out-of-range sample to the
-                // exact single pass -- so v_min_f64 IS the ternary select of the reference's min3; written as a
-                // select the compiler spends two v_cndmask per double: 10 instructions per cell instead of 8)
-                const bool lt1 = lfD < dgD;
-                const double m1 = vmin(lfD, dgD);
-                const int    s1 = lt1 ? lfS : dgS;
-                const bool lt2 = uD < m1;
-                const double m = vmin(uD, m1);
-                const int    s = lt2 ? uS : s1;
-                const double nd = c + m;
-                dgD = lfD;  dgS = lfS;
-                D[k] = nd;  S[k] = s;
-                uD = nd;    uS = s;
-            }
-            diagD = upD;  diagS = upS;
-            if constexpr (R >= 2) {
-                botD = shortlane ? D[R - 2] : D[R - 1];
-                botS = shortlane ? S[R - 2] : S[R - 1];
-            } else {
-                botD = shortlane ? upD : D[0];
-                botS = shortlane ? upS : S[0];
-            }
-            if (blk * L + q >= s0) {                       // (wave-uniform)
-                const int j = t - l;
-                if (j >= jlo && j <= jhi && D[R - 1] < best) { best = D[R - 1]; bestS = S[R - 1]; bestJ = j; }
+            for (int q = 0; q < U; q++) yv[q] = yr[qq + q];
+#pragma unroll
+            for (int q = 0; q < U; q++) {
+                const int t = tbase + blk * L + qq + q;
+                const double y = yv[q];
+                double upD;  int upS;
+                if constexpr (L >= 16) {
+                    upD = dpp_f64<SHR>(0.0, botD);
+                    upS = dpp_i32<SHR>(t + 1, botS);
+                } else {
+                    const unsigned lo = shr0<L>((unsigned)__double2loint(botD), notfirst);
+                    const unsigned hi = shr0<L>((unsigned)__double2hiint(botD), notfirst);
+                    upD = __hiloint2double((int)hi, (int)lo);
+                    upS = (int)(shr0<L>((unsigned)botS, notfirst) | (first & (unsigned)(t + 1)));
+                }
+                double dgD = diagD;  int dgS = diagS;
+                double uD = upD;     int uS = upS;
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    const double lfD = D[k];  const int lfS = S[k];
+                    const double xk = XLDS ? xl[k] : x[k];
+                    const double c = fabs(xk - y);
+                    // (no NaN can reach this pass -- pass Q sends reads with a non-finite or out-of-range sample to the
+                    // exact single pass -- so v_min_f64 IS the ternary select of the reference's min3; written as a
+                    // select the compiler spends two v_cndmask per double: 10 instructions per cell instead of 8)
+                    const bool lt1 = lfD < dgD;
+                    const double m1 = vmin(lfD, dgD);
+                    const int    s1 = lt1 ? lfS : dgS;
+                    const bool lt2 = uD < m1;
+                    const double m = vmin(uD, m1);
+                    const int    s = lt2 ? uS : s1;
+                    const double nd = c + m;
+                    dgD = lfD;  dgS = lfS;
+                    D[k] = nd;  S[k] = s;
+                    uD = nd;    uS = s;
+                }
+                diagD = upD;  diagS = upS;
+                if constexpr (R >= 2) {
+                    botD = shortlane ? D[R - 2] : D[R - 1];
+                    botS = shortlane ? S[R - 2] : S[R - 1];
+                } else {
+                    botD = shortlane ? upD : D[0];
+                    botS = shortlane ? upS : S[0];
+                }
+                if (blk * L + qq + q >= s0) {               // (wave-uniform)
+                    const int j = t - l;
+                    if (j >= jlo && j <= jhi && D[R - 1] < best) { best = D[R - 1]; bestS = S[R - 1]; bestJ = j; }
+                }
             }
         }
         F = Fnext;
@@ -455,17 +666,19 @@ void k_sdtw_w(const sdtw_kargs a)
     if (live && l == L - 1) {
         sk_hit h;
         h.n = n; h.flags = flags;
+        // tuning / sensitivity runs only: send a share of the reads to the exact retry whatever the window found
+        const bool forced = a.force_retry && (((unsigned)r * 2654435761u) >> 22) < (unsigned)a.force_retry;
         if (n <= 0) {
             h.dist = __builtin_nan(""); h.start = -1; h.end = -1;
             a.out[r] = h;
-        } else if (screened && bestS >= 0) {
+        } else if (screened && bestS >= 0 && !forced) {
             h.dist = best; h.start = bestS; h.end = bestJ;
             a.out[r] = h;
         } else {
             h.dist = __builtin_nan(""); h.start = -1; h.end = -1;    // overwritten by a later pass
             a.out[r] = h;
-            if (screened && a.soft) a.soft[atomicAdd(a.soft_cnt, 1)] = r;   // path wider than this look-back: next tier
-            else                    a.retry[atomicAdd(a.retry_cnt, 1)] = r; // the exact single pass
+            if (screened && a.soft && !forced) a.soft[atomicAdd(a.soft_cnt, 1)] = r;   // path wider than this look-back: next tier
+            else                               a.retry[atomicAdd(a.retry_cnt, 1)] = r; // the exact single pass
         }
     }
 }
@@ -475,86 +688,147 @@ typedef void (*sdtw_fn)(const sdtw_kargs);
 template <int L, int FEED, int WHICH>
 sdtw_fn pick_r(int R)
 {
+#define SK_CASE(RR) case RR: return WHICH == 0 ? (sdtw_fn)k_sdtw_q<L, RR, FEED> : \
+                                   WHICH == 1 ? (sdtw_fn)k_sdtw_p<L, RR, FEED> : (sdtw_fn)k_sdtw_w<L, RR, FEED>;
     switch (R) {
-#define SK_CASE(RR) case RR: return WHICH == 0 ? (sdtw_fn)k_sdtw_q<L, RR, FEED> : (sdtw_fn)k_sdtw_w<L, RR, FEED>;
         SK_CASE(1) SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5) SK_CASE(6) SK_CASE(7) SK_CASE(8)
         SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16)
-#undef SK_CASE
     }
+    if constexpr (L != 64) {
+        switch (R) {
+            SK_CASE(17) SK_CASE(18) SK_CASE(19) SK_CASE(20) SK_CASE(21) SK_CASE(22) SK_CASE(23) SK_CASE(24)
+            SK_CASE(25) SK_CASE(26) SK_CASE(27) SK_CASE(28) SK_CASE(29) SK_CASE(30) SK_CASE(31) SK_CASE(32)
+        }
+    }
+#undef SK_CASE
     return nullptr;
 }
 
-template <int WHICH>
-sdtw_fn pick(int feed, int L, int R)
+template <int WHICH, int FEED>
+sdtw_fn pick_l(int L, int R)
 {
-    if (L == 16) {
-        if (feed == SK_FEED_I16) return pick_r<16, SK_FEED_I16, WHICH>(R);
-        if (feed == SK_FEED_F64_NORM) return pick_r<16, SK_FEED_F64_NORM, WHICH>(R);
-        return pick_r<16, SK_FEED_F64_RAW, WHICH>(R);
-    }
-    if (feed == SK_FEED_I16) return pick_r<64, SK_FEED_I16, WHICH>(R);
-    if (feed == SK_FEED_F64_NORM) return pick_r<64, SK_FEED_F64_NORM, WHICH>(R);
-    return pick_r<64, SK_FEED_F64_RAW, WHICH>(R);
+    if (L == 8)  return pick_r<8, FEED, WHICH>(R);
+    if (L == 16) return pick_r<16, FEED, WHICH>(R);
+    return pick_r<64, FEED, WHICH>(R);
 }
 
 } // namespace
 
+// (which: 0 = Q, 1 = P, 2 = W)
+#if SK_SDTWQ_FEED == 0
+void *sk_sdtwq_pick_feed0(int which, int L, int R)
+#elif SK_SDTWQ_FEED == 1
+void *sk_sdtwq_pick_feed1(int which, int L, int R)
+#else
+void *sk_sdtwq_pick_feed2(int which, int L, int R)
+#endif
+{
+    switch (which) {
+    case 0: return (void *)pick_l<0, SK_SDTWQ_FEED>(L, R);
+    case 1: return (void *)pick_l<1, SK_SDTWQ_FEED>(L, R);
+    default: return (void *)pick_l<2, SK_SDTWQ_FEED>(L, R);
+    }
+}
+
+#ifdef SK_SDTWQ_MAIN
+void *sk_sdtwq_pick_feed1(int which, int L, int R);
+void *sk_sdtwq_pick_feed2(int which, int L, int R);
+
+// lanes per read of the screening scheme for an N-point motif (SK_DTW_QL = 8 / 16 / 64: A/B runs)
+static void screen_layout(int N, int *L, int *R)
+{
+    int l = (N <= 8 * 32) ? 8 : (N <= 16 * 32) ? 16 : 64;
+    if (const char *e = getenv("SK_DTW_QL")) {
+        const int v = atoi(e);
+        if ((v == 8 && N <= 8 * 32) || (v == 16 && N <= 16 * 32) || v == 64) l = v;
+    }
+    *L = l;
+    *R = (N + l - 1) / l;
+}
+
 // Screening + certified window over all reads; fills out[] and the retry list (device).
-// The caller (sk_launch_sdtw) reads the retry count and runs the exact pass on those reads.
+// The caller (sk_launch_sdtw) runs the exact pass on the listed reads.
 // span / span2: look-back of the window pass's first tier (every read) and of its second tier (the reads whose
 // optimal path turned out wider than `span`); span2 <= span: one tier only.
-int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P, int ck, int span, int span2,
+int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, int span2,
                           int32_t *d_retry_cnt, int32_t *d_retry)
 {
     const int N = a->nmotif;
-    // quantised motif in the same per-lane layout as the exact one; resident like the exact layout (the caller
-    // invalidates it when the motif or its layout changes), so a call makes no host-side synchronisation
+    int L, R;
+    screen_layout(N, &L, &R);
+    const int P = L * R - N;
+    // quantised motif and the exact one in this scheme's per-lane layout (the exact kernels keep their own);
+    // resident like them (the caller invalidates when the motif changes), so a call makes no host-side synchronisation
     int rc;
-    if (!c->motifq_valid) {
+    if (!c->motifq_valid || c->motifq_L != L) {
         SK_HIP(hipStreamSynchronize(c->stream));        // an earlier launch may still read the old one
         std::vector<unsigned> &layq = c->motifq_host;
+        std::vector<double> &layw = c->motifw_host;
         layq.assign((size_t)L * R, 0x80000000u);
+        layw.assign((size_t)L * R, 0.0);
         int row = 0;
         for (int l = 0; l < L; l++) {
             const int cnt = (l < P) ? R - 1 : R;
-            for (int k = 0; k < cnt; k++)
-                layq[(size_t)l * R + k] = (unsigned)((int)rint(a->motif[row++] * QSCALE)) + 0x80000000u;
+            for (int k = 0; k < cnt; k++, row++) {
+                layq[(size_t)l * R + k] = (unsigned)((int)rint(a->motif[row] * QSCALE)) + 0x80000000u;
+                layw[(size_t)l * R + k] = a->motif[row];
+            }
         }
         if ((rc = sk_reserve(c, &c->motifq, layq.size() * sizeof(unsigned)))) return rc;
+        if ((rc = sk_reserve(c, &c->motifw, layw.size() * sizeof(double)))) return rc;
         SK_HIP(hipMemcpyAsync(c->motifq.p, layq.data(), layq.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+        SK_HIP(hipMemcpyAsync(c->motifw.p, layw.data(), layw.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
         c->motifq_valid = true;
+        c->motifq_L = L;
     }
 
     const int64_t maxlen = a->max_len;
     const int nck = (int)((maxlen + L - 1) / ck);
     const size_t lq_stride = (size_t)((maxlen + 3) & ~(int64_t)3);
-    const size_t per_read = (size_t)(nck > 0 ? nck : 1) * L * (R + 2) * sizeof(unsigned) +
-                            lq_stride * sizeof(unsigned) + sizeof(int32_t);
+    const size_t state_bytes = (size_t)L * (R + 2) * sizeof(unsigned);
+    const size_t per_read = (size_t)(nck > 0 ? nck : 1) * state_bytes + lq_stride * sizeof(unsigned) + state_bytes +
+                            (size_t)(nck + 1) * L * sizeof(unsigned) + 64;
     int64_t chunk;
     while (true) {                                      // (a device short of memory: halve the budget and try again)
         chunk = sk_dtw_chunk_reads(per_read, a->nreads);
-        rc = sk_reserve(c, &c->ckpt, (size_t)chunk * (size_t)(nck > 0 ? nck : 1) * L * (R + 2) * sizeof(unsigned));
+        rc = sk_reserve(c, &c->ckpt, (size_t)chunk * (size_t)(nck > 0 ? nck : 1) * state_bytes);
         if (!rc) rc = sk_reserve(c, &c->lastq, (size_t)chunk * lq_stride * sizeof(unsigned));
+        if (!rc) rc = sk_reserve(c, &c->wstate, (size_t)chunk * state_bytes);
+        if (!rc) rc = sk_reserve(c, &c->lsum, (size_t)chunk * (size_t)(nck + 1) * L * sizeof(unsigned));
         if (rc != SK_ERR_NOMEM || chunk <= 1024) break;
         sk_dtw_scratch_shrink(0);
     }
     if (rc) return rc;
     if ((rc = sk_reserve(c, &c->qflag, (size_t)chunk * sizeof(int32_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->wrec, (size_t)chunk * sizeof(wrec)))) return rc;
     const bool tiers = span2 > span;
     if (tiers && (rc = sk_reserve(c, &c->wsoft, ((size_t)chunk + 1) * sizeof(int32_t)))) return rc;
 
-    sdtw_fn fq = pick<0>(a->feed, L, R), fw = pick<1>(a->feed, L, R);
-    if (!fq || !fw) return sk_fail(SK_ERR_UNSUPPORTED, "no screening kernel for L=%d R=%d", L, R);
+    typedef void *(*pick_fn)(int, int, int);
+    const pick_fn pk = a->feed == SK_FEED_I16 ? (pick_fn)sk_sdtwq_pick_feed0
+                     : a->feed == SK_FEED_F64_NORM ? (pick_fn)sk_sdtwq_pick_feed1 : (pick_fn)sk_sdtwq_pick_feed2;
+    sdtw_fn fq = (sdtw_fn)pk(0, L, R), fp = (sdtw_fn)pk(1, L, R), fw = (sdtw_fn)pk(2, L, R);
+    if (!fq || !fp || !fw) return sk_fail(SK_ERR_UNSUPPORTED, "no screening kernel for L=%d R=%d", L, R);
 
     sdtw_kargs k;
     memset(&k, 0, sizeof k);
     k.samples = a->samples; k.stride = a->stride; k.off = a->off; k.prep = a->prep;
-    k.xlay = (const double *)c->motif.p; k.xlayq = (const unsigned *)c->motifq.p; k.P = P; k.out = a->out;
+    k.xlay = (const double *)c->motifw.p; k.xlayq = (const unsigned *)c->motifq.p; k.P = P; k.out = a->out;
     k.nck = nck; k.ck = ck; k.span = span; k.retry = d_retry; k.retry_cnt = d_retry_cnt;
     k.ckq = (unsigned *)c->ckpt.p; k.lastq = (unsigned *)c->lastq.p; k.lq_stride = (int64_t)lq_stride;
-    k.qflag = (int32_t *)c->qflag.p;
+    k.qflag = (int32_t *)c->qflag.p; k.lsum = (unsigned *)c->lsum.p;
+    k.wstate = (unsigned *)c->wstate.p; k.wrec = c->wrec.p;
     k.qerr = (unsigned)(N + maxlen + 2);
     k.wmax = 4 * ck;
+    if (const char *e = getenv("SK_DTW_FORCE_RETRY_PM")) {       // sensitivity runs: per-mille of reads sent to the retry
+        const int pm = atoi(e);
+        if (pm > 0) k.force_retry = pm >= 1000 ? 1024 : (pm * 1024 + 999) / 1000;
+    }
+
+    // filter + medmad fused into pass Q (the caller checked the limits: sk_sdtw_fuse_ok)
+    size_t fz_lds = 0;
+    const sk_prep_fuse fz = a->fuse ? *a->fuse : sk_prep_fuse();
+    if (a->fuse) fz_lds = (size_t)4 * (size_t)(((fz.hi - fz.lo - 1) + 3) & ~3) * sizeof(unsigned);
 
     const size_t nchunks = (size_t)((a->nreads + chunk - 1) / chunk);
     while (c->evpool.size() < 3 * nchunks) {
@@ -568,26 +842,36 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int L, int R, int P,
         k.read0 = (int)r0;
         k.nreads = (int)((a->nreads - r0 < chunk) ? a->nreads - r0 : chunk);
         const int grid = (k.nreads + reads_per_block - 1) / reads_per_block;
+        if (a->fuse) {
+            k.fz_raw = fz.raw; k.fz_len = fz.len; k.fz_lo = fz.lo; k.fz_hi = fz.hi;
+            k.fz_vec = ((((uintptr_t)fz.raw & 15) == 0 && (a->stride % 8) == 0) ? 1 : 0) |
+                       ((((uintptr_t)a->samples & 15) == 0 && (a->stride % 8) == 0) ? 2 : 0);
+        }
         hipEvent_t *ev = &c->evpool[3 * (size_t)c->prof_chunks];
         SK_HIP(hipEventRecord(ev[0], c->stream));
-        hipLaunchKernelGGL(fq, dim3(grid), dim3(256), 0, c->stream, k);
+        k.clk = (r0 == 0) ? (unsigned long long *)((char *)c->dtwcnt.p + 16) : nullptr;
+        hipLaunchKernelGGL(fq, dim3(grid), dim3(256), fz_lds, c->stream, k);
+        k.fz_raw = nullptr;                                 // (the later passes only read)
         SK_HIP(hipGetLastError());
         SK_HIP(hipEventRecord(ev[1], c->stream));
         if (tiers) {
             int32_t *soft = (int32_t *)c->wsoft.p;
             SK_HIP(hipMemsetAsync(soft, 0, sizeof(int32_t), c->stream));
             k.span = span; k.wl_list = nullptr; k.wl_count = nullptr; k.soft = soft + 1; k.soft_cnt = soft;
+            hipLaunchKernelGGL(fp, dim3(grid), dim3(256), 0, c->stream, k);
             hipLaunchKernelGGL(fw, dim3(grid), dim3(256), 0, c->stream, k);
             SK_HIP(hipGetLastError());
             k.span = span2; k.wl_list = soft + 1; k.wl_count = soft; k.soft = nullptr; k.soft_cnt = nullptr;
             k.total_ptr = (int32_t *)c->dtwcnt.p + 1;       // reads that needed the second tier (sk_last_dtw_tier2)
         }
+        hipLaunchKernelGGL(fp, dim3(grid), dim3(256), 0, c->stream, k);
+        k.total_ptr = nullptr;
         hipLaunchKernelGGL(fw, dim3(grid), dim3(256), 0, c->stream, k);
         SK_HIP(hipGetLastError());
-        k.total_ptr = nullptr;
         SK_HIP(hipEventRecord(ev[2], c->stream));
         c->prof_reads[c->prof_chunks < 64 ? c->prof_chunks : 63] = k.nreads;
         c->prof_chunks++;
     }
     return SK_OK;
 }
+#endif

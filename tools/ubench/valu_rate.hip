@@ -77,7 +77,7 @@
     X(35, "v_mul_f64",              BODY_D("v_mul_f64 ", ", ", ", %8\n"))
 #define NOPS 36
 
-struct Rec { unsigned long long cyc, real; unsigned hwid, xcc; };
+struct Rec { unsigned long long cyc, real, t0, t1; unsigned hwid, xcc; };
 
 template <int OP>
 __global__ __launch_bounds__(1024) void k(unsigned *out, Rec *rec, unsigned seed, int iters)
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(1024) void k(unsigned *out, Rec *rec, unsigned seed
     for (int i = 0; i < 8; i++) s += a[i] + (unsigned)d[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) {
-        Rec r; r.cyc = t1 - t0; r.real = r1 - r0;
+        Rec r; r.cyc = t1 - t0; r.real = r1 - r0; r.t0 = t0; r.t1 = t1;
         r.hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID: simd 5:4, cu 11:8, sh 12, se 15:13
         r.xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
         rec[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = r;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(1024) void kchain(unsigned *out, Rec *rec, unsigned
     for (int i = 0; i < CH; i++) s += a[i][0] + a[i][1];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) {
-        Rec r; r.cyc = t1 - t0; r.real = r1 - r0;
+        Rec r; r.cyc = t1 - t0; r.real = r1 - r0; r.t0 = t0; r.t1 = t1;
         r.hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID: simd 5:4, cu 11:8, sh 12, se 15:13
         r.xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
         rec[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = r;
@@ -155,7 +155,7 @@ template <int N, int... I> struct mk : mk<N - 1, N - 1, I...> {};
 template <int... I> struct mk<0, I...> { typedef seq<I...> type; };
 template <int... I> void fill(fn *f, seq<I...>) { fn t[] = {k<I>...}; memcpy(f, t, sizeof t); }
 
-struct Result { double cyc_per_instr, ghz_mem, ghz_wall, ms; int wmin, wmax; };
+struct Result { double cyc_per_instr, cyc_span, ghz_mem, ghz_wall, ms; int wmin, wmax; };
 
 // Placement is forced, not assumed: up to 4 waves per SIMD = ONE workgroup of 256 x wps threads per CU (96 KB of
 // dynamic LDS each, so two cannot share a CU); 6 or 8 = two workgroups of 128 x wps threads per CU (64 KB each, a third
@@ -177,7 +177,17 @@ static Result run(fn f, int cus, int wps, int iters, double instr_per_iter, unsi
     std::vector<Rec> h(nw);
     hipMemcpy(h.data(), rec, h.size() * sizeof(Rec), hipMemcpyDeviceToHost);
     std::map<unsigned, int> per_simd;
-    for (auto &r : h) per_simd[((r.xcc & 0xF) << 16) | (r.hwid & 0xFF30)]++;
+    std::map<unsigned, std::pair<unsigned long long, unsigned long long>> span;   // SIMD -> (first start, last end)
+    for (auto &r : h) {
+        const unsigned key = ((r.xcc & 0xF) << 16) | (r.hwid & 0xFF30);
+        per_simd[key]++;
+        auto it = span.find(key);
+        if (it == span.end()) span[key] = std::make_pair(r.t0, r.t1);
+        else { it->second.first = std::min(it->second.first, r.t0); it->second.second = std::max(it->second.second, r.t1); }
+    }
+    std::vector<double> spans;
+    for (auto &kv : span) spans.push_back((double)(kv.second.second - kv.second.first));
+    std::sort(spans.begin(), spans.end());
     int wmin = 1 << 30, wmax = 0;
     for (auto &kv : per_simd) { wmin = std::min(wmin, kv.second); wmax = std::max(wmax, kv.second); }
     std::vector<double> cyc, real;
@@ -187,6 +197,8 @@ static Result run(fn f, int cus, int wps, int iters, double instr_per_iter, unsi
     Result r;
     // a wave's loop lasted mc cycles, during which its SIMD issued the loops of all wps co-resident waves
     r.cyc_per_instr = mc / (wps * iters * instr_per_iter);
+    // the stagger-proof version: from the first start to the last end of the waves that shared a SIMD
+    r.cyc_span = spans[spans.size() / 2] / (wps * iters * instr_per_iter);
     r.ghz_mem = mc / (mr / 100e6) / 1e9;                   // s_memrealtime: constant 100 MHz
     r.ghz_wall = mc / (ms * 1e-3) / 1e9;                   // loop cycles / kernel wall time (launch + ramp included)
     r.ms = ms;
@@ -208,16 +220,18 @@ int main()
     unsigned *out; hipMalloc(&out, (size_t)cus * 2048 * 4);
     Rec *rec; hipMalloc(&rec, (size_t)cus * 32 * sizeof(Rec));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    printf("# %s, %d CUs.  cyc/ins = shader cycles per wave-instruction per SIMD = median over waves of (s_memtime ticks "
-           "of the wave's loop) / (waves per SIMD x instructions per wave).  64 instructions per loop body in ONE asm "
-           "statement (no s_nop inside, profiles/r03_valu_rate_disasm.txt), 8 independent chains.  clk = s_memtime ticks "
-           "per s_memrealtime second (100 MHz reference) while the loop ran.  waves/SIMD = fewest..most waves any of the "
-           "%d SIMDs hosted (from HW_ID / XCC_ID of every wave; 0 = some SIMD hosted none).\n", p.name, cus, cus * 4);
+    printf("# %s, %d CUs.  cyc/ins = shader cycles per wave-instruction per SIMD = median over SIMDs of (s_memtime from the "
+           "first loop start to the last loop end of the waves sharing the SIMD) / (waves per SIMD x instructions per "
+           "wave); (wave) = the same from one wave's own loop, which reads low because the waves of a SIMD start "
+           "staggered.  64 instructions per loop body in ONE asm statement (no s_nop inside, "
+           "profiles/r03_valu_rate_disasm.txt), 8 independent chains.  clk = s_memtime ticks per s_memrealtime second "
+           "(100 MHz reference) while the loop ran.  waves/SIMD = fewest..most waves any of the %d SIMDs hosted (from "
+           "HW_ID / XCC_ID of every wave; 0 = some SIMD hosted none).\n", p.name, cus, cus * 4);
     printf("# --- table 1: 4 waves per SIMD ---\n");
-    printf("%-28s %8s %8s %9s %10s\n", "op", "cyc/ins", "clk GHz", "wall ms", "waves/SIMD");
+    printf("%-28s %8s %8s %8s %9s %10s\n", "op", "cyc/ins", "(wave)", "clk GHz", "wall ms", "waves/SIMD");
     for (int op = 0; op < NOPS; op++) {
         Result r = run(fns[op], cus, 4, iters, 64.0, out, rec, e0, e1);
-        printf("%-28s %8.2f %8.3f %9.3f %7d..%d\n", names[op], r.cyc_per_instr, r.ghz_mem, r.ms, r.wmin, r.wmax);
+        printf("%-28s %8.2f %8.2f %8.3f %9.3f %7d..%d\n", names[op], r.cyc_span, r.cyc_per_instr, r.ghz_mem, r.ms, r.wmin, r.wmax);
     }
     const int ws[] = {1, 2, 3, 4, 6, 8};
     printf("# --- table 2: waves per SIMD sweep (cyc/ins) ---\n");
@@ -227,7 +241,7 @@ int main()
     printf("\n");
     for (int op : sweep_ops) {
         printf("%-28s", names[op]);
-        for (int w : ws) printf(" %6.2f", run(fns[op], cus, w, iters, 64.0, out, rec, e0, e1).cyc_per_instr);
+        for (int w : ws) printf(" %6.2f", run(fns[op], cus, w, iters, 64.0, out, rec, e0, e1).cyc_span);
         printf("\n");
     }
     printf("# --- table 3: the screening cell's dependent chain (min3 -> sad -> min3 -> ...), cyc/ins; 4.00 per "
@@ -235,9 +249,17 @@ int main()
     printf("%-28s", "chains per wave \\ waves");
     for (int w : ws) printf(" %6d", w);
     printf("\n%-28s", "1 column (as in k_sdtw_q)");
-    for (int w : ws) printf(" %6.2f", run(kchain<1>, cus, w, iters, 64.0, out, rec, e0, e1).cyc_per_instr);
+    for (int w : ws) printf(" %6.2f", run(kchain<1>, cus, w, iters, 64.0, out, rec, e0, e1).cyc_span);
     printf("\n%-28s", "2 interleaved columns");
-    for (int w : ws) printf(" %6.2f", run(kchain<2>, cus, w, iters, 128.0, out, rec, e0, e1).cyc_per_instr);
+    for (int w : ws) printf(" %6.2f", run(kchain<2>, cus, w, iters, 128.0, out, rec, e0, e1).cyc_span);
+    printf("\n# --- table 4: ten times longer loops (launch and ramp amortised): cyc/ins from the SIMD span, and from the "
+           "kernel's wall time x clk / instructions per SIMD ---\n");
+    const int long_ops[] = {0, 7, 4, 13, 14};
+    for (int op : long_ops) {
+        Result r = run(fns[op], cus, 4, iters * 10, 64.0, out, rec, e0, e1);
+        printf("%-28s span %5.2f   wave %5.2f   wall-derived %5.2f   clk %.3f GHz   wall %.3f ms\n", names[op], r.cyc_span,
+               r.cyc_per_instr, r.ms * 1e-3 * r.ghz_mem * 1e9 / (4.0 * iters * 10 * 64.0), r.ghz_mem, r.ms);
+    }
     printf("\n");
     return 0;
 }
