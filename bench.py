@@ -535,32 +535,45 @@ def motifseq_roofline(a, w, prof, steps, mean_n):
     if prof["launches"] > 0:
         # dominant kernel = the fixed-point screening pass k_sdtw_q<L,R,feed>; one launch per chunk
         per_step = prof["launches"] / steps
-        Lg, Rg = (16, (N + 15) // 16) if N <= 256 else (64, (N + 63) // 64)
-        dominant = "k_sdtw_q<%d,%d,0> (screening pass, %d launches per call)" % (Lg, Rg, per_step)
+        Lg = int(os.environ.get("SK_DTW_QL", 0)) or (8 if N <= 256 else 16 if N <= 512 else 64)   # sk_sdtwq.hip screen_layout
+        Rg = (N + Lg - 1) // Lg
+        dominant = "k_sdtw_q<%d,%d,0> (screening pass%s, %d launches per call)" % (
+            Lg, Rg, " with the filter + medmad prologue" if prep_ms < 0.05 else "", per_step)
         dom_ms = prof["dist_ms"] / prof["launches"]
         alg_bytes = alg_bytes / per_step                      # algorithmic bytes one launch covers
-        # its roof: 2 VALU instructions per cell (v_min3_u32 + v_sad_u32).  Nominal issue cost of a wave64 VALU
-        # op on a SIMD-32 is 2 cycles (MI355X_MICROARCH.md); these two measure 4.2-4.6 cycles each in isolation
-        # (profiles/r02_valu_rate.txt), which is what the "measured issue" roof uses.
+        # Its roof: 2 VALU instructions per cell, v_min3_u32 + v_sad_u32, 4 shader cycles of issue each on one SIMD
+        # (tools/ubench/valu_rate, profiles/r03_valu_rate.txt: cycles counted with s_memtime -- 4.30 at 4 waves per
+        # SIMD, 4.15 at 8; v_add_f32 / v_add_u32 / v_and / v_mov: 2.1; v_add_f64 4.1) => at most SIMDs x 64 lanes / 8
+        # cycles x clock cell-updates per second.  The clock is the one the pass ran at: its first wave counts shader
+        # cycles against the 100 MHz reference (sk_last_dtw_clock); the nominal 2.4 GHz figure is given beside it.
+        ghz = C.c_double(0.0)
+        w.L.sk_last_dtw_clock(C.byref(ghz))
+        clk = ghz.value if 0.5 < ghz.value < 3.0 else None
         q_ach = R * cells / (prof["dist_ms"] / steps * 1e-3)
+        step_ach = R * cells / ((prep_ms + main_ms) * 1e-3)
+        nominal = WAVE_ISSUE_SLOTS / 8.0                      # cell-updates/s at 2.4 GHz
+        at_clk = nominal * (clk / 2.4) if clk else None
         valu["screening_pass"] = {
             "bound": "valu_issue", "achieved": q_ach / 1e12, "unit": "T cell-updates/s",
-            "peak_at_measured_issue_cost": WAVE_ISSUE_SLOTS / 8.0 / 1e12,
-            "frac": q_ach / (WAVE_ISSUE_SLOTS / 8.0),
-            "peak_at_nominal_2_cycles": WAVE_ISSUE_SLOTS / 4.0 / 1e12,
-            "frac_of_nominal": q_ach / (WAVE_ISSUE_SLOTS / 4.0)}
-        step_ach = R * cells / ((prep_ms + main_ms) * 1e-3)
+            "issue_cycles_per_cell": 8, "measured_clock_ghz": clk,
+            "peak_at_measured_clock": at_clk / 1e12 if at_clk else None,
+            "frac": q_ach / at_clk if at_clk else None,
+            "peak_at_2.4_ghz": nominal / 1e12, "frac_at_2.4_ghz": q_ach / nominal,
+            "note": "the pass also carries the filter + medmad prologue of its reads" if prep_ms < 0.05 else None}
         valu["whole_step"] = {"bound": "valu_issue", "achieved": step_ach / 1e12, "unit": "T cell-updates/s",
-                              "peak": WAVE_ISSUE_SLOTS / 8.0 / 1e12, "frac": step_ach / (WAVE_ISSUE_SLOTS / 8.0),
-                              "note": "prep + screening + certified window + retries, against the screening "
-                                      "pass's own roof"}
+                              "peak_at_measured_clock": at_clk / 1e12 if at_clk else None,
+                              "frac": step_ach / at_clk if at_clk else None,
+                              "frac_at_2.4_ghz": step_ach / nominal,
+                              "note": "screening (+ prologue) + pre-roll + certified window + retries, against the "
+                                      "screening pass's own roof"}
         valu["passes_ms_per_call"] = {"prep": prep_ms, "screen": prof["dist_ms"] / steps,
                                       "window": prof["start_ms"] / steps,
-                                      "retried_reads": prof["retries"] / steps}
+                                      "retried_reads": prof["retries"] / steps,
+                                      "second_tier_reads": int(w.L.sk_last_dtw_tier2())}
     f64_roof = VALU_F64_LANEOPS / 4.0 / cells                 # reads/s of the reference's 4-f64-op cell at full rate
     valu["exact_f64_recurrence_roof_reads_per_s"] = f64_roof
     valu["speed_vs_exact_f64_roof"] = (R / ((prep_ms + main_ms) * 1e-3)) / f64_roof
-    valu["note"] = ("speed_vs_exact_f64_roof is a ratio, not a fraction of peak: 98 % of the cells are evaluated "
+    valu["note"] = ("speed_vs_exact_f64_roof is a ratio, not a fraction of peak: 95 % of the cells are evaluated "
                     "in 32-bit fixed point (2 integer ops), only the certified window in f64")
     per_read, src = traffic_from_profiles("motifseq", "k_sdtw_q")
     traffic = per_read * (alg_bytes / (2 * M + HIT_BYTES)) if per_read else None

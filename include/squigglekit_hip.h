@@ -230,6 +230,33 @@ int sk_tsv_parse_i16(const char *buf, size_t len, int32_t start_col, int64_t nli
                      int32_t *nsamp, int64_t *name_off, int32_t *name_len, int64_t *id_off, int32_t *id_len,
                      int32_t *flags, int64_t *line_off, int32_t nthreads);
 
+/* ---- result tables as text / BLOW5 ingest (host code; no GPU needed) ------ */
+/* The rows the command-line tools print (MotifSeq.py:446-449: 12 tab-separated columns per hit; segmenter.py:222-227:
+ * name <TAB> s0,e0,s1,e1...) formatted on all cores: columns of strings, int32, float64 -- floats exactly as Python's
+ * "{}".format(float) / repr() writes them -- or comma-joined int32 lists.  Rows with skip[i] != 0 are left out.
+ * Returns a malloc'ed buffer of *out_len bytes (free with sk_fmt_free), NULL on failure. */
+enum { SK_FMT_STR = 0, SK_FMT_I32 = 1, SK_FMT_F64 = 2, SK_FMT_CONST = 3, SK_FMT_I32LIST = 4, SK_FMT_STRSPAN = 5 };
+typedef struct sk_fmt_col {
+    int32_t        kind;     /* SK_FMT_*                                                                    */
+    const void    *data;     /* STR / CONST: bytes; I32 / I32LIST: int32[]; F64: double[]                   */
+    const int64_t *off;      /* STR / I32LIST: nrows + 1 offsets into data; CONST: off[0..1]; STRSPAN: [nrows][2]
+                                = first / one-past-last byte of row i's string in data; else unused         */
+} sk_fmt_col;
+void *sk_fmt_rows(int64_t nrows, int32_t ncols, const sk_fmt_col *cols, const uint8_t *skip, int32_t nthreads,
+                  int64_t *out_len);
+void  sk_fmt_free(void *p);
+
+/* BLOW5 (binary SLOW5: what the reference reads through pyslow5, segmenter.py:321-396, dRNA_segmenter.py:85-100).
+ * sk_blow5_index walks the records of a file image from byte `first` (just behind the ASCII header): payload offset
+ * and size of up to `cap` records; returns the number of records in the file (call with cap = 0 to count).
+ * sk_blow5_rows_i16 decodes records (comp: 0 = stored, 1 = zlib) into int16 rows of `stride` samples on all cores:
+ * nsamp[i] samples, ids[i * id_width ..] the read id (NUL padded; NULL to skip), calib[3 i ..] = digitisation, offset,
+ * range (NULL to skip); flags[i]: 1 = longer than a row (truncated to stride), 2 = unreadable record, 4 = id cut. */
+int64_t sk_blow5_index(const void *buf, int64_t len, int64_t first, int64_t *rec_off, int64_t *rec_size, int64_t cap);
+int sk_blow5_rows_i16(const void *buf, const int64_t *rec_off, const int64_t *rec_size, int64_t nrec, int32_t comp,
+                      int64_t stride, int16_t *rows, int32_t *nsamp, char *ids, int32_t id_width, double *calib,
+                      int32_t *flags, int32_t nthreads);
+
 /* ---- multi-GPU: the final gather of result records (RCCL over xGMI) ------ */
 /* The reference's per-read loops (segmenter.py:189-230, MotifSeq.py:261-298) carry no state from one read
  * to the next, so N GPUs take contiguous blocks of the reads with no data-path collective; the one exchange

@@ -130,6 +130,11 @@ ABI = {
                                C.c_int32]),
     "sk_tsv_parse_i16": (C.c_int, [_vp, C.c_size_t, C.c_int32, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, C.c_int32]),
+    "sk_fmt_rows": (_vp, [C.c_int64, C.c_int32, _vp, _vp, C.c_int32, _i64p]),
+    "sk_fmt_free": (None, [_vp]),
+    "sk_blow5_index": (C.c_int64, [_vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int64]),
+    "sk_blow5_rows_i16": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int32, C.c_int64, _vp, _vp, _vp, C.c_int32, _vp, _vp,
+                                    C.c_int32]),
     "sk_comm_unique_id": (C.c_int, [_vp]),
     "sk_comm_init_rank": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sk_comm_init_all": (C.c_int, [_i32p, C.c_int]),
@@ -196,6 +201,25 @@ def init(device=None, slot=None):
         check(L.sk_init_slot(int(slot), int(device)))
     _tls.device = int(device)
     return _tls.device
+
+
+def warm_start(device=None, also=()):
+    """Start binding the GPU on a background thread (the HIP runtime's start-up costs a few hundred milliseconds that a
+    command-line tool can spend parsing its first chunk of input) and import the modules named in `also` there too.
+    Every thread binds for itself later (init / ensure_init), by then at no cost.  Returns the thread."""
+    if device is not None:
+        os.environ["SK_DEVICE"] = str(int(device))
+
+    def run():
+        try:
+            init(device)
+            for mod in also:
+                __import__(mod)
+        except Exception:                                            # noqa: BLE001 -- the foreground call reports it
+            pass
+    t = threading.Thread(target=run, name="sk-warm", daemon=True)
+    t.start()
+    return t
 
 
 def ensure_init():

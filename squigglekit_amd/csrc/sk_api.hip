@@ -238,21 +238,48 @@ int sk_motifseq_multi_batch_i16(const int16_t *sig, int64_t stride, const int32_
     if ((rc = sk_reserve(c, &c->comp, sb))) return rc;
     if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
     if ((rc = sk_reserve(c, &c->out, ob))) return rc;
-    SK_HIP(hipMemcpyAsync(c->sig.p, sig, sb, hipMemcpyHostToDevice, c->stream));
-    SK_HIP(hipMemcpyAsync(c->len.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    SK_HIP(hipEventRecord(c->ev[0], c->stream));
-    rc = sk_launch_prep_i16(c, (const int16_t *)c->sig.p, stride, (const int32_t *)c->len.p, nreads, scale_low,
-                            scale_hi, scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE, 0.0,
-                            (int16_t *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
-    if (rc) return rc;
-    SK_HIP(hipEventRecord(c->ev[1], c->stream));
-    for (int32_t k = 0; k < nmotifs; k++) {
-        sk_sdtw_args a;
-        a.feed = SK_FEED_I16; a.samples = c->comp.p; a.stride = stride; a.off = nullptr;
-        a.prep = (const sk_prep *)c->prep.p; a.nreads = nreads; a.motif = motifs + motif_off[k];
-        a.nmotif = motif_off[k + 1] - motif_off[k]; a.out = (sk_hit *)c->out.p + (size_t)k * nreads;
-        a.last_row = nullptr; a.max_len = stride; a.force_single = 0;
-        if ((rc = sk_launch_sdtw(c, &a))) return rc;
+    // sub-batches as in sk_motifseq_batch_i16: the H2D copy of one runs on the second stream under the kernels of the
+    // previous one; filter + statistics once per sub-batch (as the prologue of the first motif's screening pass when
+    // that applies), then one DTW launch set per motif
+    const bool fuse = scale_mode == SK_SCALE_MEDMAD && sk_sdtw_fuse_ok(scale_low, scale_hi);
+    const SubBatches B = sub_batches(nreads, stride);
+    if (B.n > 1 && (rc = second_stream(c))) return rc;
+    for (int32_t bi = 0; bi < B.n; bi++) {
+        const int32_t r0 = bi * B.per;
+        const int32_t nr = (nreads - r0 < B.per) ? nreads - r0 : B.per;
+        if (nr <= 0) break;
+        int16_t *d_sig = (int16_t *)c->sig.p + (size_t)r0 * (size_t)stride;
+        int16_t *d_comp = (int16_t *)c->comp.p + (size_t)r0 * (size_t)stride;
+        int32_t *d_len = (int32_t *)c->len.p + r0;
+        sk_prep *d_prep = (sk_prep *)c->prep.p + r0;
+        hipStream_t cs = (B.n > 1) ? c->stream2 : c->stream;
+        SK_HIP(hipMemcpyAsync(d_sig, sig + (size_t)r0 * (size_t)stride, (size_t)nr * (size_t)stride * sizeof(int16_t),
+                              hipMemcpyHostToDevice, cs));
+        SK_HIP(hipMemcpyAsync(d_len, len + r0, (size_t)nr * sizeof(int32_t), hipMemcpyHostToDevice, cs));
+        if (B.n > 1) {                                      // the kernels of this sub-batch wait for its copy only
+            SK_HIP(hipEventRecord(c->ev_chunk[bi & 7], cs));
+            SK_HIP(hipStreamWaitEvent(c->stream, c->ev_chunk[bi & 7], 0));
+        }
+        sk_prep_fuse fz;
+        fz.raw = d_sig; fz.len = d_len; fz.lo = scale_low; fz.hi = scale_hi;
+        SK_HIP(hipEventRecord(c->ev[0], c->stream));
+        if (!fuse) {
+            rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nr, scale_low, scale_hi,
+                                    scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE, 0.0, d_comp, d_prep,
+                                    nullptr, 0);
+            if (rc) return rc;
+        }
+        SK_HIP(hipEventRecord(c->ev[1], c->stream));
+        for (int32_t k = 0; k < nmotifs; k++) {
+            sk_sdtw_args a;
+            a.feed = SK_FEED_I16; a.samples = d_comp; a.stride = stride; a.off = nullptr;
+            a.prep = d_prep; a.nreads = nr; a.motif = motifs + motif_off[k];
+            a.nmotif = motif_off[k + 1] - motif_off[k]; a.out = (sk_hit *)c->out.p + (size_t)k * nreads + r0;
+            a.last_row = nullptr; a.max_len = stride; a.force_single = 0;
+            a.accumulate = (bi > 0 || k > 0) ? 1 : 0;
+            a.fuse = (fuse && k == 0) ? &fz : nullptr;      // (the later motifs find the samples / statistics in place)
+            if ((rc = sk_launch_sdtw(c, &a))) return rc;
+        }
     }
     c->ev_valid = true;
     SK_HIP(hipMemcpyAsync(out, c->out.p, ob, hipMemcpyDeviceToHost, c->stream));

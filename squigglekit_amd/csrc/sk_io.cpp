@@ -1,0 +1,246 @@
+// sk_io.cpp -- host-side I/O helpers of the drop-in command-line tools (no GPU involved):
+//   * sk_fmt_rows        the result tables as text, with Python's own float formatting, on all cores --
+//                        what `print("\t".join("{}".format(v) ...))` (MotifSeq.py:446-449, segmenter.py:222-227)
+//                        produces one row at a time;
+//   * sk_blow5_index /   BLOW5 records (slow5lib's binary SLOW5; the reference reads it through pyslow5,
+//     sk_blow5_rows_i16  segmenter.py:321-396, dRNA_segmenter.py:85-100) straight into int16 rows.
+// Both exist because the kernels handle millions of reads per second and a Python loop per read handles
+// a few hundred thousand.
+#include "squigglekit_hip.h"
+#include <charconv>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <thread>
+#include <vector>
+#include <zlib.h>
+
+namespace {
+
+// repr(float) of CPython (float_repr_style "short": shortest digits that round-trip, fixed notation when
+// -4 < decpt <= 16, else d.ddde[+-]XX; always a ".0" on integral fixed values)
+inline void put_pyfloat(std::string &o, double v)
+{
+    if (v != v) { o += "nan"; return; }
+    if (v == HUGE_VAL) { o += "inf"; return; }
+    if (v == -HUGE_VAL) { o += "-inf"; return; }
+    char b[40];
+    const auto r = std::to_chars(b, b + sizeof b, v, std::chars_format::scientific);   // [-]d[.ddd]e[+-]XX, shortest
+    const char *p = b, *end = r.ptr;
+    if (*p == '-') { o += '-'; p++; }
+    char dig[24];
+    int nd = 0;
+    const char *e = p;
+    while (e < end && *e != 'e') { if (*e != '.') dig[nd++] = *e; e++; }
+    int ex = 0;
+    {
+        const char *q = e + 1;
+        const bool neg = (*q == '-');
+        if (*q == '+' || *q == '-') q++;
+        while (q < end) ex = ex * 10 + (*q++ - '0');
+        if (neg) ex = -ex;
+    }
+    if (nd == 1 && dig[0] == '0') { o += "0.0"; return; }
+    const int decpt = ex + 1;                               // value = 0.d1d2... x 10^decpt
+    if (decpt > -4 && decpt <= 16) {
+        if (decpt <= 0) {
+            o += "0.";
+            o.append((size_t)(-decpt), '0');
+            o.append(dig, (size_t)nd);
+        } else if (decpt >= nd) {
+            o.append(dig, (size_t)nd);
+            o.append((size_t)(decpt - nd), '0');
+            o += ".0";
+        } else {
+            o.append(dig, (size_t)decpt);
+            o += '.';
+            o.append(dig + decpt, (size_t)(nd - decpt));
+        }
+    } else {
+        o += dig[0];
+        if (nd > 1) { o += '.'; o.append(dig + 1, (size_t)(nd - 1)); }
+        o += 'e';
+        int x = decpt - 1;
+        o += (x < 0) ? '-' : '+';
+        if (x < 0) x = -x;
+        char t[8];
+        int nt = 0;
+        do { t[nt++] = (char)('0' + x % 10); x /= 10; } while (x);
+        if (nt < 2) t[nt++] = '0';
+        while (nt) o += t[--nt];
+    }
+}
+
+inline void put_int(std::string &o, long long v)
+{
+    char b[24];
+    const auto r = std::to_chars(b, b + sizeof b, v);
+    o.append(b, (size_t)(r.ptr - b));
+}
+
+int clamp_threads(int nthreads, int64_t items, int64_t per_thread_min)
+{
+    int t = nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency();
+    if (t < 1) t = 1;
+    if (t > 64) t = 64;
+    const int64_t cap = items / (per_thread_min > 0 ? per_thread_min : 1);
+    if (cap < t) t = cap < 1 ? 1 : (int)cap;
+    return t;
+}
+
+} // namespace
+
+extern "C" {
+
+void *sk_fmt_rows(int64_t nrows, int32_t ncols, const sk_fmt_col *cols, const uint8_t *skip, int32_t nthreads,
+                  int64_t *out_len)
+{
+    if (out_len) *out_len = 0;
+    if (nrows < 0 || ncols <= 0 || !cols || !out_len) return nullptr;
+    const int T = clamp_threads(nthreads, nrows, 2048);
+    std::vector<std::string> parts((size_t)T);
+    auto work = [&](int t) {
+        const int64_t lo = nrows * t / T, hi = nrows * (t + 1) / T;
+        std::string &o = parts[(size_t)t];
+        o.reserve((size_t)(hi - lo) * 96);
+        for (int64_t i = lo; i < hi; i++) {
+            if (skip && skip[i]) continue;
+            for (int32_t c = 0; c < ncols; c++) {
+                const sk_fmt_col &k = cols[c];
+                if (c) o += '\t';
+                switch (k.kind) {
+                case SK_FMT_STR: {
+                    const char *s = (const char *)k.data;
+                    o.append(s + k.off[i], (size_t)(k.off[i + 1] - k.off[i]));
+                    break;
+                }
+                case SK_FMT_STRSPAN: {
+                    const char *s = (const char *)k.data;
+                    o.append(s + k.off[2 * i], (size_t)(k.off[2 * i + 1] - k.off[2 * i]));
+                    break;
+                }
+                case SK_FMT_CONST: {
+                    const char *s = (const char *)k.data;
+                    o.append(s + k.off[0], (size_t)(k.off[1] - k.off[0]));
+                    break;
+                }
+                case SK_FMT_I32: put_int(o, ((const int32_t *)k.data)[i]); break;
+                case SK_FMT_F64: put_pyfloat(o, ((const double *)k.data)[i]); break;
+                case SK_FMT_I32LIST: {
+                    const int32_t *v = (const int32_t *)k.data;
+                    for (int64_t j = k.off[i]; j < k.off[i + 1]; j++) {
+                        if (j > k.off[i]) o += ',';
+                        put_int(o, v[j]);
+                    }
+                    break;
+                }
+                default: break;
+                }
+            }
+            o += '\n';
+        }
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    size_t total = 0;
+    for (auto &p : parts) total += p.size();
+    char *out = (char *)malloc(total ? total : 1);
+    if (!out) return nullptr;
+    size_t at = 0;
+    for (auto &p : parts) { memcpy(out + at, p.data(), p.size()); at += p.size(); }
+    *out_len = (int64_t)total;
+    return out;
+}
+
+void sk_fmt_free(void *p) { free(p); }
+
+// ---- BLOW5 ------------------------------------------------------------------------------------------------
+// File: "BLOW5\1" magic, version (3 bytes), record compression (0 none, 1 zlib), [signal compression, >= 0.2.0],
+// padding to 64 bytes, uint32 ASCII-header length, ASCII header, then records: uint64 size | payload, payload =
+// uint16 idlen | id | uint32 read_group | f64 digitisation | f64 offset | f64 range | f64 sampling_rate |
+// uint64 n | int16[n] | aux fields; the file ends with "5WOLB".
+
+int64_t sk_blow5_index(const void *buf_, int64_t len, int64_t first, int64_t *rec_off, int64_t *rec_size, int64_t cap)
+{
+    const unsigned char *buf = (const unsigned char *)buf_;
+    if (!buf || len < 0 || first < 0) return SK_ERR_INVALID;
+    int64_t pos = first, n = 0;
+    while (pos + 8 <= len) {
+        if (pos + 5 <= len && memcmp(buf + pos, "5WOLB", 5) == 0) break;
+        uint64_t size;
+        memcpy(&size, buf + pos, 8);
+        pos += 8;
+        if (size > (uint64_t)(len - pos)) return SK_ERR_INVALID;          // truncated file
+        if (rec_off && n < cap) { rec_off[n] = pos; rec_size[n] = (int64_t)size; }
+        n++;
+        pos += (int64_t)size;
+    }
+    return n;
+}
+
+int sk_blow5_rows_i16(const void *buf_, const int64_t *rec_off, const int64_t *rec_size, int64_t nrec, int32_t comp,
+                      int64_t stride, int16_t *rows, int32_t *nsamp, char *ids, int32_t id_width, double *calib,
+                      int32_t *flags, int32_t nthreads)
+{
+    const unsigned char *buf = (const unsigned char *)buf_;
+    if (!buf || !rec_off || !rec_size || nrec < 0 || stride <= 0 || !rows || !nsamp || !flags || (comp != 0 && comp != 1))
+        return SK_ERR_INVALID;
+    const int T = clamp_threads(nthreads, nrec, 256);
+    auto work = [&](int t) {
+        std::vector<unsigned char> tmp;
+        const int64_t lo = nrec * t / T, hi = nrec * (t + 1) / T;
+        for (int64_t i = lo; i < hi; i++) {
+            flags[i] = 0; nsamp[i] = 0;
+            const unsigned char *p = buf + rec_off[i];
+            size_t sz = (size_t)rec_size[i];
+            if (comp == 1) {
+                size_t cap = sz * 4 + 4096;
+                int zr = Z_BUF_ERROR;
+                for (int tries = 0; tries < 8 && zr == Z_BUF_ERROR; tries++, cap *= 2) {
+                    tmp.resize(cap);
+                    uLongf dl = (uLongf)cap;
+                    zr = uncompress(tmp.data(), &dl, p, (uLong)sz);
+                    if (zr == Z_OK) sz = (size_t)dl;
+                }
+                if (zr != Z_OK) { flags[i] = 2; continue; }
+                p = tmp.data();
+            }
+            if (sz < 2) { flags[i] = 2; continue; }
+            uint16_t idlen;
+            memcpy(&idlen, p, 2);
+            const size_t fixed = 2 + (size_t)idlen + 4 + 32 + 8;
+            if (sz < fixed) { flags[i] = 2; continue; }
+            if (ids && id_width > 0) {
+                char *d = ids + (size_t)i * (size_t)id_width;
+                size_t n = idlen;
+                while (n > 0 && p[2 + n - 1] == 0) n--;                       // (ids are NUL-padded in some writers)
+                if (n > (size_t)id_width) { n = (size_t)id_width; flags[i] |= 4; }
+                memcpy(d, p + 2, n);
+                if (n < (size_t)id_width) memset(d + n, 0, (size_t)id_width - n);
+            }
+            const unsigned char *q = p + 2 + idlen + 4;
+            if (calib) memcpy(calib + 3 * i, q, 24);                         // digitisation, offset, range
+            uint64_t n;
+            memcpy(&n, q + 32, 8);
+            if (n > (sz - fixed) / 2) { flags[i] = 2; continue; }
+            nsamp[i] = n > 0x7fffffffull ? 0x7fffffff : (int32_t)n;
+            if (n > (uint64_t)stride) { flags[i] |= 1; n = (uint64_t)stride; }   // longer than a row: caller's slow path
+            memcpy(rows + (size_t)i * (size_t)stride, q + 40, (size_t)n * 2);
+        }
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    return SK_OK;
+}
+
+} // extern "C"

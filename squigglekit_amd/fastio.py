@@ -1,0 +1,182 @@
+"""Host-side fast paths of the command-line tools (csrc/sk_io.cpp; no GPU involved): result tables formatted
+natively with Python's own float formatting, and BLOW5 records decoded straight into int16 rows.
+
+The reference prints one row per read with `"\\t".join("{}".format(v) ...)` (MotifSeq.py:446-449,
+segmenter.py:222-227) and reads BLOW5 through pyslow5 one record at a time (segmenter.py:321-396); at a few
+microseconds of interpreter time per read neither keeps up with kernels that finish millions of reads per second.
+"""
+import ctypes as C
+import mmap
+import os
+import struct
+
+import numpy as np
+
+from . import _lib
+
+STR, I32, F64, CONST, I32LIST, STRSPAN = 0, 1, 2, 3, 4, 5
+
+
+class _Col(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("data", C.c_void_p), ("off", C.c_void_p)]
+
+
+def _addr(buf):
+    """Address of a bytes / mmap / numpy buffer (no copy)."""
+    if isinstance(buf, np.ndarray):
+        return buf.ctypes.data
+    if isinstance(buf, bytes):
+        return C.cast(C.c_char_p(buf), C.c_void_p).value
+    return np.frombuffer(buf, dtype=np.uint8).ctypes.data
+
+
+def fmt_rows(nrows, cols, skip=None, nthreads=0):
+    """The table as bytes: one line per row, columns joined by tabs.  cols: list of
+         ("str", blob, off)        strings blob[off[i]:off[i+1]]             (off: int64[nrows + 1])
+         ("span", buf, spans)      strings buf[spans[i,0]:spans[i,1]]        (spans: int64[nrows, 2]; buf bytes / mmap)
+         ("const", bytes)          the same string in every row
+         ("i32", int32[nrows])     ("f64", float64[nrows])  -- floats as Python's repr() writes them
+         ("i32list", values, off)  comma-joined int32 values[off[i]:off[i+1]]
+    skip: optional uint8[nrows], rows with a non-zero entry are left out."""
+    L = _lib.load()
+    arr = (_Col * len(cols))()
+    keep = []
+    for k, c in enumerate(cols):
+        kind = c[0]
+        if kind == "str":
+            off = np.ascontiguousarray(c[2], dtype=np.int64)
+            keep += [c[1], off]
+            arr[k] = _Col(STR, _addr(c[1]), off.ctypes.data)
+        elif kind == "span":
+            sp = np.ascontiguousarray(c[2], dtype=np.int64)
+            keep += [c[1], sp]
+            arr[k] = _Col(STRSPAN, _addr(c[1]), sp.ctypes.data)
+        elif kind == "const":
+            off = np.array([0, len(c[1])], dtype=np.int64)
+            keep += [c[1], off]
+            arr[k] = _Col(CONST, _addr(c[1]), off.ctypes.data)
+        elif kind == "i32":
+            a = np.ascontiguousarray(c[1], dtype=np.int32)
+            keep.append(a)
+            arr[k] = _Col(I32, a.ctypes.data, None)
+        elif kind == "f64":
+            a = np.ascontiguousarray(c[1], dtype=np.float64)
+            keep.append(a)
+            arr[k] = _Col(F64, a.ctypes.data, None)
+        elif kind == "i32list":
+            a = np.ascontiguousarray(c[1], dtype=np.int32)
+            off = np.ascontiguousarray(c[2], dtype=np.int64)
+            keep += [a, off]
+            arr[k] = _Col(I32LIST, a.ctypes.data, off.ctypes.data)
+        else:
+            raise ValueError("unknown column kind %r" % (kind,))
+    sk = None
+    if skip is not None:
+        sk = np.ascontiguousarray(skip, dtype=np.uint8)
+        keep.append(sk)
+    n = C.c_int64(0)
+    p = L.sk_fmt_rows(int(nrows), len(cols), C.cast(arr, C.c_void_p), None if sk is None else sk.ctypes.data,
+                      int(nthreads), C.byref(n))
+    if not p:
+        raise MemoryError("sk_fmt_rows failed")
+    try:
+        return C.string_at(p, n.value)
+    finally:
+        L.sk_fmt_free(p)
+
+
+def write_stdout(text):
+    """Bytes to stdout behind whatever print() already queued (a redirected / captured stdout may be a text-only
+    stream without a byte layer)."""
+    import sys
+    sys.stdout.flush()
+    raw = getattr(sys.stdout, "buffer", None)
+    if raw is not None:
+        raw.write(text)
+    else:
+        sys.stdout.write(text.decode())
+
+
+# ------------------------------------------------------------------------------------------------
+# BLOW5
+# ------------------------------------------------------------------------------------------------
+class Blow5Block:
+    """A run of decoded records: rows int16 [n, stride] (nsamp[i] samples each), ids (numpy 'S' array), calib [n, 3]
+    = digitisation, offset, range; flags[i] & 1: read longer than a row (truncated), & 2: unreadable record."""
+
+    def __init__(self, rows, nsamp, ids, calib, flags):
+        self.rows, self.nsamp, self.ids, self.calib, self.flags = rows, nsamp, ids, calib, flags
+        self.n = len(nsamp)
+
+
+def blow5_open(path):
+    """(mmap, record compression, offset of the first record)."""
+    fh = open(path, "rb")
+    mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+    fh.close()
+    if mm[:6] != b"BLOW5\x01":
+        raise ValueError("not a BLOW5 file: %s" % path)
+    major, minor, _patch, comp = struct.unpack_from("<BBBB", mm, 6)
+    if comp not in (0, 1):
+        raise ValueError("unsupported BLOW5 record compression %d (only none / zlib)" % comp)
+    if (major, minor) >= (0, 2) and mm[10] != 0:
+        raise ValueError("unsupported BLOW5 signal compression %d" % mm[10])
+    (hlen,) = struct.unpack_from("<I", mm, 64)
+    return mm, comp, 68 + hlen
+
+
+def iter_blow5_blocks_i16(path, block_reads=131072, id_width=64, nthreads=0):
+    """Stream a BLOW5 file as Blow5Block chunks (csrc/sk_io.cpp): the records of a chunk are decoded on all cores
+    straight into int16 rows whose stride fits the chunk's longest read."""
+    L = _lib.load()
+    mm, comp, first = blow5_open(path)
+    base = _addr(mm)
+    nrec = L.sk_blow5_index(base, len(mm), first, None, None, 0)
+    if nrec < 0:
+        raise ValueError("truncated BLOW5 file: %s" % path)
+    off = np.zeros(max(1, nrec), dtype=np.int64)
+    size = np.zeros(max(1, nrec), dtype=np.int64)
+    L.sk_blow5_index(base, len(mm), first, off.ctypes.data, size.ctypes.data, nrec)
+    for lo in range(0, nrec, block_reads):
+        hi = min(nrec, lo + block_reads)
+        n = hi - lo
+        # stored records: the signal is all of the payload but ~60 bytes of fixed fields, the id and aux data, so
+        # size / 2 bounds the sample count; zlib: start from the compressed size and grow if a read does not fit
+        guess = int(size[lo:hi].max()) // 2 if comp == 0 else int(size[lo:hi].max()) * 2
+        stride = max(8, (guess + 7) // 8 * 8)
+        while True:
+            rows = np.empty((n, stride), dtype=np.int16)
+            nsamp = np.zeros(n, dtype=np.int32)
+            ids = np.zeros(n, dtype="S%d" % id_width)
+            calib = np.zeros((n, 3), dtype=np.float64)
+            flags = np.zeros(n, dtype=np.int32)
+            _lib.check(L.sk_blow5_rows_i16(base, off[lo:hi].ctypes.data, size[lo:hi].ctypes.data, n, comp, stride,
+                                           rows.ctypes.data, nsamp.ctypes.data, ids.ctypes.data, id_width,
+                                           calib.ctypes.data, flags.ctypes.data, int(nthreads)))
+            if comp == 1 and np.any(flags & 1) and stride < (1 << 24):
+                stride = (int(nsamp.max()) + 7) // 8 * 8          # (nsamp holds the true lengths)
+                continue
+            break
+        yield Blow5Block(rows, nsamp, ids, calib, flags)
+
+
+def write_blow5(path, reads, read_ids=None, compress=False):
+    """A minimal BLOW5 0.2.0 file (tools / tests): `reads` = int16 arrays (or a 2-D array), stored or zlib records."""
+    import zlib
+    hdr = b"#slow5_version\t0.2.0\n#num_read_groups\t1\n@asic_id\t0\n#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\t" \
+          b"uint64_t\tint16_t*\n#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\t" \
+          b"raw_signal\n"
+    with open(path, "wb") as fh:
+        head = b"BLOW5\x01" + bytes([0, 2, 0, 1 if compress else 0, 0])
+        fh.write(head + b"\0" * (64 - len(head)))
+        fh.write(struct.pack("<I", len(hdr)) + hdr)
+        for i, sig in enumerate(reads):
+            sig = np.ascontiguousarray(sig, dtype="<i2")
+            rid = (read_ids[i] if read_ids is not None else "read%d" % i).encode()
+            rec = struct.pack("<H", len(rid)) + rid + struct.pack("<IddddQ", 0, 8192.0, 10.0, 1400.0, 4000.0, sig.size) \
+                + sig.tobytes()
+            if compress:
+                rec = zlib.compress(rec, 1)
+            fh.write(struct.pack("<Q", len(rec)) + rec)
+        fh.write(b"5WOLB")
+    return path

@@ -5,7 +5,9 @@ scale_outliers + medmad/zscale + dtw_subsequence run on the GPU (batched, C ABI)
 the scoring of MotifSeq.py:441-445 stays in Python so the printed floats are the
 reference's digit for digit.  fast5 input (-f / -p) goes through h5py when it is importable and
 through the built-in reader (hdf5min.py) otherwise, with the reference's stderr messages.
-Additive flags: --device, --gpus, --batch, --after_stall, --strict-compat.
+Additive flags: --device, --gpus, --batch, --after_stall, --strict-compat, --blow5, --i16.
+Whole chunks of plain integer reads (TSV chunks, BLOW5 / packed blocks) go to the GPU as one batch and their rows are
+formatted natively (csrc/sk_io.cpp writes floats as Python does); anything unusual takes the per-read route.
 """
 import argparse
 import os
@@ -13,7 +15,7 @@ import sys
 
 import numpy as np
 
-from . import api, tsvio
+from . import api, fastio, tsvio
 
 VERSION = "1.3.0"          # the reference's MotifSeq version string (MotifSeq.py:84)
 HEADER = ["fast5", "readID", "model", "start", "end", "length", "distance_score", "model_mean",
@@ -39,6 +41,9 @@ def build_parser():
     src.add_argument("-f", "--f5f", help="text file listing fast5 paths")
     src.add_argument("-p", "--f5_path", help="directory searched recursively for fast5 files")
     src.add_argument("-s", "--signal", help="signal TSV written by SquigglePull (.gz accepted)")
+    src.add_argument("--blow5", help="[extension] BLOW5 file (stored or zlib records): raw ADC values, decoded natively")
+    src.add_argument("--i16", help="[extension] packed reads: a .npy file holding an int16 array [reads, samples] "
+                                   "(readID = row index)")
     p.add_argument("-l", "--scale", default="medmad", choices=["zscale", "medmad"],
                    help="per-read normalisation applied before the search")
     mod.add_argument("-i", "--fasta_input", help="fasta of motifs, turned into squiggles with scrappy")
@@ -173,6 +178,57 @@ class _Batcher:
                 row.append(cut)
             print("\t".join("{}".format(v) for v in row))
 
+    def table(self, n, fast5_col, id_col, hits):
+        """The rows of n reads x every motif through the native formatter (file order, read-major).  Returns False --
+        nothing written -- when some read needs the general route (-x, a flagged read)."""
+        a = self.args
+        K = len(self.order)
+        if a.sig_extract or any(bool((h["flags"] & 3).any()) for h in hits):
+            return False
+        names = [nm.encode() for nm in self.order]
+        nblob = b"".join(names)
+        noff = np.concatenate([[0], np.cumsum([len(x) for x in names])]).astype(np.int64)
+        nspan = np.tile(np.stack([noff[:-1], noff[1:]], axis=1), (n, 1))
+        mm = np.array([(a.slope * self.lens[c]) + a.intercept for c in range(K)], dtype=np.float64)
+        ms = mm * a.std_const
+        dist = np.stack([h["dist"] for h in hits], axis=1)                   # [n, K]
+        start = np.stack([h["start"] for h in hits], axis=1)
+        end = np.stack([h["end"] for h in hits], axis=1)
+        with np.errstate(all="ignore"):
+            z = (dist - mm[None, :]) / ms[None, :]                           # MotifSeq.py:441-445, the same IEEE operations
+            pv = norm_cdf(z)
+            hp = (1 - pv) * 100
+
+        def rep(col):                                                        # one entry per read -> one per row
+            if K == 1:
+                return col
+            kind = col[0]
+            if kind == "span":
+                return ("span", col[1], np.repeat(np.asarray(col[2]), K, axis=0))
+            if kind == "i32":
+                return ("i32", np.repeat(np.asarray(col[1]), K))
+            return col
+        cols = [rep(fast5_col), rep(id_col), ("span", nblob, nspan), ("i32", start.ravel()), ("i32", end.ravel()),
+                ("i32", (end - start).ravel()), ("f64", dist.ravel()), ("f64", np.tile(mm, n)), ("f64", np.tile(ms, n)),
+                ("f64", z.ravel()), ("f64", pv.ravel()), ("f64", hp.ravel())]
+        text = fastio.fmt_rows(n * K, cols)
+        fastio.write_stdout(text)
+        return True
+
+    def rows(self, rows, nsamp, fast5_col, id_col, name_of, id_of):
+        """A block of plain int16 reads (BLOW5 / packed input): one GPU batch, native table; the per-read route only
+        when a read is flagged."""
+        if not len(nsamp):
+            return
+        motifs = [np.asarray(self.models[n_], dtype=np.float64) for n_ in self.order]
+        a = self.args
+        hits = api.motifseq_multi_batch(rows, nsamp, motifs, a.scale, a.scale_low, a.scale_hi)
+        if self.table(len(nsamp), fast5_col, id_col, hits):
+            return
+        for i in range(len(nsamp)):
+            self.emit(name_of(i), id_of(i), [hits[c][i] for c in range(len(self.order))],
+                      rows[i, :nsamp[i]] if a.sig_extract else None, None)
+
     def block(self, blk):
         """A parsed TSV chunk (tsvio.TsvBlock): its integer lines go to the GPU as ONE int16 batch straight from the
         tokenizer's rows (every motif against them); any other line takes the per-read route, in its place."""
@@ -187,6 +243,13 @@ class _Batcher:
             hits = api.motifseq_multi_batch(rows, blk.nsamp[idx], [np.asarray(self.models[n], dtype=np.float64)
                                                                     for n in self.order],
                                             a.scale, a.scale_low, a.scale_hi)
+            if idx.size == blk.n:
+                # every line of the chunk is a plain integer read: the whole table in one native call
+                no = blk.base + blk._no.astype(np.int64)
+                io = blk.base + blk._io.astype(np.int64)
+                if self.table(blk.n, ("span", blk.buf, np.stack([no, no + blk._nl], axis=1)),
+                              ("span", blk.buf, np.stack([io, io + blk._il], axis=1)), hits):
+                    return
             res = {int(i): k for k, i in enumerate(idx)}
             # the scoring of MotifSeq.py:441-445 for the whole chunk at once (the same IEEE operations as the
             # per-row arithmetic of emit(), so the same digits), then plain Python numbers for the formatting
@@ -262,7 +325,7 @@ def main(argv=None):
     print("\t".join(HEADER + (["normalised_signal"] if args.sig_extract else [])
                     + (["search_from"] if args.after_stall else [])))                  # MotifSeq.py:160-163
 
-    if not (args.f5f or args.f5_path or args.signal):
+    if not (args.f5f or args.f5_path or args.signal or args.blow5 or args.i16):
         sys.stderr.write("Unknown file or path input")
         parser.print_help(sys.stderr)
         sys.exit(1)
@@ -270,7 +333,7 @@ def main(argv=None):
         return
 
     from . import _lib
-    _lib.init(args.device)
+    _lib.warm_start(args.device, also=("scipy.special",))          # HIP start-up runs beside the parsing of the first chunk
     if args.gpus > 1:
         api.set_devices(range(args.gpus))
     out = _Batcher(args, models, order, lens)
@@ -293,6 +356,34 @@ def main(argv=None):
                     continue
                 out.add(fast5, read_id, sig)
             out.flush()
+    elif args.blow5:
+        # [extension] BLOW5: records decoded natively into int16 rows (raw ADC values, as the fast5 branches use)
+        fast5 = os.path.basename(args.blow5).encode()
+        for blk in fastio.iter_blow5_blocks_i16(args.blow5):
+            bad = np.flatnonzero(blk.flags & 2)
+            for i in bad:
+                sys.stderr.write("MotifSeq: unreadable BLOW5 record {} in {}; skipped\n".format(int(i), args.blow5))
+            if bad.size:
+                ok = np.flatnonzero((blk.flags & 2) == 0)
+                blk = fastio.Blow5Block(blk.rows[ok], blk.nsamp[ok], blk.ids[ok], blk.calib[ok], blk.flags[ok])
+            w = blk.ids.dtype.itemsize
+            st = np.arange(blk.n, dtype=np.int64) * w
+            spans = np.stack([st, st + np.char.str_len(blk.ids)], axis=1)
+            out.rows(blk.rows, blk.nsamp, ("const", fast5), ("span", blk.ids, spans),
+                     lambda i: fast5.decode(), lambda i, b=blk: b.ids[i].decode())
+    elif args.i16:
+        # [extension] packed reads: int16 [reads, samples] in a .npy file, memory mapped
+        arr = np.load(args.i16, mmap_mode="r")
+        if arr.ndim != 2 or arr.dtype != np.int16:
+            sys.stderr.write("MotifSeq: --i16 needs a 2-D int16 .npy array, got {} {}\n".format(arr.dtype, arr.shape))
+            sys.exit(1)
+        fast5 = os.path.basename(args.i16).encode()
+        step = max(1, (1 << 30) // max(1, arr.shape[1] * 2))                 # ~1 GB of samples per GPU call
+        for lo in range(0, arr.shape[0], step):
+            part = arr[lo:lo + step]
+            ns = np.full(part.shape[0], part.shape[1], dtype=np.int32)
+            out.rows(part, ns, ("const", fast5), ("i32", np.arange(lo, lo + part.shape[0], dtype=np.int32)),
+                     lambda i: fast5.decode(), lambda i, lo=lo: str(lo + i))
     else:
         if args.f5f:                                 # MotifSeq.py:165-184: first column = path
             with tsvio.open_text(args.f5f) as fh:

@@ -11,7 +11,7 @@ import sys
 
 import numpy as np
 
-from . import api, tsvio
+from . import api, fastio, tsvio
 from ._lib import SegParams
 
 
@@ -28,7 +28,10 @@ def build_parser():
     src.add_argument("-i", "--ind", nargs="+", help="one or more fast5 files")
     src.add_argument("-p", "--f5_path", help="directory searched recursively for fast5 files")
     src.add_argument("-s", "--signal", help="signal TSV written by SquigglePull (.gz accepted)")
-    src.add_argument("--blow5", help="[extension] BLOW5 file (uncompressed or zlib records)")
+    src.add_argument("--blow5", help="[extension] BLOW5 file (uncompressed or zlib records); with --raw_signal the "
+                                     "records are decoded natively into int16 batches")
+    src.add_argument("--i16", help="[extension] packed reads: a .npy file holding an int16 array [reads, samples] "
+                                   "(read name = row index)")
     p.add_argument("--single", action="store_true", help="fast5 files hold one read each")
     p.add_argument("-n", "--Num", type=int, default=0, help="use only the first Num samples; 0 = whole read")
     p.add_argument("-e", "--error", type=int, default=5, help="out-of-band samples tolerated inside a segment")
@@ -100,6 +103,28 @@ class _Batcher:
             self.emit(name, miss, next(results))
         self.names, self.sigs = [], []
 
+    def rows(self, rows, nsamp, name_col, name_of):
+        """A block of plain int16 reads (BLOW5 --raw_signal / packed input): one GPU batch; the table through the
+        native formatter unless -u asks for the per-read checks."""
+        if not len(nsamp):
+            return
+        Num = self.args.Num
+        lens = (np.maximum(nsamp + Num, 0) if Num < 0 else np.minimum(nsamp, Num)).astype(np.int32)   # sig[:Num]
+        segs, nsegs = api.segment_batch(rows, lens, self.params)
+        if self.args.test:
+            for i in range(len(nsamp)):
+                nm = name_of(i)
+                self.emit(nm, nm, segs[i, :nsegs[i]].tolist() if nsegs[i] else False)
+            return
+        for i in np.flatnonzero(nsegs == 0):
+            sys.stderr.write("no segments found: {}".format(name_of(int(i))))          # segmenter.py:213
+        off = np.zeros(len(nsamp) + 1, dtype=np.int64)
+        np.cumsum(2 * nsegs.astype(np.int64), out=off[1:])
+        keep = np.arange(segs.shape[1])[None, :] < nsegs[:, None]
+        vals = segs[keep].ravel()                                                   # [start, end] pairs, read order
+        text = fastio.fmt_rows(len(nsamp), [name_col, ("i32list", vals, off)], skip=(nsegs == 0).astype(np.uint8))
+        fastio.write_stdout(text)
+
     def block(self, blk, path):
         """A parsed TSV chunk (tsvio.TsvBlock): the integer lines go to the GPU as ONE int16 batch straight from
         the tokenizer's rows; every other line takes the per-read route above, in its place."""
@@ -143,13 +168,13 @@ def main(argv=None):
     if args.view:
         sys.stderr.write("segmenter: -v/--view plotting is not part of this build; ignoring\n")
 
-    if not (args.f5_path or args.ind or args.signal or args.blow5):
+    if not (args.f5_path or args.ind or args.signal or args.blow5 or args.i16):
         sys.stderr.write("Unknown file or path input")
         parser.print_help(sys.stderr)
         sys.exit(1)
 
     from . import _lib
-    _lib.init(args.device)
+    _lib.warm_start(args.device, also=())          # HIP start-up runs beside the parsing of the first chunk
     if args.gpus > 1:
         api.set_devices(range(args.gpus))
     out = _Batcher(args)
@@ -173,6 +198,25 @@ def main(argv=None):
                     continue
                 out.add(name, sig[:args.Num])
             out.flush()
+    elif args.blow5 and args.raw_signal:
+        for blk in fastio.iter_blow5_blocks_i16(args.blow5):
+            ok = np.flatnonzero((blk.flags & 2) == 0)
+            if ok.size != blk.n:
+                blk = fastio.Blow5Block(blk.rows[ok], blk.nsamp[ok], blk.ids[ok], blk.calib[ok], blk.flags[ok])
+            w = blk.ids.dtype.itemsize
+            st = np.arange(blk.n, dtype=np.int64) * w
+            out.rows(blk.rows, blk.nsamp, ("span", blk.ids, np.stack([st, st + np.char.str_len(blk.ids)], axis=1)),
+                     lambda i, b=blk: b.ids[i].decode())
+    elif args.i16:
+        arr = np.load(args.i16, mmap_mode="r")
+        if arr.ndim != 2 or arr.dtype != np.int16:
+            sys.stderr.write("segmenter: --i16 needs a 2-D int16 .npy array, got {} {}\n".format(arr.dtype, arr.shape))
+            sys.exit(1)
+        step = max(1, (1 << 30) // max(1, arr.shape[1] * 2))                 # ~1 GB of samples per GPU call
+        for lo in range(0, arr.shape[0], step):
+            part = arr[lo:lo + step]
+            ns = np.full(part.shape[0], part.shape[1], dtype=np.int32)
+            out.rows(part, ns, ("i32", np.arange(lo, lo + part.shape[0], dtype=np.int32)), lambda i, lo=lo: str(lo + i))
     elif args.blow5:
         from .blow5 import read_blow5, to_pA
         for rec in read_blow5(args.blow5):

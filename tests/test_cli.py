@@ -250,3 +250,56 @@ def test_motifseq_cli_constant_read_is_reported_not_printed(gpu, tmp_path):
     assert code == 0 and len(rows) == 2 and rows[1].startswith("b.fast5\tfine\t")
     assert "the MAD of flat is 0" in se and "flat" not in so
     assert "note: -m searches for the model's motif(s)" in se
+
+
+@pytest.mark.gpu
+def test_packed_and_blow5_inputs_equal_the_tsv_route(gpu, tmp_path):
+    """[extensions] --i16 / --blow5: the same reads through the packed-npy, the BLOW5 (stored and zlib) and the TSV
+    inputs give the same numbers -- every column but the name columns -- for both tools; a second model file with two
+    motifs checks the read-major row order of the native table."""
+    from squigglekit_amd import fastio, synth
+    from squigglekit_amd.motifseq_cli import main as mmain
+    from squigglekit_amd.segmenter_cli import main as smain
+    R, M = 300, 3000
+    motif = synth.synthetic_motif(163, seed=11)
+    sig = synth.squiggle_batch(R, M, 777, motif=motif)
+    sig[7, :] = 500                                           # MAD = 0: flagged -> the per-read route inside a block
+    np.save(tmp_path / "r.npy", sig)
+    ids = ["read-%04d" % i for i in range(R)]
+    fastio.write_blow5(str(tmp_path / "r.blow5"), sig, ids)
+    fastio.write_blow5(str(tmp_path / "rz.blow5"), sig, ids, compress=True)
+    with open(tmp_path / "m.tsv", "w") as fm, open(tmp_path / "s.tsv", "w") as fs:
+        for i in range(R):
+            vals = "\t".join(str(int(v)) for v in sig[i])
+            fm.write("\t".join(["f.fast5", ids[i]] + ["x"] * 6) + "\t" + vals + "\n")
+            fs.write("\t".join([ids[i], "a", "b", "c"]) + "\t" + vals + "\n")
+    model = os.path.join(GOLD, "CATCTATCCAGGGTTAAATT.model")
+    two = tmp_path / "two.model"
+    vals = load_golden("motifseq_cli.json.gz")["model_expanded"]["values"]
+    two.write_text("mA\t20\t.\t" + "\t".join(repr(v) for v in vals) + "\n" +
+                   "mB\t12\t.\t" + "\t".join(repr(v) for v in vals[20:120]) + "\n")
+
+    def cols(text, first):
+        return [ln.split("\t")[first:] for ln in text.strip().split("\n")]
+
+    for mfile, K in ((model, 1), (str(two), 2)):
+        ref, err, code = run_cli(mmain, ["-s", str(tmp_path / "m.tsv"), "-m", mfile])
+        assert code == 0 and len(ref.strip().split("\n")) == 1 + K * (R - 1), err[-500:]
+        for argv in (["--i16", str(tmp_path / "r.npy")], ["--blow5", str(tmp_path / "r.blow5")],
+                     ["--blow5", str(tmp_path / "rz.blow5")]):
+            got, err2, code = run_cli(mmain, argv + ["-m", mfile])
+            assert code == 0 and "MAD" in err2
+            assert cols(got, 2) == cols(ref, 2), argv                # model, start .. hit_Probability
+            if argv[0] == "--blow5":
+                assert [r[1] for r in cols(got, 0)[1:]] == [r[1] for r in cols(ref, 0)[1:]]     # readID column
+    ref, _, code = run_cli(smain, ["-s", str(tmp_path / "s.tsv")])
+    assert code == 0 and ref.count("\n") > R // 2
+    for argv in (["--i16", str(tmp_path / "r.npy")], ["--blow5", str(tmp_path / "r.blow5"), "--raw_signal"],
+                 ["--blow5", str(tmp_path / "rz.blow5"), "--raw_signal"]):
+        got, _, code = run_cli(smain, argv)
+        assert code == 0 and cols(got, 1) == cols(ref, 1), argv
+        if argv[0] == "--blow5":
+            assert got == ref
+    got, _, _ = run_cli(smain, ["--i16", str(tmp_path / "r.npy"), "-u", "-k"])          # -u: the per-read checks
+    want, _, _ = run_cli(smain, ["-s", str(tmp_path / "s.tsv"), "-u", "-k"])
+    assert cols(got, 1) == cols(want, 1)

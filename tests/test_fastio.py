@@ -1,0 +1,89 @@
+"""CPU: the host-side fast paths of the command-line tools (csrc/sk_io.cpp) -- the table formatter must write floats
+exactly as Python does, the BLOW5 decoder must agree with the pure-Python reader."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD
+
+
+def _floats():
+    rng = np.random.default_rng(12)
+    special = [0.0, -0.0, 1.0, -1.0, 0.1, 0.1 + 0.2, 1e15, 1e16, 9999999999999998.0, 1e17, 1.5e16, 123456789012345678.0,
+               1e-4, 1e-5, 9.999e-5, 0.0001234, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, float("inf"),
+               float("-inf"), float("nan"), 44.22162497382986, 100.0, 1e22, 1e21, 123456.0, 0.5, 2.90 * 20 - 9.6,
+               (2.90 * 20 - 9.6) * 0.08468, 99.99999999999999, 3.0000000000000004e-05]
+    bits = rng.integers(0, 2**63, 20000, dtype=np.uint64) | (rng.integers(0, 2, 20000, dtype=np.uint64) << np.uint64(63))
+    rnd = bits.view(np.float64)
+    rnd = rnd[np.isfinite(rnd)]
+    wide = 10.0 ** rng.uniform(-8, 20, 5000) * rng.choice([-1, 1], 5000)
+    usual = np.concatenate([rng.normal(40, 20, 5000), rng.uniform(0, 1, 5000), np.round(rng.normal(0, 5, 3000), 2)])
+    return np.concatenate([np.array(special), rnd, wide, usual])
+
+
+def test_native_float_text_equals_python_repr():
+    from squigglekit_amd import fastio
+    v = _floats()
+    got = fastio.fmt_rows(len(v), [("f64", v)], nthreads=3).decode().split("\n")
+    assert got[-1] == "" and len(got) == len(v) + 1
+    for x, t in zip(v.tolist(), got):
+        assert t == repr(x) == "{}".format(x), (x, t)
+
+
+def test_table_columns_and_skip():
+    from squigglekit_amd import fastio
+    names = [b"a.fast5", b"", b"read-3", b"x" * 70]
+    blob = b"".join(names)
+    off = np.concatenate([[0], np.cumsum([len(s) for s in names])]).astype(np.int64)
+    spans = np.stack([off[:-1], off[1:]], axis=1)
+    ints = np.array([0, -7, 2147483647, -2147483648], dtype=np.int32)
+    vals = np.array([1.5, -0.0, 1e-7, 12345.678])
+    lst = np.array([1, 2, 3, 40, 50, -6], dtype=np.int32)
+    loff = np.array([0, 2, 2, 3, 6], dtype=np.int64)
+    skip = np.array([0, 0, 1, 0], dtype=np.uint8)
+    out = fastio.fmt_rows(4, [("str", blob, off), ("span", blob, spans), ("const", b"motif"), ("i32", ints), ("f64", vals),
+                              ("i32list", lst, loff)], skip=skip).decode()
+    want = ""
+    for i in range(4):
+        if skip[i]:
+            continue
+        n = names[i].decode()
+        want += "\t".join([n, n, "motif", str(int(ints[i])), repr(float(vals[i])),
+                           ",".join(str(int(x)) for x in lst[loff[i]:loff[i + 1]])]) + "\n"
+    assert out == want
+    assert fastio.fmt_rows(0, [("const", b"x")]) == b""
+    big = fastio.fmt_rows(50000, [("i32", np.arange(50000, dtype=np.int32)), ("f64", np.arange(50000) * 0.25)], nthreads=8)
+    assert big.decode() == "".join("%d\t%r\n" % (i, i * 0.25) for i in range(50000))
+
+
+@pytest.mark.parametrize("compress", [False, True])
+def test_blow5_native_decoder_equals_python_reader(tmp_path, compress):
+    from squigglekit_amd import blow5, fastio
+    rng = np.random.default_rng(3)
+    reads = [rng.integers(-500, 1500, int(n)).astype(np.int16) for n in rng.integers(0, 3000, 700)]
+    reads[5] = np.zeros(0, dtype=np.int16)
+    ids = ["%08x-read-%d" % (int(rng.integers(0, 2**31)), i) for i in range(len(reads))]
+    path = fastio.write_blow5(str(tmp_path / "t.blow5"), reads, ids, compress=compress)
+    py = list(blow5.read_blow5(path))
+    assert [r["read_id"] for r in py] == ids
+    seen = 0
+    for blk in fastio.iter_blow5_blocks_i16(path, block_reads=256, nthreads=3):
+        assert not np.any(blk.flags)
+        for i in range(blk.n):
+            want = py[seen]
+            assert blk.ids[i].decode() == want["read_id"] and blk.nsamp[i] == want["signal"].size
+            assert np.array_equal(blk.rows[i, :blk.nsamp[i]], want["signal"])
+            assert blk.calib[i].tolist() == [want["digitisation"], want["offset"], want["range"]]
+            seen += 1
+    assert seen == len(reads)
+
+
+def test_blow5_native_decoder_reads_the_reference_example():
+    """The one real read the reference ships (example/slow5/0.blow5, zlib records; copy under tests/golden)."""
+    from squigglekit_amd import blow5, fastio
+    path = os.path.join(GOLD, "example_0.blow5")
+    want = next(blow5.read_blow5(path))
+    blks = list(fastio.iter_blow5_blocks_i16(path))
+    assert len(blks) == 1 and blks[0].n == 1 and blks[0].nsamp[0] == want["signal"].size == 36978
+    assert np.array_equal(blks[0].rows[0, :36978], want["signal"]) and blks[0].ids[0].decode() == want["read_id"]
