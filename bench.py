@@ -442,6 +442,52 @@ def e2e_all_ranks(a, w, comm):
     return Rh, best
 
 
+def cli_block(a, L, main):
+    """N = 1 extras: the drop-in command-line tools end to end, process start and text output included (the full-size
+    runs are tools/cli_throughput.py -> profiles/r03_cli_throughput.txt).  200 000 of the batch's reads as a packed
+    int16 .npy (--i16), 4 000 as the SquigglePull-style TSV the reference reads."""
+    import shutil
+    import subprocess
+    import tempfile
+    from squigglekit_amd._lib import check, ptr
+    d = tempfile.mkdtemp()
+    out = {"note": "wall clock of the whole process (interpreter start, HIP start-up, ingest, kernels, text out), best "
+                   "of 2; at these sizes start-up (~0.35 s) dominates -- see profiles/r03_cli_throughput.txt for 1 M reads"}
+    try:
+        Rp = min(main.R, 200_000)
+        host = np.empty((Rp, main.stride), dtype=np.int16)
+        check(L.sk_dev_download(ptr(host), main.d_sig, host.nbytes))
+        np.save(os.path.join(d, "r.npy"), host[:, :main.M])
+        model = os.path.join(ROOT, "tests", "golden", "CATCTATCCAGGGTTAAATT.model")
+        Rt = min(Rp, 4000)
+        for name, ncols in (("s.tsv", 4), ("m.tsv", 8)):
+            with open(os.path.join(d, name), "w") as fh:
+                for r in range(Rt):
+                    fh.write("\t".join(["read%d.fast5" % r, "id%d" % r] + ["x"] * (ncols - 2)
+                                       + [str(v) for v in host[r, :main.M].tolist()]) + "\n")
+        runs = (("segmenter_i16", Rp, [os.path.join(ROOT, "segmenter.py"), "--i16", os.path.join(d, "r.npy")]),
+                ("motifseq_i16", Rp, [os.path.join(ROOT, "MotifSeq.py"), "--i16", os.path.join(d, "r.npy"), "-m", model]),
+                ("segmenter_tsv", Rt, [os.path.join(ROOT, "segmenter.py"), "-s", os.path.join(d, "s.tsv")]),
+                ("motifseq_tsv", Rt, [os.path.join(ROOT, "MotifSeq.py"), "-s", os.path.join(d, "m.tsv"), "-m", model]))
+        for label, n, cmd in runs:
+            best, lines = None, 0
+            for _ in range(2):
+                t0 = time.perf_counter()
+                p = subprocess.run([sys.executable] + cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+                dt = time.perf_counter() - t0
+                if p.returncode != 0:
+                    best = None
+                    break
+                best = dt if best is None else min(best, dt)
+                lines = p.stdout.count(b"\n")
+            out[label] = {"reads": n, "seconds": best, "reads_per_s": n / best if best else None, "output_lines": lines}
+    except Exception as e:                                            # noqa: BLE001 -- report, keep the line
+        out["error"] = repr(e)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def sensitivity_block(a, L, main):
     """N = 1, after everything else: what the headline is worth on less friendly data.  (i) reads that are windows of
     the one measured squiggle the reference ships (example/slow5/0.blow5, 36 978 samples; copy under tests/golden)
@@ -805,6 +851,7 @@ def rank_body(a, comm, rank, world, shape):
     if world == 1 and not a.no_extras:
         line.update(extras_single_gpu(a, L, w))
         if a.workload == "motifseq" and not a.no_sensitivity:
+            line["cli"] = cli_block(a, L, w)
             line["sensitivity"] = sensitivity_block(a, L, w)
     w.free()
     return line

@@ -5,6 +5,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from squigglekit_amd import _warm  # noqa: E402
+_warm.start()                      # the GPU context comes up while numpy and the tool are being imported
 from squigglekit_amd.drna_cli import main  # noqa: E402
 
 if __name__ == "__main__":

@@ -125,7 +125,7 @@ def blow5_open(path):
     return mm, comp, 68 + hlen
 
 
-def iter_blow5_blocks_i16(path, block_reads=131072, id_width=64, nthreads=0):
+def iter_blow5_blocks_i16(path, block_reads=65536, id_width=64, nthreads=0):
     """Stream a BLOW5 file as Blow5Block chunks (csrc/sk_io.cpp): the records of a chunk are decoded on all cores
     straight into int16 rows whose stride fits the chunk's longest read."""
     L = _lib.load()
@@ -137,7 +137,19 @@ def iter_blow5_blocks_i16(path, block_reads=131072, id_width=64, nthreads=0):
     off = np.zeros(max(1, nrec), dtype=np.int64)
     size = np.zeros(max(1, nrec), dtype=np.int64)
     L.sk_blow5_index(base, len(mm), first, off.ctypes.data, size.ctypes.data, nrec)
-    for lo in range(0, nrec, block_reads):
+    from concurrent.futures import ThreadPoolExecutor
+    pools = [{}, {}, {}]                                       # three sets of buffers, reused (fresh pages cost page
+                                                               # faults): a GPU call on the previous block, the block
+                                                               # the caller holds, the one being decoded
+
+    def buf(pool, name, shape, dtype):
+        need = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        b = pool.get(name)
+        if b is None or b.nbytes < need:
+            b = pool[name] = np.empty(max(need, 1), dtype=np.uint8)
+        return b[:need].view(dtype).reshape(shape)
+
+    def decode(lo, pool):
         hi = min(nrec, lo + block_reads)
         n = hi - lo
         # stored records: the signal is all of the payload but ~60 bytes of fixed fields, the id and aux data, so
@@ -145,11 +157,11 @@ def iter_blow5_blocks_i16(path, block_reads=131072, id_width=64, nthreads=0):
         guess = int(size[lo:hi].max()) // 2 if comp == 0 else int(size[lo:hi].max()) * 2
         stride = max(8, (guess + 7) // 8 * 8)
         while True:
-            rows = np.empty((n, stride), dtype=np.int16)
-            nsamp = np.zeros(n, dtype=np.int32)
-            ids = np.zeros(n, dtype="S%d" % id_width)
-            calib = np.zeros((n, 3), dtype=np.float64)
-            flags = np.zeros(n, dtype=np.int32)
+            rows = buf(pool, "rows", (n, stride), np.int16)          # (valid until three blocks later)
+            nsamp = buf(pool, "nsamp", (n,), np.int32)
+            ids = buf(pool, "ids", (n,), "S%d" % id_width)
+            calib = buf(pool, "calib", (n, 3), np.float64)
+            flags = buf(pool, "flags", (n,), np.int32)
             _lib.check(L.sk_blow5_rows_i16(base, off[lo:hi].ctypes.data, size[lo:hi].ctypes.data, n, comp, stride,
                                            rows.ctypes.data, nsamp.ctypes.data, ids.ctypes.data, id_width,
                                            calib.ctypes.data, flags.ctypes.data, int(nthreads)))
@@ -157,7 +169,76 @@ def iter_blow5_blocks_i16(path, block_reads=131072, id_width=64, nthreads=0):
                 stride = (int(nsamp.max()) + 7) // 8 * 8          # (nsamp holds the true lengths)
                 continue
             break
-        yield Blow5Block(rows, nsamp, ids, calib, flags)
+        return Blow5Block(rows, nsamp, ids, calib, flags)
+
+    with ThreadPoolExecutor(1) as ex:
+        k = 0
+        fut = ex.submit(decode, 0, pools[0]) if nrec > 0 else None
+        for lo in range(0, nrec, block_reads):
+            blk = fut.result()
+            k = (k + 1) % 3
+            fut = ex.submit(decode, lo + block_reads, pools[k]) if lo + block_reads < nrec else None
+            yield blk
+
+
+def iter_npy_blocks_i16(path, block_bytes=256 << 20, nthreads=8):
+    """Stream a .npy file holding an int16 array [reads, samples] as (first_row, rows) blocks: parallel preads into
+    two reused page-locked buffers (api.pinned_empty), the next block being read while the caller works on the current
+    one.  A memory map would cost a page fault per 4 KB and a staging copy inside the H2D transfer."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import api
+    with open(path, "rb") as fh:
+        major, minor = np.lib.format.read_magic(fh)
+        shape, fortran, dtype = (np.lib.format.read_array_header_1_0(fh) if major == 1
+                                 else np.lib.format.read_array_header_2_0(fh))
+        data0 = fh.tell()
+    if len(shape) != 2 or dtype != np.int16 or fortran:
+        raise ValueError("%s: need a C-ordered 2-D int16 array, got %s %s" % (path, dtype, shape))
+    R, M = shape
+    per = max(1, block_bytes // max(1, M * 2))
+    fd = os.open(path, os.O_RDONLY)
+    def alloc():
+        try:
+            return api.pinned_empty((min(per, max(R, 1)), M), np.int16)
+        except Exception:                                            # noqa: BLE001 -- no device yet / no pinned memory
+            return np.empty((min(per, max(R, 1)), M), dtype=np.int16)
+    # three buffers: the caller may still have a GPU call in flight on the previous block while it holds the
+    # current one and the next is being read
+    nbuf = 3 if R > 2 * per else (2 if R > per else 1)
+    bufs = [alloc() for _ in range(nbuf)]
+    ex = ThreadPoolExecutor(max(1, nthreads))
+
+    def fill(k, lo):
+        n = min(per, R - lo)
+        flat = bufs[k][:n].reshape(-1).view(np.uint8)
+        nb = flat.size
+        step = (nb + nthreads - 1) // nthreads // 4096 * 4096 + 4096
+
+        def part(a):
+            b = min(nb, a + step)
+            mv = memoryview(flat)[a:b]
+            got = 0
+            while got < b - a:
+                r = os.preadv(fd, [mv[got:]], data0 + lo * M * 2 + a + got)
+                if r <= 0:
+                    raise IOError("short read from %s" % path)
+                got += r
+        return [ex.submit(part, a) for a in range(0, nb, step)], n
+
+    try:
+        pending = fill(0, 0) if R else None
+        lo, k = 0, 0
+        while pending is not None:
+            futs, n = pending
+            for f in futs:
+                f.result()
+            nxt = lo + n
+            pending = fill((k + 1) % nbuf, nxt) if nxt < R else None
+            yield lo, bufs[k][:n]
+            lo, k = nxt, (k + 1) % nbuf
+    finally:
+        ex.shutdown(wait=True)
+        os.close(fd)
 
 
 def write_blow5(path, reads, read_ids=None, compress=False):

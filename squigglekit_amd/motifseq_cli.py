@@ -75,6 +75,14 @@ def build_parser():
     return p
 
 
+def _mark(label):
+    """Stage timestamps on stderr when SK_T0 (launch time, seconds since the epoch) is set: tools/cli_throughput.py."""
+    t0 = os.environ.get("SK_T0")
+    if t0:
+        import time
+        sys.stderr.write("[t+%.3f s] %s\n" % (time.time() - float(t0), label))
+
+
 def norm_cdf(z):
     """scipy.stats.norm.cdf == scipy.special.ndtr (MotifSeq.py:444)."""
     try:
@@ -114,6 +122,7 @@ class _Batcher:
     def __init__(self, args, models, order, lens):
         self.args, self.models, self.order, self.lens = args, models, order, lens
         self.meta, self.sigs = [], []
+        self._pending, self._worker = None, None
 
     def add(self, fast5, read_id, sig):
         self.meta.append((fast5, read_id))
@@ -217,17 +226,35 @@ class _Batcher:
 
     def rows(self, rows, nsamp, fast5_col, id_col, name_of, id_of):
         """A block of plain int16 reads (BLOW5 / packed input): one GPU batch, native table; the per-read route only
-        when a read is flagged."""
+        when a read is flagged.  One block deep pipeline: the GPU call of this block runs on a worker thread while the
+        previous block's table is written (drain() at the end); the caller keeps `rows` alive one call longer."""
         if not len(nsamp):
             return
         motifs = [np.asarray(self.models[n_], dtype=np.float64) for n_ in self.order]
         a = self.args
-        hits = api.motifseq_multi_batch(rows, nsamp, motifs, a.scale, a.scale_low, a.scale_hi)
+        if self._worker is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._worker = ThreadPoolExecutor(1)
+        job = self._worker.submit(api.motifseq_multi_batch, rows, nsamp, motifs, a.scale, a.scale_low, a.scale_hi)
+        prev, self._pending = self._pending, (job, rows, nsamp, fast5_col, id_col, name_of, id_of)
+        if prev is not None:
+            self._finish(prev)
+        if a.sig_extract:                                   # (-x normalises on the GPU from this thread: no overlap)
+            self.drain()
+
+    def drain(self):
+        prev, self._pending = self._pending, None
+        if prev is not None:
+            self._finish(prev)
+
+    def _finish(self, p):
+        job, rows, nsamp, fast5_col, id_col, name_of, id_of = p
+        hits = job.result()
         if self.table(len(nsamp), fast5_col, id_col, hits):
             return
         for i in range(len(nsamp)):
             self.emit(name_of(i), id_of(i), [hits[c][i] for c in range(len(self.order))],
-                      rows[i, :nsamp[i]] if a.sig_extract else None, None)
+                      rows[i, :nsamp[i]] if self.args.sig_extract else None, None)
 
     def block(self, blk):
         """A parsed TSV chunk (tsvio.TsvBlock): its integer lines go to the GPU as ONE int16 batch straight from the
@@ -321,6 +348,7 @@ def main(argv=None):
     if args.view or args.save:
         sys.stderr.write("MotifSeq: -v/--save plotting is not part of this build; ignoring\n")
 
+    _mark("main() entered")
     models, order, lens = load_models(args)
     print("\t".join(HEADER + (["normalised_signal"] if args.sig_extract else [])
                     + (["search_from"] if args.after_stall else [])))                  # MotifSeq.py:160-163
@@ -373,17 +401,16 @@ def main(argv=None):
                      lambda i: fast5.decode(), lambda i, b=blk: b.ids[i].decode())
     elif args.i16:
         # [extension] packed reads: int16 [reads, samples] in a .npy file, memory mapped
-        arr = np.load(args.i16, mmap_mode="r")
-        if arr.ndim != 2 or arr.dtype != np.int16:
-            sys.stderr.write("MotifSeq: --i16 needs a 2-D int16 .npy array, got {} {}\n".format(arr.dtype, arr.shape))
-            sys.exit(1)
         fast5 = os.path.basename(args.i16).encode()
-        step = max(1, (1 << 30) // max(1, arr.shape[1] * 2))                 # ~1 GB of samples per GPU call
-        for lo in range(0, arr.shape[0], step):
-            part = arr[lo:lo + step]
-            ns = np.full(part.shape[0], part.shape[1], dtype=np.int32)
-            out.rows(part, ns, ("const", fast5), ("i32", np.arange(lo, lo + part.shape[0], dtype=np.int32)),
-                     lambda i: fast5.decode(), lambda i, lo=lo: str(lo + i))
+        try:
+            blocks = fastio.iter_npy_blocks_i16(args.i16)
+            for lo, part in blocks:
+                ns = np.full(part.shape[0], part.shape[1], dtype=np.int32)
+                out.rows(part, ns, ("const", fast5), ("i32", np.arange(lo, lo + part.shape[0], dtype=np.int32)),
+                         lambda i: fast5.decode(), lambda i, lo=lo: str(lo + i))
+        except ValueError as e:
+            sys.stderr.write("MotifSeq: --i16: {}\n".format(e))
+            sys.exit(1)
     else:
         if args.f5f:                                 # MotifSeq.py:165-184: first column = path
             with tsvio.open_text(args.f5f) as fh:
@@ -400,7 +427,9 @@ def main(argv=None):
                     out.note("main():data not extracted. Moving to next file - {}\n".format(path))  # MotifSeq.py:213
                 continue
             out.add(fast5, read_id, np.array(sig, dtype=int))
+    out.drain()
     out.flush()
+    _mark("end of main()")
 
 
 if __name__ == "__main__":

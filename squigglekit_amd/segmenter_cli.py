@@ -66,6 +66,7 @@ class _Batcher:
         self.args = args
         self.params = SegParams.from_args(args)
         self.names, self.sigs = [], []
+        self._pending, self._worker = None, None
 
     def add(self, name, sig, miss_name=None):
         self.names.append((name, miss_name if miss_name is not None else name))
@@ -105,24 +106,40 @@ class _Batcher:
 
     def rows(self, rows, nsamp, name_col, name_of):
         """A block of plain int16 reads (BLOW5 --raw_signal / packed input): one GPU batch; the table through the
-        native formatter unless -u asks for the per-read checks."""
+        native formatter unless -u asks for the per-read checks.  One block deep pipeline: this block's GPU call runs
+        on a worker thread while the previous block's table is written (drain() at the end)."""
         if not len(nsamp):
             return
         Num = self.args.Num
         lens = (np.maximum(nsamp + Num, 0) if Num < 0 else np.minimum(nsamp, Num)).astype(np.int32)   # sig[:Num]
-        segs, nsegs = api.segment_batch(rows, lens, self.params)
+        if self._worker is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._worker = ThreadPoolExecutor(1)
+        job = self._worker.submit(api.segment_batch, rows, lens, self.params)
+        prev, self._pending = self._pending, (job, len(nsamp), name_col, name_of)
+        if prev is not None:
+            self._finish(prev)
+
+    def drain(self):
+        prev, self._pending = self._pending, None
+        if prev is not None:
+            self._finish(prev)
+
+    def _finish(self, p):
+        job, n, name_col, name_of = p
+        segs, nsegs = job.result()
         if self.args.test:
-            for i in range(len(nsamp)):
+            for i in range(n):
                 nm = name_of(i)
                 self.emit(nm, nm, segs[i, :nsegs[i]].tolist() if nsegs[i] else False)
             return
         for i in np.flatnonzero(nsegs == 0):
             sys.stderr.write("no segments found: {}".format(name_of(int(i))))          # segmenter.py:213
-        off = np.zeros(len(nsamp) + 1, dtype=np.int64)
+        off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(2 * nsegs.astype(np.int64), out=off[1:])
         keep = np.arange(segs.shape[1])[None, :] < nsegs[:, None]
         vals = segs[keep].ravel()                                                   # [start, end] pairs, read order
-        text = fastio.fmt_rows(len(nsamp), [name_col, ("i32list", vals, off)], skip=(nsegs == 0).astype(np.uint8))
+        text = fastio.fmt_rows(n, [name_col, ("i32list", vals, off)], skip=(nsegs == 0).astype(np.uint8))
         fastio.write_stdout(text)
 
     def block(self, blk, path):
@@ -208,15 +225,13 @@ def main(argv=None):
             out.rows(blk.rows, blk.nsamp, ("span", blk.ids, np.stack([st, st + np.char.str_len(blk.ids)], axis=1)),
                      lambda i, b=blk: b.ids[i].decode())
     elif args.i16:
-        arr = np.load(args.i16, mmap_mode="r")
-        if arr.ndim != 2 or arr.dtype != np.int16:
-            sys.stderr.write("segmenter: --i16 needs a 2-D int16 .npy array, got {} {}\n".format(arr.dtype, arr.shape))
+        try:
+            for lo, part in fastio.iter_npy_blocks_i16(args.i16):
+                ns = np.full(part.shape[0], part.shape[1], dtype=np.int32)
+                out.rows(part, ns, ("i32", np.arange(lo, lo + part.shape[0], dtype=np.int32)), lambda i, lo=lo: str(lo + i))
+        except ValueError as e:
+            sys.stderr.write("segmenter: --i16: {}\n".format(e))
             sys.exit(1)
-        step = max(1, (1 << 30) // max(1, arr.shape[1] * 2))                 # ~1 GB of samples per GPU call
-        for lo in range(0, arr.shape[0], step):
-            part = arr[lo:lo + step]
-            ns = np.full(part.shape[0], part.shape[1], dtype=np.int32)
-            out.rows(part, ns, ("i32", np.arange(lo, lo + part.shape[0], dtype=np.int32)), lambda i, lo=lo: str(lo + i))
     elif args.blow5:
         from .blow5 import read_blow5, to_pA
         for rec in read_blow5(args.blow5):
@@ -240,6 +255,7 @@ def main(argv=None):
             else:
                 for read, sig in tsvio.read_multi_fast5(path, args.raw_signal).items():
                     out.add(read, np.array(sig[:args.Num], dtype=float), miss_name=label)
+    out.drain()
     out.flush()
     sys.stderr.write("Done")                        # segmenter.py:297
 
