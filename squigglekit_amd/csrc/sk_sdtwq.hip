@@ -125,7 +125,7 @@ struct wrec {
 // pass Q
 // ---------------------------------------------------------------------------------------------
 #ifndef SK_Q_WAVES
-#define SK_Q_WAVES(R) ((R) >= 22 && (R) <= 25 ? 5 : 1)
+#define SK_Q_WAVES(R) 1
 #endif
 template <int L, int R, int FEED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SK_Q_WAVES(R), 8)))
@@ -134,7 +134,7 @@ void k_sdtw_q(const sdtw_kargs a)
     static_assert(L == 8 || L == 16 || L == 64, "lanes per read");
     constexpr int G = 64 / L;
     constexpr int CKW = R + 2;
-    constexpr int U = (L < 16) ? 4 : 16;            // steps per unrolled run (y values prefetched from LDS)
+    constexpr int U = (L < 16) ? L : 16;            // steps per unrolled run (y values prefetched from LDS)
 
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -222,16 +222,20 @@ void k_sdtw_q(const sdtw_kargs a)
         if constexpr (FEED == SK_FEED_I16) return (int)s16[min(idx, nlast)];
         else                               return s64[min(idx, nlast)];
     };
+    // screening only: fma(x, 2^22 / s, -c 2^22 / s) instead of the reference's (x - c) / s -- the two differ by
+    // < 1e-6 of a fixed-point unit, covered by the slack in E (pass W divides, exactly).  Rounding to the nearest
+    // integer by adding 1.5 * 2^52: the sum's low word is the two's complement integer.
+    const double qa = inv_scale * QSCALE, qb = -center * qa;
     auto toq = [&](auto raw_, int idx) -> unsigned {
-        if (idx >= n) return QINF;
         const double raw = (double)raw_;
-        double v = raw;
-        // screening only: (x - c) * (1/s) instead of the reference's division -- the two differ by
-        // < 1e-6 of a fixed-point unit, covered by the slack in E (pass W divides, exactly)
-        if constexpr (FEED != SK_FEED_F64_RAW) v = (raw - center) * inv_scale;
-        const bool ok = fabs(v) < QLIM;              // false for NaN / inf too
-        bad |= ok ? 0 : 1;
-        return ok ? qimg(v) : QINF;
+        double t;
+        if constexpr (FEED != SK_FEED_F64_RAW) t = __builtin_fma(raw, qa, qb);
+        else                                   t = raw * QSCALE;
+        const bool ok = fabs(t) < QLIM * QSCALE;     // false for NaN / inf too
+        const unsigned q = (unsigned)__double2loint(t + 6755399441055744.0) ^ 0x80000000u;
+        const bool in = idx < n;
+        bad |= (in && !ok) ? 1 : 0;
+        return (in && ok) ? q : QINF;
     };
 
     const unsigned smask = shortlane ? 0xffffffffu : 0u;

@@ -685,16 +685,19 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
                       getenv("SK_WALK_GENERAL") == nullptr;
 
     const bool by_runs = getenv("SK_WALK_STEP") == nullptr;       // A/B switch: the per-sample straight-line walk
-    // (measured: the two kernels are both vector-issue bound, so running them side by side gains nothing --
-    // 3.35 / 3.33 / 3.38 / 3.78 ms for 1 / 2 / 4 / 8 chunks per 1 M reads; one chunk is the default)
-    int nchunks = 1;
+    // Large batches go in four chunks, the walk of one on a second stream beside the statistics of the next -- which
+    // only pays when the persistent statistics grid leaves the walk's waves room on the SIMDs: at its full six
+    // workgroups per CU (78 VGPRs x 24 waves) nothing else fits and the overlap gained nothing (round 2: 3.35 / 3.33 /
+    // 3.38 / 3.78 ms for 1 / 2 / 4 / 8 chunks); with four workgroups per CU the statistics kernel is as fast (it is
+    // co-limited by HBM) and the step drops from 2.89 to 2.70 ms per 1 M reads (round 3, same box).
+    int nchunks = nreads >= 262144 ? 4 : 1;
     if (const char *e = getenv("SK_SEG_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 8) nchunks = v; }
     if (nreads < 65536) nchunks = 1;
     if (nchunks > 1 && !c->stream2) {
         SK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         for (int i = 0; i < 9; i++) SK_HIP(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
     }
-    int per_cu = 8, rounds = 8;
+    int per_cu = nchunks > 1 ? 4 : 8, rounds = 8;
     if (const char *e = getenv("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
     if (const char *e = getenv("SK_PREP_PERCU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }
 
