@@ -23,7 +23,7 @@ def main():
     bad = rounds = 0
     while time.time() < t_end:
         rounds += 1
-        R = int(rng.choice([1, 3, 64, 255, 256, 300, 700]))
+        R = int(rng.choice([1, 3, 64, 255, 256, 300, 700, 1100]))
         M = int(rng.choice([8, 63, 512, 1000, 2047, 4000, 4001, 6000]))
         sig = synth.squiggle_batch(R, M, int(rng.integers(1 << 30)))
         if rng.random() < 0.3:
@@ -33,7 +33,10 @@ def main():
         lens = rng.integers(0, M + 1, R).astype(np.int32)
         lens[rng.integers(0, R)] = M
         # ---- MotifSeq ----
-        N = int(rng.choice([1, 7, 16, 17, 100, 163, 200, 256, 257, 400, 1030]))
+        # (round 3: every rows-per-lane instantiation of the screening kernels can come up -- 8 lanes x 1..32 rows up to
+        # 256 points, 16 x 17..32 up to 512, 64 x 9..16 beyond -- not only the lengths the unit tests pin)
+        N = int(rng.choice([1, 7, 16, 17, 100, 163, 200, 256, 257, 400, 512, 513, 1030])) if rng.random() < 0.5 \
+            else int(rng.integers(1, 1025))
         motif = synth.synthetic_motif(N, seed=int(rng.integers(1000)))
         lo, hi = [(0, 1200), (0, 900), (-50, 2500), (400, 650)][int(rng.integers(4))]
         scale = ["medmad", "zscale"][int(rng.integers(2))]

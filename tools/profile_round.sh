@@ -2,19 +2,24 @@
 # Regenerate the measurement artefacts kept under profiles/ on a GPU box:
 #   tools/profile_round.sh <tag>      (run from the repo root; writes gpurun_out/prof_<tag>/)
 # bench lines (default flags), rocprofv3 --kernel-trace --stats summaries of the same command, HBM traffic from
-# separate --pmc passes (FETCH_SIZE / WRITE_SIZE) and one SQ pass (VALU instruction counts / issue cycles) --
-# counters always with --kernel-trace only, never with other trace domains -- and the VALU issue-cost
-# microbenchmark the DTW roof rests on.
+# separate --pmc passes (FETCH_SIZE / WRITE_SIZE) and two SQ passes (VALU instruction counts / issue and wait
+# cycles) -- counters always with --kernel-trace only, never with other trace domains -- the VALU issue-cost
+# microbenchmark the DTW roof rests on, the command-line tools end to end, and the multi-rank dry run.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 "$R/tools/ubench/valu_rate" > "$OUT/valu_rate.txt" 2>&1
 python "$R/bench.py" > "$OUT/bench_motifseq.json" 2> "$OUT/bench_motifseq.err"
-SK_SEG_CHUNKS=1 python "$R/bench.py" --workload segmenter --no-extras > "$OUT/bench_segmenter.json" 2> "$OUT/bench_segmenter.err"
-SQ="SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
+python "$R/bench.py" --workload segmenter --no-extras > "$OUT/bench_segmenter.json" 2> "$OUT/bench_segmenter.err"
+python "$R/bench.py" --reads 10000 --motif 163 --no-extras --steps 20 --warmup 3 > "$OUT/bench_c3_10k_x_163pt.json" 2>/dev/null
+python "$R/bench.py" --reads 100000 --samples 20000 --motif 500 --no-extras --cpu-seconds 6 > "$OUT/bench_c5_100k_x_20000_x_500pt.json" 2>/dev/null
+python "$R/bench.py" --workload segmenter --reads 10000 --no-extras --steps 20 --warmup 3 > "$OUT/bench_c2_10k_segmenter.json" 2>/dev/null
+python "$R/bench.py" --gpus 2 --ranks-on-device 0 --reads 200000 --steps 3 --warmup 1 --cpu-seconds 2 > "$OUT/bench_2ranks_on_one_gpu.json" 2>/dev/null
+SQ1="SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
+SQ2="SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"
 for WL in motifseq segmenter; do
     export SK_SEG_CHUNKS=1      # kernels timed one after the other (the default overlaps the walk with the statistics)
     rocprofv3 --kernel-trace --stats -d "$OUT/kt_$WL" -- python "$R/bench.py" --workload $WL --steps 3 --warmup 1 \
@@ -28,10 +33,17 @@ for WL in motifseq segmenter; do
     done
     python "$R/tools/pmc_traffic.py" 1000000 2 "$OUT/pmc_FETCH_SIZE_$WL" "$OUT/pmc_WRITE_SIZE_$WL" \
         "bench.py --workload $WL --steps 2 --warmup 0 ($TAG, 1M reads/call)" > "$OUT/traffic_$WL.json"
-    rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d "$OUT/pmc_sq_$WL" -- \
-        python "$R/bench.py" --workload $WL --steps 2 --warmup 0 --cpu-seconds 0 --no-extras > "$OUT/pmc_sq_$WL.log" 2>&1
-    python "$R/tools/pmc_sq.py" "$OUT/pmc_sq_$WL" "bench.py --workload $WL --steps 2 --warmup 0 ($TAG)" > "$OUT/sq_$WL.json"
-    rm -rf "$OUT/kt_$WL" "$OUT/pmc_FETCH_SIZE_$WL" "$OUT/pmc_WRITE_SIZE_$WL" "$OUT/pmc_sq_$WL"
+    i=1
+    for SQ in "$SQ1" "$SQ2"; do
+        rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d "$OUT/pmc_sq${i}_$WL" -- \
+            python "$R/bench.py" --workload $WL --steps 2 --warmup 0 --cpu-seconds 0 --no-extras > "$OUT/pmc_sq${i}_$WL.log" 2>&1
+        python "$R/tools/pmc_sq.py" "$OUT/pmc_sq${i}_$WL" "bench.py --workload $WL --steps 2 --warmup 0 ($TAG, pass $i)" > "$OUT/sq${i}_$WL.json"
+        rm -rf "$OUT/pmc_sq${i}_$WL"
+        i=$((i+1))
+    done
+    rm -rf "$OUT/kt_$WL" "$OUT/pmc_FETCH_SIZE_$WL" "$OUT/pmc_WRITE_SIZE_$WL"
     unset SK_SEG_CHUNKS
 done
+python "$R/tools/cli_throughput.py" 100000 1000000 > "$OUT/cli_throughput.txt" 2>&1
+(cd "$R" && python tools/parity_at_scale.py 400000 128 && python tools/parity_at_scale.py segmenter 1000000 128) > "$OUT/parity_at_scale.txt" 2>&1
 ls -la "$OUT"
