@@ -127,7 +127,8 @@ struct wrec {
 #ifndef SK_Q_WAVES
 #define SK_Q_WAVES(R) 1
 #endif
-template <int L, int R, int FEED>
+// P0: every lane owns R rows (the motif fills L x R slots exactly): no short-lane select after the column
+template <int L, int R, int FEED, bool P0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SK_Q_WAVES(R), 8)))
 void k_sdtw_q(const sdtw_kargs a)
 {
@@ -257,8 +258,9 @@ void k_sdtw_q(const sdtw_kargs a)
         qcolumn<R>(old, nw, xq, yq, diagq, upq);
         diagq = upq;
         // (a bit select, v_bitop3_b32: 2 cycles of issue against v_cndmask's 4)
-        if constexpr (R >= 2) asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(botq) : "v"(nw[R - 2]), "v"(nw[R - 1]), "v"(smask));
-        else                  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(botq) : "v"(upq), "v"(nw[0]), "v"(smask));
+        if constexpr (P0)          botq = nw[R - 1];
+        else if constexpr (R >= 2) asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(botq) : "v"(nw[R - 2]), "v"(nw[R - 1]), "v"(smask));
+        else                       asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(botq) : "v"(upq), "v"(nw[0]), "v"(smask));
         *hslot = nw[R - 1];                         // (only lane L-1's lands in hbuf)
     };
     for (int blk = 0; blk < nblk; blk++) {
@@ -290,8 +292,10 @@ void k_sdtw_q(const sdtw_kargs a)
             }
         }
         F = toq(rawnext, (blk + 1) * L + l);
-        const int j = t0 + l - (L - 1);             // lane L-1's column at step t0 + l
-        if (j >= 0 && j < n) { const unsigned hv = hbuf[l]; lastq[j] = hv; smin = min(smin, hv); }
+        // lane L-1's column at step t0 + l is t0 + l - (L - 1).  Rows of lastq carry L columns of padding in front and
+        // 2 L behind, so every lane stores without a range test; columns outside the read hold costs of 2^30 units
+        // and more (their sample is "infinite"), which neither the summaries nor pass P's column test (j < n) mind.
+        { const unsigned hv = hbuf[l]; lastq[t0 + l + 1] = hv; smin = min(smin, hv); }
     }
     // the columns after the last checkpoint
     {
@@ -377,7 +381,7 @@ void k_sdtw_p(const sdtw_kargs a)
             const int j0 = cc * a.ck + l - (L - 1);
             for (int q = 0; q < a.ck / L; q++) {
                 const int j = j0 + q * L;
-                if (j >= 0 && j < n && lastq[j] <= thr) { jlo = min(jlo, j); jhi = max(jhi, j); }
+                if (j >= 0 && j < n && lastq[j + L] <= thr) { jlo = min(jlo, j); jhi = max(jhi, j); }   // (rows start L early)
             }
         }
     }
@@ -692,7 +696,8 @@ typedef void (*sdtw_fn)(const sdtw_kargs);
 template <int L, int FEED, int WHICH>
 sdtw_fn pick_r(int R)
 {
-#define SK_CASE(RR) case RR: return WHICH == 0 ? (sdtw_fn)k_sdtw_q<L, RR, FEED> : \
+#define SK_CASE(RR) case RR: return WHICH == 0 ? (sdtw_fn)k_sdtw_q<L, RR, FEED, false> : \
+                                   WHICH == 3 ? (sdtw_fn)k_sdtw_q<L, RR, FEED, (RR >= 2)> : \
                                    WHICH == 1 ? (sdtw_fn)k_sdtw_p<L, RR, FEED> : (sdtw_fn)k_sdtw_w<L, RR, FEED>;
     switch (R) {
         SK_CASE(1) SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5) SK_CASE(6) SK_CASE(7) SK_CASE(8)
@@ -730,6 +735,7 @@ void *sk_sdtwq_pick_feed2(int which, int L, int R)
     switch (which) {
     case 0: return (void *)pick_l<0, SK_SDTWQ_FEED>(L, R);
     case 1: return (void *)pick_l<1, SK_SDTWQ_FEED>(L, R);
+    case 3: return (void *)pick_l<3, SK_SDTWQ_FEED>(L, R);       // pass Q without short lanes
     default: return (void *)pick_l<2, SK_SDTWQ_FEED>(L, R);
     }
 }
@@ -788,7 +794,7 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
 
     const int64_t maxlen = a->max_len;
     const int nck = (int)((maxlen + L - 1) / ck);
-    const size_t lq_stride = (size_t)((maxlen + 3) & ~(int64_t)3);
+    const size_t lq_stride = (size_t)((maxlen + 3 * L + 7) & ~(int64_t)3);      // L columns of padding in front, 2 L behind
     const size_t state_bytes = (size_t)L * (R + 2) * sizeof(unsigned);
     const size_t per_read = (size_t)(nck > 0 ? nck : 1) * state_bytes + lq_stride * sizeof(unsigned) + state_bytes +
                             (size_t)(nck + 1) * L * sizeof(unsigned) + 64;
@@ -811,7 +817,7 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
     typedef void *(*pick_fn)(int, int, int);
     const pick_fn pk = a->feed == SK_FEED_I16 ? (pick_fn)sk_sdtwq_pick_feed0
                      : a->feed == SK_FEED_F64_NORM ? (pick_fn)sk_sdtwq_pick_feed1 : (pick_fn)sk_sdtwq_pick_feed2;
-    sdtw_fn fq = (sdtw_fn)pk(0, L, R), fp = (sdtw_fn)pk(1, L, R), fw = (sdtw_fn)pk(2, L, R);
+    sdtw_fn fq = (sdtw_fn)pk(P == 0 ? 3 : 0, L, R), fp = (sdtw_fn)pk(1, L, R), fw = (sdtw_fn)pk(2, L, R);
     if (!fq || !fp || !fw) return sk_fail(SK_ERR_UNSUPPORTED, "no screening kernel for L=%d R=%d", L, R);
 
     sdtw_kargs k;
