@@ -555,15 +555,16 @@ void k_sdtw_w(const sdtw_kargs a)
     const int nblk = (nsteps + L - 1) / L;
 
     double x[XLDS ? 1 : R];
-    __shared__ double lds_x[XLDS ? L * R : 1];
+    constexpr int RP = R | 1;                       // odd row pitch: the lanes of a group land in different LDS banks
+    __shared__ double lds_x[XLDS ? L * RP : 1];     // (R = 32, L = 16: a pitch of 256 bytes put all 16 on one bank)
     if constexpr (XLDS) {
-        for (int i = threadIdx.x; i < L * R; i += blockDim.x) lds_x[i] = a.xlay[i];
+        for (int i = threadIdx.x; i < L * R; i += blockDim.x) lds_x[(i / R) * RP + i % R] = a.xlay[i];
         __syncthreads();
     } else {
 #pragma unroll
         for (int k = 0; k < R; k++) x[k] = a.xlay[l * R + k];
     }
-    const double *xl = lds_x + (XLDS ? l * R : 0);
+    const double *xl = lds_x + (XLDS ? l * RP : 0);
 
     const int nlast = max(n - 1, 0);
     if (n == 0) { s16 = (const int16_t *)a.xlay; s64 = (const double *)a.xlay; }       // any valid address
@@ -744,10 +745,13 @@ void *sk_sdtwq_pick_feed2(int which, int L, int R)
 void *sk_sdtwq_pick_feed1(int which, int L, int R);
 void *sk_sdtwq_pick_feed2(int which, int L, int R);
 
-// lanes per read of the screening scheme for an N-point motif (SK_DTW_QL = 8 / 16 / 64: A/B runs)
-static void screen_layout(int N, int *L, int *R)
+// lanes per read of the screening scheme for an N-point motif (SK_DTW_QL = 8 / 16 / 64: A/B runs).  The long lanes
+// of L = 8 pay off once the batch fills the chip with them (8 reads per wavefront: measured 1.75 / 1.45 / 1.50 ms
+// with 8 / 16 / 64 lanes at 10 000 reads x 163 points, 2.06 / 1.80 / 2.45 at 20 000 x 200, level from 40 000 on,
+// 8 ahead at 1 M).
+static void screen_layout(int N, int64_t nreads, int *L, int *R)
 {
-    int l = (N <= 8 * 32) ? 8 : (N <= 16 * 32) ? 16 : 64;
+    int l = (N <= 8 * 32 && nreads >= 49152) ? 8 : (N <= 16 * 32) ? 16 : 64;
     if (const char *e = getenv("SK_DTW_QL")) {
         const int v = atoi(e);
         if ((v == 8 && N <= 8 * 32) || (v == 16 && N <= 16 * 32) || v == 64) l = v;
@@ -765,7 +769,7 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
 {
     const int N = a->nmotif;
     int L, R;
-    screen_layout(N, &L, &R);
+    screen_layout(N, a->nreads, &L, &R);
     const int P = L * R - N;
     // quantised motif and the exact one in this scheme's per-lane layout (the exact kernels keep their own);
     // resident like them (the caller invalidates when the motif changes), so a call makes no host-side synchronisation
