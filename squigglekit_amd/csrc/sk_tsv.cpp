@@ -93,6 +93,66 @@ inline int conv(const char *p, const char *e, double *out, int *isint)
 
 struct LineInfo { const char *b, *e; };
 
+// Line starts of one buffer, found on several threads (every thread scans its slice for newlines) and kept per host
+// thread between sk_tsv_count_lines / _count_tokens / _parse*, which a caller runs one after the other on the same
+// chunk: three serial memchr passes over the chunk had become most of the tokenizer's time.
+struct LineIndex {
+    const char *buf = nullptr;
+    size_t len = 0;
+    uint64_t print = 0;                // fingerprint of the bytes (an allocator may hand the same address out again)
+    std::vector<int64_t> off;          // off[i] = start of line i; off[n] = len
+};
+thread_local LineIndex g_lines;
+
+uint64_t fingerprint(const char *buf, size_t len)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)len;
+    for (int k = 0; k < 16 && len >= 8; k++) {
+        uint64_t w;
+        memcpy(&w, buf + (len - 8) * (size_t)k / 15, 8);
+        h = (h ^ w) * 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 29;
+    }
+    return h;
+}
+
+// fresh: rebuild even if the cached index looks like this buffer's (sk_tsv_count_lines, the first call on a chunk)
+const LineIndex &line_index(const char *buf, size_t len, bool fresh = false)
+{
+    LineIndex &L = g_lines;
+    const uint64_t fp = fingerprint(buf, len);
+    if (!fresh && L.buf == buf && L.len == len && L.print == fp && !L.off.empty()) return L;
+    L.buf = buf; L.len = len; L.print = fp; L.off.clear();
+    int T = (int)std::thread::hardware_concurrency();
+    if (T > 16) T = 16;
+    if ((size_t)T > len / (1u << 20) + 1) T = (int)(len / (1u << 20)) + 1;
+    if (T < 1) T = 1;
+    std::vector<std::vector<int64_t>> part((size_t)T);
+    auto scan = [&](int t) {
+        const size_t a = len * (size_t)t / (size_t)T, b = len * (size_t)(t + 1) / (size_t)T;
+        std::vector<int64_t> &v = part[(size_t)t];
+        const char *p = buf + a, *end = buf + b;
+        while (p < end) {
+            const char *q = (const char *)memchr(p, '\n', (size_t)(end - p));
+            if (!q) break;
+            v.push_back((int64_t)(q - buf) + 1);         // a line starts behind every newline
+            p = q + 1;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(scan, t);
+    scan(0);
+    for (auto &x : th) x.join();
+    size_t total = 1;
+    for (auto &v : part) total += v.size();
+    L.off.reserve(total + 1);
+    if (len > 0) L.off.push_back(0);
+    for (auto &v : part) L.off.insert(L.off.end(), v.begin(), v.end());
+    if (!L.off.empty() && L.off.back() == (int64_t)len) L.off.pop_back();   // the file's last newline starts no line
+    L.off.push_back((int64_t)len);                                          // sentinel: off[n] = len
+    return L;
+}
+
 } // namespace
 
 extern "C" {
@@ -101,15 +161,7 @@ extern "C" {
 int64_t sk_tsv_count_lines(const char *buf, size_t len)
 {
     if (!buf) return -1;
-    int64_t n = 0;
-    const char *p = buf, *end = buf + len;
-    while (p < end) {
-        const char *q = (const char *)memchr(p, '\n', (size_t)(end - p));
-        n++;
-        if (!q) break;
-        p = q + 1;
-    }
-    return n;
+    return (int64_t)line_index(buf, len, true).off.size() - 1;
 }
 
 // Count the tokens from column start_col on, per line, so the caller can size `values`.
@@ -118,20 +170,14 @@ int sk_tsv_count_tokens(const char *buf, size_t len, int32_t start_col, int64_t 
                         int32_t nthreads)
 {
     if (!buf || !ntok || start_col < 0 || nlines < 0) return SK_ERR_INVALID;
-    std::vector<LineInfo> lines((size_t)nlines);
-    {
-        const char *p = buf, *end = buf + len;
-        for (int64_t i = 0; i < nlines; i++) {
-            const char *q = (const char *)memchr(p, '\n', (size_t)(end - p));
-            lines[(size_t)i].b = p;
-            lines[(size_t)i].e = q ? q : end;
-            p = q ? q + 1 : end;
-        }
-    }
+    const LineIndex &LI = line_index(buf, len);
+    if ((int64_t)LI.off.size() - 1 != nlines) return SK_ERR_INVALID;
+    const int64_t *lo = LI.off.data();
     if (nthreads < 1) nthreads = 1;
     auto work = [&](int t) {
         for (int64_t i = t; i < nlines; i += nthreads) {
-            const char *p = lines[(size_t)i].b, *e = lines[(size_t)i].e;
+            const char *p = buf + lo[i], *e = buf + lo[i + 1];
+            if (e > p && e[-1] == '\n') e--;
             int64_t tabs = 0;
             for (const char *s = p; s < e; s++) tabs += (*s == '\t');
             const int64_t cols = tabs + 1;
@@ -220,13 +266,9 @@ int sk_tsv_parse_i16(const char *buf, size_t len, int32_t start_col, int64_t nli
     if (!buf || !rows || !nsamp || !flags || !line_off || start_col < 0 || nlines < 0 || stride <= 0)
         return SK_ERR_INVALID;
     {
-        const char *p = buf, *end = buf + len;
-        for (int64_t i = 0; i < nlines; i++) {
-            const char *q = (const char *)memchr(p, '\n', (size_t)(end - p));
-            line_off[i] = p - buf;
-            p = q ? q + 1 : end;
-        }
-        line_off[nlines] = (int64_t)len;
+        const LineIndex &LI = line_index(buf, len);
+        if ((int64_t)LI.off.size() - 1 != nlines) return SK_ERR_INVALID;
+        memcpy(line_off, LI.off.data(), (size_t)(nlines + 1) * sizeof(int64_t));
     }
     if (nthreads < 1) nthreads = 1;
     auto work = [&](int t) {

@@ -136,6 +136,7 @@ class _Batcher:
         self.sigs.append(None)
 
     def flush(self):
+        self.drain()                                  # (a pipelined block's table comes first)
         if not self.sigs:
             return
         a = self.args
@@ -264,19 +265,21 @@ class _Batcher:
         if a.after_stall:
             fast[:] = False                                                 # (needs the raw reads on the host)
         idx = np.flatnonzero(fast)
+        if idx.size == blk.n and blk.n and not a.sig_extract:
+            # every line of the chunk is a plain integer read: one GPU batch, the whole table in one native call,
+            # pipelined with the next chunk (rows())
+            no = blk.base + blk._no.astype(np.int64)
+            io = blk.base + blk._io.astype(np.int64)
+            self.rows(blk.rows, blk.nsamp, ("span", blk.buf, np.stack([no, no + blk._nl], axis=1)),
+                      ("span", blk.buf, np.stack([io, io + blk._il], axis=1)), blk.name, blk.read_id)
+            return
+        self.drain()                                                        # (what follows prints directly)
         res, hits = {}, None
         if idx.size:
             rows = blk.rows[idx] if idx.size != blk.n else blk.rows
             hits = api.motifseq_multi_batch(rows, blk.nsamp[idx], [np.asarray(self.models[n], dtype=np.float64)
                                                                     for n in self.order],
                                             a.scale, a.scale_low, a.scale_hi)
-            if idx.size == blk.n:
-                # every line of the chunk is a plain integer read: the whole table in one native call
-                no = blk.base + blk._no.astype(np.int64)
-                io = blk.base + blk._io.astype(np.int64)
-                if self.table(blk.n, ("span", blk.buf, np.stack([no, no + blk._nl], axis=1)),
-                              ("span", blk.buf, np.stack([io, io + blk._il], axis=1)), hits):
-                    return
             res = {int(i): k for k, i in enumerate(idx)}
             # the scoring of MotifSeq.py:441-445 for the whole chunk at once (the same IEEE operations as the
             # per-row arithmetic of emit(), so the same digits), then plain Python numbers for the formatting

@@ -93,6 +93,7 @@ class _Batcher:
         print("\t".join([name, ",".join(str(v) for pair in segs for v in pair)]))
 
     def flush(self):
+        self.drain()                                  # (a pipelined block's table comes first)
         if not self.sigs:
             return
         live = [s for s in self.sigs if s is not None]
@@ -148,6 +149,12 @@ class _Batcher:
         Num = self.args.Num
         fast = (blk.flags & 27) == 3                                        # ALLINT | ANY, not SLOW / SHORT
         idx = np.flatnonzero(fast)
+        if idx.size == blk.n and blk.n and not self.args.test:
+            # every line is a plain integer read: one GPU batch, one native table, pipelined with the next chunk
+            no = blk.base + blk._no.astype(np.int64)
+            self.rows(blk.rows, blk.nsamp, ("span", blk.buf, np.stack([no, no + blk._nl], axis=1)), blk.name)
+            return
+        self.drain()                                                        # (what follows prints directly)
         res = {}
         if idx.size:
             ns = blk.nsamp[idx]

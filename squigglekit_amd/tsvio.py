@@ -179,9 +179,13 @@ class TsvBlock:
         return _parse_block_float((self.buf, self.base, self.end), start_col, nthreads or min(32, os.cpu_count() or 1))
 
 
-def iter_tsv_blocks_i16(path, start_col, chunk_bytes=48 << 20, nthreads=None):
+def iter_tsv_blocks_i16(path, start_col, chunk_bytes=48 << 20, nthreads=None, prefetch=True):
     """Stream a SquigglePull TSV as TsvBlock chunks (csrc/sk_tsv.cpp: sk_tsv_parse_i16): integer lines land in
-    int16 rows without a float64 detour or a Python object per read."""
+    int16 rows without a float64 detour or a Python object per read.  With `prefetch` the next chunk is tokenised on
+    a background thread (the tokenizer releases the GIL) while the caller works on the current one."""
+    if prefetch:
+        yield from _prefetched(iter_tsv_blocks_i16(path, start_col, chunk_bytes, nthreads, prefetch=False))
+        return
     import os
     from . import _lib
     L = _lib.load()
@@ -209,6 +213,31 @@ def iter_tsv_blocks_i16(path, start_col, chunk_bytes=48 << 20, nthreads=None):
                                       _lib.ptr(name_off), _lib.ptr(name_len), _lib.ptr(id_off), _lib.ptr(id_len),
                                       _lib.ptr(flags), _lib.ptr(line_off), nthreads))
         yield TsvBlock(chunk, rows, nsamp, flags, name_off, name_len, id_off, id_len, line_off)
+
+
+def _prefetched(gen, depth=2):
+    """Items of `gen`, produced up to `depth` ahead on a background thread; an exception of the producer is re-raised
+    at the place of the item it replaced."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    done = object()
+
+    def run():
+        try:
+            for item in gen:
+                q.put((item, None))
+        except BaseException as e:                      # noqa: BLE001 -- handed to the consumer
+            q.put((None, e))
+        q.put((done, None))
+    threading.Thread(target=run, name="sk-tsv-prefetch", daemon=True).start()
+    while True:
+        item, err = q.get()
+        if err is not None:
+            raise err
+        if item is done:
+            return
+        yield item
 
 
 # ----------------------------------------------------------------------------
