@@ -123,7 +123,7 @@ int sk_comm_init_all(const int *devices, int ndev)
     ncclComm_t comms[SK_MAX_DEVICES];
     SK_NCCL(R, R->CommInitAll(comms, ndev, devices));
     for (int i = 0; i < ndev; i++) sk_ctx_of(devices[i])->comm = comms[i];
-    if (before >= 0) return sk_init(before);             // the calling thread keeps its binding
+    if (before >= 0) return sk_init_slot(before, sk_ctx_of(before)->device);   // the calling thread keeps its binding
     return SK_OK;
 }
 
