@@ -87,3 +87,39 @@ def test_blow5_native_decoder_reads_the_reference_example():
     blks = list(fastio.iter_blow5_blocks_i16(path))
     assert len(blks) == 1 and blks[0].n == 1 and blks[0].nsamp[0] == want["signal"].size == 36978
     assert np.array_equal(blks[0].rows[0, :36978], want["signal"]) and blks[0].ids[0].decode() == want["read_id"]
+
+
+def test_npy_block_reader_equals_numpy(tmp_path):
+    """iter_npy_blocks_i16 (parallel preads into reused buffers; page-locked ones when a GPU is there, plain memory
+    here): every row arrives once, in order, whatever the block size; wrong dtypes are refused."""
+    from squigglekit_amd import fastio
+    rng = np.random.default_rng(8)
+    arr = rng.integers(-2000, 2000, (1237, 301)).astype(np.int16)
+    np.save(tmp_path / "a.npy", arr)
+    for block_bytes in (301 * 2 * 100, 301 * 2 * 5000, 301 * 2 * 413):
+        seen = 0
+        for lo, part in fastio.iter_npy_blocks_i16(str(tmp_path / "a.npy"), block_bytes=block_bytes, nthreads=3):
+            assert lo == seen and np.array_equal(part, arr[lo:lo + part.shape[0]])
+            seen += part.shape[0]
+        assert seen == arr.shape[0]
+    np.save(tmp_path / "f.npy", arr.astype(np.float32))
+    with pytest.raises(ValueError):
+        next(fastio.iter_npy_blocks_i16(str(tmp_path / "f.npy")))
+    np.save(tmp_path / "e.npy", np.zeros((0, 16), dtype=np.int16))
+    assert list(fastio.iter_npy_blocks_i16(str(tmp_path / "e.npy"))) == []
+
+
+def test_prefetch_keeps_order_and_hands_errors_over():
+    from squigglekit_amd import tsvio
+
+    def gen(n, fail_at=None):
+        for i in range(n):
+            if i == fail_at:
+                raise RuntimeError("producer failed at %d" % i)
+            yield i
+    assert list(tsvio._prefetched(gen(50))) == list(range(50))
+    got = []
+    with pytest.raises(RuntimeError, match="failed at 7"):
+        for x in tsvio._prefetched(gen(20, fail_at=7)):
+            got.append(x)
+    assert got == list(range(7))
