@@ -121,6 +121,33 @@ struct wrec {
     int32_t flags;      // 1: screened (a window exists)  2: the state was restored from a checkpoint
 };
 
+// Candidate columns of read r: [jlo, jhi] = the first and the last column whose screening cost is within 2E of the
+// screening minimum b (jhi < jlo: none).  Pass Q left, per checkpoint interval c and lane l', the minimum over the
+// last-row columns c * ck + q * L + l' - (L - 1), q = 0 .. ck / L - 1: only intervals whose summary is within the
+// threshold can hold a candidate, so a read costs (nck + 1) * L summary words here instead of its whole last row.
+// Every lane of the read's group calls this with its own l and gets the group's result.
+template <int L>
+__device__ __forceinline__ void candidate_columns(const sdtw_kargs &a, int r, int n, unsigned b, int l, int &jlo_out, int &jhi_out)
+{
+    const unsigned *lastq = a.lastq + (int64_t)(r - a.read0) * a.lq_stride;
+    const unsigned *ls = a.lsum + (int64_t)(r - a.read0) * (a.nck + 1) * L + l;
+    const unsigned thr = (b > QINF - 2u * a.qerr) ? QINF : b + 2u * a.qerr;
+    int jlo = 0x7fffffff, jhi = -1;
+    if (n > 0 && b < QSAFE) {
+        for (int cc = 0; cc <= a.nck; cc++) {
+            if (ls[(int64_t)cc * L] > thr) continue;
+            const int j0 = cc * a.ck + l - (L - 1);
+            for (int q = 0; q < a.ck / L; q++) {
+                const int j = j0 + q * L;
+                if (j >= 0 && j < n && lastq[j + L] <= thr) { jlo = min(jlo, j); jhi = max(jhi, j); }   // (rows start L early)
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < L; d <<= 1) { jlo = min(jlo, __shfl_xor(jlo, d)); jhi = max(jhi, __shfl_xor(jhi, d)); }
+    jlo_out = jlo; jhi_out = jhi;
+}
+
 // ---------------------------------------------------------------------------------------------
 // pass Q
 // ---------------------------------------------------------------------------------------------
@@ -317,7 +344,17 @@ void k_sdtw_q(const sdtw_kargs a)
         bad |= __shfl_xor(bad, d);
         qmin = min(qmin, (unsigned)__shfl_xor((int)qmin, d));
     }
-    if (live && l == 0) a.qflag[r - a.read0] = (int32_t)(bad ? QINF : qmin);
+    const unsigned bq = bad ? QINF : qmin;
+    if (live && l == 0) a.qflag[r - a.read0] = (int32_t)bq;
+    if (a.wrec) {                                   // epilogue: the candidate columns, for the first tier of pass P
+        int jlo, jhi;
+        candidate_columns<L>(a, r, n, bq, l, jlo, jhi);
+        if (live && l == 0) {
+            wrec w;
+            w.tbase = 0; w.jlo = jlo; w.jhi = jhi; w.flags = 0;
+            ((wrec *)a.wrec)[slot] = w;
+        }
+    }
     if (timer && lane == 0) {
         a.clk[0] = __builtin_amdgcn_s_memtime() - tc0;
         a.clk[1] = __builtin_amdgcn_s_memrealtime() - tr0;
@@ -367,26 +404,16 @@ void k_sdtw_p(const sdtw_kargs a)
     if (!live) n = 0;
 
     // ---- candidate columns: screening cost within 2E of the screening minimum ----------------
-    // Pass Q left, per checkpoint interval c and lane l', the minimum over the last-row columns
-    // c * ck + q * L + l' - (L - 1), q = 0 .. ck / L - 1: only intervals whose summary is within the threshold can
-    // hold a candidate, so a read costs (nck + 1) * L summary words here instead of its whole last row.
-    const unsigned *lastq = a.lastq + (int64_t)(r - a.read0) * a.lq_stride;
-    const unsigned *ls = a.lsum + (int64_t)(r - a.read0) * (a.nck + 1) * L + l;
+    // The first tier finds them in pass Q's epilogue (the read's wave scans the interval minima it has just written:
+    // latency that the other waves' sweeps hide); a second-tier launch looks again (its reads come from a list).
     const unsigned b = (unsigned)a.qflag[r - a.read0];   // the screening minimum (pass Q), QINF: not usable
-    const unsigned thr = (b > QINF - 2u * a.qerr) ? QINF : b + 2u * a.qerr;
-    int jlo = 0x7fffffff, jhi = -1;
-    if (n > 0 && b < QSAFE) {
-        for (int cc = 0; cc <= a.nck; cc++) {
-            if (ls[(int64_t)cc * L] > thr) continue;
-            const int j0 = cc * a.ck + l - (L - 1);
-            for (int q = 0; q < a.ck / L; q++) {
-                const int j = j0 + q * L;
-                if (j >= 0 && j < n && lastq[j + L] <= thr) { jlo = min(jlo, j); jhi = max(jhi, j); }   // (rows start L early)
-            }
-        }
+    int jlo, jhi;
+    if (a.wl_list == nullptr) {
+        const wrec q = ((const wrec *)a.wrec)[slot];
+        jlo = q.jlo; jhi = q.jhi;
+    } else {
+        candidate_columns<L>(a, r, n, b, l, jlo, jhi);
     }
-#pragma unroll
-    for (int d = 1; d < L; d <<= 1) { jlo = min(jlo, __shfl_xor(jlo, d)); jhi = max(jhi, __shfl_xor(jhi, d)); }
     const bool screened = (n > 0) && (b < QSAFE) && (jhi >= jlo) && (jhi - jlo <= a.wmax);
 
     int tbase = 0, c0 = 0, npre = 0;
