@@ -35,6 +35,8 @@ struct sk_ctx {
     bool        ready = false;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;    // second stream (created on first use): overlapped walks / copies
+    hipStream_t stream3 = nullptr;    // third stream (created on first use): the early exact retry beside the window passes
+    hipEvent_t  ev_r[2] = {nullptr, nullptr};   // its ordering events: pass Q done / early retry done
     hipEvent_t  ev_chunk[9] = {};     // ordering events between the two streams (no timing)
     hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};   // prep start/stop, main start/stop
     bool        ev_valid = false;
@@ -153,7 +155,7 @@ struct sk_sdtw_args {
 int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a);
 // fixed-point screening + certified window over all reads (sk_sdtwq.hip); leaves the retry list on the device
 int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, int span2,
-                          int32_t *d_retry_cnt, int32_t *d_retry);
+                          int32_t *d_retry_cnt, int32_t *d_retry, int32_t *d_early_cnt, int32_t *d_early);
 
 // ---- dRNA --signal branch (rolling mean): statistics + masks (sk_prep.hip), scan (sk_segment.hip) ----
 struct sk_roll_params;

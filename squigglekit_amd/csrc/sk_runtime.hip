@@ -143,6 +143,11 @@ int sk_shutdown(void)
             for (int i = 0; i < 9; i++) if (c->ev_chunk[i]) (void)hipEventDestroy(c->ev_chunk[i]);
             (void)hipStreamDestroy(c->stream2);
         }
+        if (c->stream3) {
+            (void)hipStreamSynchronize(c->stream3);
+            for (int i = 0; i < 2; i++) if (c->ev_r[i]) (void)hipEventDestroy(c->ev_r[i]);
+            (void)hipStreamDestroy(c->stream3);
+        }
         (void)hipStreamDestroy(c->stream);
         *c = sk_ctx();
     }

@@ -325,12 +325,12 @@ sdtw_fn pick_any(int feed, int L, int R, int mode)
     return nullptr;
 }
 
-int launch(sk_ctx *c, sdtw_fn fn, const sdtw_kargs &k, int L)
+int launch(sk_ctx *c, sdtw_fn fn, const sdtw_kargs &k, int L, hipStream_t stream = nullptr)
 {
     if (k.nreads <= 0) return SK_OK;
     const int reads_per_block = 4 * (64 / L);
     const int grid = (k.nreads + reads_per_block - 1) / reads_per_block;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, c->stream, k);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, stream ? stream : c->stream, k);
     SK_HIP(hipGetLastError());
     return SK_OK;
 }
@@ -552,49 +552,70 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
     // worst case and return at once where the list ends.  A short list is latency-bound, so its first 8 192
     // entries are swept with each read spread over 64 lanes; whatever lies beyond uses the batch layout.
     int rc;
-    if ((rc = sk_reserve(c, &c->retry, ((size_t)a->nreads + 2) * sizeof(int32_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->retry, 2 * ((size_t)a->nreads + 2) * sizeof(int32_t)))) return rc;
     if ((rc = sk_reserve(c, &c->dtwcnt, 64))) return rc;
     int32_t *cnt = (int32_t *)c->retry.p;                  // [0] = counter, [2..] = read indices
+    int32_t *ecnt = cnt + a->nreads + 2;                   // a second list of the same shape: the early retry's
     SK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), c->stream));
+    SK_HIP(hipMemsetAsync(ecnt, 0, sizeof(int32_t), c->stream));
     if (!a->accumulate) SK_HIP(hipMemsetAsync(c->dtwcnt.p, 0, 32, c->stream));   // [0] retried, [1] second tier, +16: clock
     c->retry_dev = true;
-    auto launch_retry = [&]() -> int {
+    // the motif laid out for 64 lanes (the short retry list is swept with a read per wavefront): uploaded here, ahead
+    // of everything the call enqueues, because the early retry runs on another stream
+    if (L == 16 && !c->motif64_valid && pick_any(a->feed, 64, (N + 63) / 64, MODE_FULL)) {
+        const int R64 = (N + 63) / 64, P64 = 64 * R64 - N;
+        SK_HIP(hipStreamSynchronize(c->stream));          // an earlier launch may still read it
+        if (c->stream3) SK_HIP(hipStreamSynchronize(c->stream3));
+        c->motif64_host.assign((size_t)64 * R64, 0.0);
+        int row = 0;
+        for (int l = 0; l < 64; l++) {
+            const int rows = (l < P64) ? R64 - 1 : R64;
+            for (int kk = 0; kk < rows; kk++) c->motif64_host[(size_t)l * R64 + kk] = a->motif[row++];
+        }
+        if ((rc = sk_reserve(c, &c->motif64, c->motif64_host.size() * sizeof(double)))) return rc;
+        SK_HIP(hipMemcpyAsync(c->motif64.p, c->motif64_host.data(),
+                              c->motif64_host.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        c->motif64_valid = true;
+    }
+    auto launch_retry = [&](int32_t *list = nullptr, hipStream_t stream = nullptr) -> int {
+        if (!list) list = cnt;
         sdtw_kargs kr = k;
-        kr.read0 = 0; kr.ridx = cnt + 2; kr.count_ptr = cnt; kr.ckpt = nullptr;
+        kr.read0 = 0; kr.ridx = list + 2; kr.count_ptr = list; kr.ckpt = nullptr;
         kr.total_ptr = (int32_t *)c->dtwcnt.p; kr.list_off = 0;
         const int R64 = (N + 63) / 64, P64 = 64 * R64 - N;
         sdtw_fn f64 = (L == 16) ? pick_any(a->feed, 64, R64, MODE_FULL) : nullptr;
         if (f64) {
-            if (!c->motif64_valid) {
-                SK_HIP(hipStreamSynchronize(c->stream));      // an earlier launch may still read it
-                c->motif64_host.assign((size_t)64 * R64, 0.0);
-                int row = 0;
-                for (int l = 0; l < 64; l++) {
-                    const int rows = (l < P64) ? R64 - 1 : R64;
-                    for (int kk = 0; kk < rows; kk++) c->motif64_host[(size_t)l * R64 + kk] = a->motif[row++];
-                }
-                int rc2;
-                if ((rc2 = sk_reserve(c, &c->motif64, c->motif64_host.size() * sizeof(double)))) return rc2;
-                SK_HIP(hipMemcpyAsync(c->motif64.p, c->motif64_host.data(),
-                                      c->motif64_host.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-                c->motif64_valid = true;
-            }
             sdtw_kargs k64 = kr;
             k64.xlay = (const double *)c->motif64.p; k64.P = P64;
             k64.nreads = a->nreads < 8192 ? a->nreads : 8192;
             int rc2;
-            if ((rc2 = launch(c, f64, k64, 64))) return rc2;
+            if ((rc2 = launch(c, f64, k64, 64, stream))) return rc2;
             if (a->nreads <= 8192) return SK_OK;
             kr.list_off = 8192; kr.total_ptr = nullptr; kr.nreads = a->nreads - 8192;
-            return launch(c, ff, kr, L);
+            return launch(c, ff, kr, L, stream);
         }
         kr.nreads = a->nreads;
-        return launch(c, ff, kr, L);
+        return launch(c, ff, kr, L, stream);
     };
     if (a->fuse && !qok) return sk_fail(SK_ERR_INVALID, "internal: fused prologue without a screening pass");
     if (qok) {
-        if ((rc = sk_launch_sdtw_screen(c, a, ck, span_q, span2, cnt, cnt + 2))) return rc;
+        // The reads pass Q itself finds unscreenable (on the C4 batch: all of the ~190 that retry) get their exact
+        // pass on a third stream as soon as pass Q is done -- one sweep's latency (0.5 ms) that then runs beside the
+        // window passes instead of behind them; what the window passes give up on follows as before.
+        const bool early = getenv("SK_DTW_NO_EARLY") == nullptr;
+        if (early && !c->stream3) {
+            SK_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+            for (int i = 0; i < 2; i++) SK_HIP(hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming));
+        }
+        if ((rc = sk_launch_sdtw_screen(c, a, ck, span_q, span2, cnt, cnt + 2, early ? ecnt : nullptr,
+                                        early ? ecnt + 2 : nullptr))) return rc;
+        if (early) {
+            SK_HIP(hipStreamWaitEvent(c->stream3, c->ev_r[0], 0));
+            if ((rc = launch_retry(ecnt, c->stream3))) return rc;
+            SK_HIP(hipEventRecord(c->ev_r[1], c->stream3));
+        }
         if ((rc = launch_retry())) return rc;
+        if (early) SK_HIP(hipStreamWaitEvent(c->stream, c->ev_r[1], 0));
         SK_HIP(hipEventRecord(c->ev[3], c->stream));
         return SK_OK;
     }

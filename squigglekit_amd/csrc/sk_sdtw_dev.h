@@ -80,6 +80,8 @@ struct sdtw_kargs {
     const int16_t *fz_raw;      // raw rows (same stride), or nullptr: prep / samples were filled by an earlier kernel
     const int32_t *fz_len;
     int            fz_lo, fz_hi, fz_vec;
+    int32_t       *early;       // reads pass Q already knows cannot be screened (candidate range too wide, samples out of
+    int32_t       *early_cnt;   // range): their exact retry starts right behind pass Q, beside the window passes
     unsigned long long *clk;    // pass Q: {shader cycles, 100 MHz reference ticks} of the first wave's sweep, or nullptr
     int            force_retry; // sensitivity runs: reads whose hash (10 bits) is below this take the exact retry
     // window pass, second tier: the reads of one chunk whose path crossed the first (short) look-back

@@ -353,6 +353,10 @@ void k_sdtw_q(const sdtw_kargs a)
             wrec w;
             w.tbase = 0; w.jlo = jlo; w.jhi = jhi; w.flags = 0;
             ((wrec *)a.wrec)[slot] = w;
+            // a read the window passes cannot take (no usable minimum, candidates too far apart) goes to the exact
+            // retry -- which starts now, beside the window passes, instead of behind them
+            const bool screened = (bq < QSAFE) && (jhi >= jlo) && (jhi - jlo <= a.wmax);
+            if (a.early_cnt && n > 0 && !screened) a.early[atomicAdd(a.early_cnt, 1)] = r;
         }
     }
     if (timer && lane == 0) {
@@ -710,6 +714,8 @@ void k_sdtw_w(const sdtw_kargs a)
         } else if (screened && bestS >= 0 && !forced) {
             h.dist = best; h.start = bestS; h.end = bestJ;
             a.out[r] = h;
+        } else if (!screened && a.early_cnt) {
+            // (pass Q listed this read for the early exact retry, which writes its record -- perhaps right now)
         } else {
             h.dist = __builtin_nan(""); h.start = -1; h.end = -1;    // overwritten by a later pass
             a.out[r] = h;
@@ -792,7 +798,7 @@ static void screen_layout(int N, int64_t nreads, int *L, int *R)
 // span / span2: look-back of the window pass's first tier (every read) and of its second tier (the reads whose
 // optimal path turned out wider than `span`); span2 <= span: one tier only.
 int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, int span2,
-                          int32_t *d_retry_cnt, int32_t *d_retry)
+                          int32_t *d_retry_cnt, int32_t *d_retry, int32_t *d_early_cnt, int32_t *d_early)
 {
     const int N = a->nmotif;
     int L, R;
@@ -859,6 +865,7 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
     k.ckq = (unsigned *)c->ckpt.p; k.lastq = (unsigned *)c->lastq.p; k.lq_stride = (int64_t)lq_stride;
     k.qflag = (int32_t *)c->qflag.p; k.lsum = (unsigned *)c->lsum.p;
     k.wstate = (unsigned *)c->wstate.p; k.wrec = c->wrec.p;
+    k.early_cnt = d_early_cnt; k.early = d_early;
     k.qerr = (unsigned)(N + maxlen + 2);
     k.wmax = 4 * ck;
     if (const char *e = getenv("SK_DTW_FORCE_RETRY_PM")) {       // sensitivity runs: per-mille of reads sent to the retry
@@ -893,6 +900,7 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
         k.clk = (r0 == 0) ? (unsigned long long *)((char *)c->dtwcnt.p + 16) : nullptr;
         hipLaunchKernelGGL(fq, dim3(grid), dim3(256), fz_lds, c->stream, k);
         k.fz_raw = nullptr;                                 // (the later passes only read)
+        if (d_early_cnt && r0 + chunk >= a->nreads) SK_HIP(hipEventRecord(c->ev_r[0], c->stream));   // last pass Q done
         SK_HIP(hipGetLastError());
         SK_HIP(hipEventRecord(ev[1], c->stream));
         if (tiers) {
