@@ -128,3 +128,39 @@ def test_c5_full_size_100k_long_reads(gpu, ora, monkeypatch, budget_mb):
     if budget_mb:
         monkeypatch.setenv("SK_DTW_SCRATCH_MB", str(budget_mb))
     _full_size(gpu, ora, 100_000, 20000, 500, synth.SEED_C5, 2000, 2 if budget_mb else 1)
+
+
+def test_early_retry_equals_late_retry(gpu, ora, monkeypatch):
+    """Reads pass Q itself cannot screen -- two identical copies of the motif far apart (candidate columns > 512 apart),
+    a sample far outside the fixed-point range after normalisation -- are retried on a third stream beside the window
+    passes; the result must equal the run with that switched off (SK_DTW_NO_EARLY) and the oracle, also when the
+    scratch budget forces several chunks."""
+    from squigglekit_amd import api, synth
+    L = gpu.load()
+    R, M = 1500, 4000
+    motif = synth.synthetic_motif(200, seed=21)
+    sig = synth.squiggle_batch(R, M, 777001, motif=motif)
+    lens = np.full(R, M, dtype=np.int32)
+    copy = np.clip(np.rint(motif * 93.4 + 511.0), 1, 1199).astype(np.int16)
+    twice = np.arange(3, R, 41)
+    for r in twice:                                       # the same samples twice: two exactly equal minima
+        sig[r, 300:300 + copy.size] = copy
+        sig[r, 2900:2900 + copy.size] = copy
+    flat = np.arange(11, R, 97)
+    for r in flat:                                        # MAD of a few units and one sample hundreds of MADs away
+        sig[r, :] = 500 + (np.arange(M) % 3)
+        sig[r, 1234] = 1190
+    got = api.motifseq_batch(sig, lens, motif)
+    n_early = L.sk_last_dtw_retries()
+    monkeypatch.setenv("SK_DTW_NO_EARLY", "1")
+    late = api.motifseq_batch(sig, lens, motif)
+    assert got.tobytes() == late.tobytes() and n_early == L.sk_last_dtw_retries()
+    monkeypatch.delenv("SK_DTW_NO_EARLY")
+    monkeypatch.setenv("SK_DTW_SCRATCH_MB", "8")
+    chunked = api.motifseq_batch(sig, lens, motif)
+    assert chunked.tobytes() == got.tobytes()
+    assert n_early >= twice.size, "the doubled reads should have gone to the exact retry (%d)" % n_early
+    want = oracle_motifseq_threaded(ora, sig, lens, motif)
+    ok = (got["flags"] & 2) == 0
+    _same(got[ok], want[ok], "early retry")
+    assert np.array_equal(got["end"][twice], want["end"][twice]) and np.all(want["end"][twice] < 600)   # the first copy wins
