@@ -163,4 +163,6 @@ def test_early_retry_equals_late_retry(gpu, ora, monkeypatch):
     want = oracle_motifseq_threaded(ora, sig, lens, motif)
     ok = (got["flags"] & 2) == 0
     _same(got[ok], want[ok], "early retry")
-    assert np.array_equal(got["end"][twice], want["end"][twice]) and np.all(want["end"][twice] < 600)   # the first copy wins
+    # (where the doubled copy holds the minimum at all, the FIRST of the two equal columns wins: first argmin)
+    assert np.array_equal(got["end"][twice], want["end"][twice]) and np.mean(want["end"][twice] < 600) > 0.8
+    assert not np.any((want["end"][twice] > 3000) & (want["end"][twice] < 3200))
