@@ -1,5 +1,7 @@
 """GPU parity: the float64 sample path (pA TSVs, segmenter.py:198-199 / MotifSeq.py:270):
 radix-select median / MAD, numpy-order mean/std on doubles, same state machine and DTW."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -138,3 +140,33 @@ def test_f64_selection_corners(gpu, ora):
         f = ora.scale_outliers(sig, 0, 900)
         want = ora.get_segs(f) if f.size else False
         assert got == want
+
+
+@pytest.mark.parametrize("scale,lanes", [("medmad", None), ("zscale", None), ("medmad", "8"), ("zscale", "64")])
+def test_motifseq_f64_batch_through_the_screening_scheme(gpu, ora, example_model, scale, lanes, monkeypatch):
+    """Enough float64 (pA) reads for the default scheme -- fixed-point screening, pre-roll, certified window -- on the
+    normalise-on-the-fly feed, in the lane layout a batch of this size gets and in the other two."""
+    from concurrent.futures import ThreadPoolExecutor
+    from squigglekit_amd import api
+    if lanes:
+        monkeypatch.setenv("SK_DTW_QL", lanes)
+    reads = _pa_reads(288, 2900, 11)
+    rng = np.random.default_rng(4)
+    for r in range(0, 288, 9):
+        reads[r] = reads[r][:int(rng.integers(1200, 2901))]
+    got = api.motifseq_reads_f64(reads, example_model, scale=scale, scale_low=0, scale_hi=1200)
+    launches = C.c_int32()
+    gpu.load().sk_last_dtw_profile(None, C.byref(launches), None, None, None)
+    assert launches.value >= 1, "the batch did not take the screening scheme"
+
+    def one(sig):
+        f = ora.scale_outliers(sig, 0, 1200)
+        y = ora.medmad(f)[0] if scale == "medmad" else ora.zscale(f)[0]
+        return (ora.dtw_subsequence(example_model, y) + (f.size,)) if np.all(np.isfinite(y)) else None
+    with ThreadPoolExecutor(16) as ex:
+        want = list(ex.map(one, reads))
+    for r, w in enumerate(want):
+        if w is None:
+            assert got["flags"][r] & 2
+        else:
+            assert (got["dist"][r], got["start"][r], got["end"][r], got["n"][r]) == w, (scale, lanes, r)
