@@ -11,3 +11,4 @@ from squigglekit_amd.drna_cli import main  # noqa: E402
 
 if __name__ == "__main__":
     main()
+    _warm.fast_exit(0)             # (sys.exit inside main() leaves the ordinary way)

@@ -249,10 +249,14 @@ void  sk_fmt_free(void *p);
 /* BLOW5 (binary SLOW5: what the reference reads through pyslow5, segmenter.py:321-396, dRNA_segmenter.py:85-100).
  * sk_blow5_index walks the records of a file image from byte `first` (just behind the ASCII header): payload offset
  * and size of up to `cap` records; returns the number of records in the file (call with cap = 0 to count).
+ * sk_blow5_index_some is the same walk for at most max_rec records from byte `pos`; *next_pos = where the next call
+ * continues, fewer than max_rec records returned = end of the file (a reader indexes chunk by chunk).
  * sk_blow5_rows_i16 decodes records (comp: 0 = stored, 1 = zlib) into int16 rows of `stride` samples on all cores:
  * nsamp[i] samples, ids[i * id_width ..] the read id (NUL padded; NULL to skip), calib[3 i ..] = digitisation, offset,
  * range (NULL to skip); flags[i]: 1 = longer than a row (truncated to stride), 2 = unreadable record, 4 = id cut. */
 int64_t sk_blow5_index(const void *buf, int64_t len, int64_t first, int64_t *rec_off, int64_t *rec_size, int64_t cap);
+int64_t sk_blow5_index_some(const void *buf, int64_t len, int64_t pos, int64_t max_rec, int64_t *rec_off,
+                            int64_t *rec_size, int64_t *next_pos);
 int sk_blow5_rows_i16(const void *buf, const int64_t *rec_off, const int64_t *rec_size, int64_t nrec, int32_t comp,
                       int64_t stride, int16_t *rows, int32_t *nsamp, char *ids, int32_t id_width, double *calib,
                       int32_t *flags, int32_t nthreads);

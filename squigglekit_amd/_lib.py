@@ -133,6 +133,7 @@ ABI = {
     "sk_fmt_rows": (_vp, [C.c_int64, C.c_int32, _vp, _vp, C.c_int32, _i64p]),
     "sk_fmt_free": (None, [_vp]),
     "sk_blow5_index": (C.c_int64, [_vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int64]),
+    "sk_blow5_index_some": (C.c_int64, [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp]),
     "sk_blow5_rows_i16": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int32, C.c_int64, _vp, _vp, _vp, C.c_int32, _vp, _vp,
                                     C.c_int32]),
     "sk_comm_unique_id": (C.c_int, [_vp]),
@@ -200,7 +201,16 @@ def init(device=None, slot=None):
     else:
         check(L.sk_init_slot(int(slot), int(device)))
     _tls.device = int(device)
+    _ready.set()
     return _tls.device
+
+
+_ready = threading.Event()
+
+
+def is_ready():
+    """Has some thread of this process already bound a GPU (so that init() costs nothing now)?"""
+    return _ready.is_set()
 
 
 def warm_start(device=None, also=()):

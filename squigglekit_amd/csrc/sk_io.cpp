@@ -184,6 +184,29 @@ int64_t sk_blow5_index(const void *buf_, int64_t len, int64_t first, int64_t *re
     return n;
 }
 
+// The same walk, at most `max_rec` records from byte `pos` on: lets a reader index the next chunk while the current
+// one is decoded instead of touching every record of the file before the first sample moves.  *next_pos = where
+// the following call continues; fewer than max_rec records returned = end of the file.
+int64_t sk_blow5_index_some(const void *buf_, int64_t len, int64_t pos, int64_t max_rec, int64_t *rec_off,
+                            int64_t *rec_size, int64_t *next_pos)
+{
+    const unsigned char *buf = (const unsigned char *)buf_;
+    if (!buf || len < 0 || pos < 0 || max_rec < 0 || !rec_off || !rec_size || !next_pos) return SK_ERR_INVALID;
+    int64_t n = 0;
+    while (n < max_rec && pos + 8 <= len) {
+        if (pos + 5 <= len && memcmp(buf + pos, "5WOLB", 5) == 0) break;
+        uint64_t size;
+        memcpy(&size, buf + pos, 8);
+        pos += 8;
+        if (size > (uint64_t)(len - pos)) return SK_ERR_INVALID;          // truncated file
+        rec_off[n] = pos; rec_size[n] = (int64_t)size;
+        n++;
+        pos += (int64_t)size;
+    }
+    *next_pos = pos;
+    return n;
+}
+
 int sk_blow5_rows_i16(const void *buf_, const int64_t *rec_off, const int64_t *rec_size, int64_t nrec, int32_t comp,
                       int64_t stride, int16_t *rows, int32_t *nsamp, char *ids, int32_t id_width, double *calib,
                       int32_t *flags, int32_t nthreads)

@@ -125,66 +125,111 @@ def blow5_open(path):
     return mm, comp, 68 + hlen
 
 
-def iter_blow5_blocks_i16(path, block_reads=65536, id_width=64, nthreads=0):
-    """Stream a BLOW5 file as Blow5Block chunks (csrc/sk_io.cpp): the records of a chunk are decoded on all cores
-    straight into int16 rows whose stride fits the chunk's longest read."""
+def iter_blow5_blocks_i16(path, block_reads=16384, id_width=64, nthreads=0, keep=None):
+    """Stream a BLOW5 file as Blow5Block chunks (csrc/sk_io.cpp): the records of a chunk are indexed, then decoded
+    on all cores straight from the file mapping into int16 rows whose stride fits the chunk's longest read -- both
+    one chunk ahead of the caller, on a background thread.  `keep`: a list that takes over the file mapping and the
+    buffers at the end instead of their being released there (a command-line tool about to exit: the unmapping holds
+    up a GPU call still in flight).
+    The rows are ordinary memory, not page-locked (SK_BLOW5_PIN=1 pins them): the H2D copy of a chunk is hidden
+    behind the decoding of the next either way, while pinning three 300 MB buffers cost ~60 ms each when first used
+    and ~0.1 s more when the process exits -- 1 M reads x 4 000 samples: 0.72-0.75 s (segmenter.py) / 0.96-1.07 s
+    (MotifSeq.py) unpinned against 0.98-1.03 / 1.16-1.19 s pinned, process start to exit, same box."""
     L = _lib.load()
+    if os.environ.get("SK_BLOW5_BLOCK"):
+        block_reads = max(1, int(os.environ["SK_BLOW5_BLOCK"]))
     mm, comp, first = blow5_open(path)
     base = _addr(mm)
-    nrec = L.sk_blow5_index(base, len(mm), first, None, None, 0)
-    if nrec < 0:
-        raise ValueError("truncated BLOW5 file: %s" % path)
-    off = np.zeros(max(1, nrec), dtype=np.int64)
-    size = np.zeros(max(1, nrec), dtype=np.int64)
-    L.sk_blow5_index(base, len(mm), first, off.ctypes.data, size.ctypes.data, nrec)
+    flen = len(mm)
     from concurrent.futures import ThreadPoolExecutor
     pools = [{}, {}, {}]                                       # three sets of buffers, reused (fresh pages cost page
                                                                # faults): a GPU call on the previous block, the block
                                                                # the caller holds, the one being decoded
 
-    def buf(pool, name, shape, dtype):
+    def buf(pool, name, shape, dtype, pinned=False):
         need = int(np.prod(shape)) * np.dtype(dtype).itemsize
         b = pool.get(name)
-        if b is None or b.nbytes < need:
-            b = pool[name] = np.empty(max(need, 1), dtype=np.uint8)
+        # (page-locked rows on request, once a GPU is bound: the first chunks of a tool that is still starting the
+        # HIP runtime are decoded into ordinary memory meanwhile)
+        want_pinned = pinned and os.environ.get("SK_BLOW5_PIN", "0") == "1" and _lib.is_ready()
+        if b is None or b.nbytes < need or (want_pinned and not pool.get(name + ":pinned")):
+            cap = max(need + need // 8, 1)
+            b = None
+            if want_pinned:
+                try:
+                    from . import api
+                    b = api.pinned_empty((cap,), np.uint8)
+                except Exception:                              # noqa: BLE001 -- no pinned memory: ordinary pages
+                    b = None
+            pool[name + ":pinned"] = want_pinned               # (asked once per pool, whatever came of it)
+            if b is None:
+                b = np.empty(cap, dtype=np.uint8)
+            pool[name] = b
         return b[:need].view(dtype).reshape(shape)
 
-    def decode(lo, pool):
-        hi = min(nrec, lo + block_reads)
-        n = hi - lo
+    def decode(pos, pool):
+        """Index and decode the chunk that starts at byte `pos`: (block or None, position of the next chunk)."""
+        off = buf(pool, "off", (block_reads,), np.int64)
+        size = buf(pool, "size", (block_reads,), np.int64)
+        nxt = C.c_int64(0)
+        n = L.sk_blow5_index_some(base, flen, pos, block_reads, off.ctypes.data, size.ctypes.data, C.byref(nxt))
+        if n < 0:
+            raise ValueError("truncated BLOW5 file: %s" % path)
+        if n == 0:
+            return None, nxt.value
         # stored records: the signal is all of the payload but ~60 bytes of fixed fields, the id and aux data, so
         # size / 2 bounds the sample count; zlib: start from the compressed size and grow if a read does not fit
-        guess = int(size[lo:hi].max()) // 2 if comp == 0 else int(size[lo:hi].max()) * 2
+        guess = int(size[:n].max()) // 2 if comp == 0 else int(size[:n].max()) * 2
         stride = max(8, (guess + 7) // 8 * 8)
         while True:
-            rows = buf(pool, "rows", (n, stride), np.int16)          # (valid until three blocks later)
+            rows = buf(pool, "rows", (n, stride), np.int16, pinned=True)    # (valid until three blocks later)
             nsamp = buf(pool, "nsamp", (n,), np.int32)
             ids = buf(pool, "ids", (n,), "S%d" % id_width)
             calib = buf(pool, "calib", (n, 3), np.float64)
             flags = buf(pool, "flags", (n,), np.int32)
-            _lib.check(L.sk_blow5_rows_i16(base, off[lo:hi].ctypes.data, size[lo:hi].ctypes.data, n, comp, stride,
+            _lib.check(L.sk_blow5_rows_i16(base, off.ctypes.data, size.ctypes.data, n, comp, stride,
                                            rows.ctypes.data, nsamp.ctypes.data, ids.ctypes.data, id_width,
                                            calib.ctypes.data, flags.ctypes.data, int(nthreads)))
             if comp == 1 and np.any(flags & 1) and stride < (1 << 24):
                 stride = (int(nsamp.max()) + 7) // 8 * 8          # (nsamp holds the true lengths)
                 continue
             break
-        return Blow5Block(rows, nsamp, ids, calib, flags)
+        zapper.submit(forget, pos, nxt.value)
+        return Blow5Block(rows, nsamp, ids, calib, flags), (nxt.value if n == block_reads else -1)
 
-    with ThreadPoolExecutor(1) as ex:
+    # A decoded chunk's pages are dropped from this process's mapping at once (they stay in the page cache), on a
+    # thread of their own: left mapped, 8 GB of page-table entries are torn down when the process exits, serially,
+    # while whoever started the tool waits (0.15-0.2 s per million 4 000-sample reads).
+    libc = C.CDLL(None, use_errno=True)
+    libc.madvise.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    page = mmap.PAGESIZE
+
+    def forget(a, b):
+        a = (a + page - 1) // page * page
+        b = b // page * page
+        if b > a and os.environ.get("SK_BLOW5_ZAP", "1") != "0":
+            libc.madvise(base + a, b - a, mmap.MADV_DONTNEED)
+
+    with ThreadPoolExecutor(1) as ex, ThreadPoolExecutor(1) as zapper:
         k = 0
-        fut = ex.submit(decode, 0, pools[0]) if nrec > 0 else None
-        for lo in range(0, nrec, block_reads):
-            blk = fut.result()
+        fut = ex.submit(decode, first, pools[0])
+        while fut is not None:
+            blk, nxt = fut.result()
             k = (k + 1) % 3
-            fut = ex.submit(decode, lo + block_reads, pools[k]) if lo + block_reads < nrec else None
-            yield blk
+            fut = ex.submit(decode, nxt, pools[k]) if (blk is not None and nxt >= 0) else None
+            if blk is not None:
+                yield blk
+    if keep is not None:
+        keep.append((mm, pools))
 
 
-def iter_npy_blocks_i16(path, block_bytes=256 << 20, nthreads=8):
+def iter_npy_blocks_i16(path, block_bytes=128 << 20, nthreads=8, keep=None):
     """Stream a .npy file holding an int16 array [reads, samples] as (first_row, rows) blocks: parallel preads into
-    two reused page-locked buffers (api.pinned_empty), the next block being read while the caller works on the current
-    one.  A memory map would cost a page fault per 4 KB and a staging copy inside the H2D transfer."""
+    three reused buffers, the next block being read while the caller works on the current one.  (A memory map would
+    cost a page fault per 4 KB.)  The buffers are ordinary memory unless SK_I16_PIN=1: page-locked ones make the H2D
+    copy faster, but that copy is hidden behind the reading of the next block either way, and pinning 3 x 256 MB
+    cost more at first use and at process exit than it saved -- 1 M reads x 4 000 samples, process start to exit,
+    same box: 0.57-0.59 s (segmenter.py) / 0.78-0.80 s (MotifSeq.py) against 0.74-0.76 / 0.89-0.94 s pinned."""
     from concurrent.futures import ThreadPoolExecutor
     from . import api
     with open(path, "rb") as fh:
@@ -195,13 +240,17 @@ def iter_npy_blocks_i16(path, block_bytes=256 << 20, nthreads=8):
     if len(shape) != 2 or dtype != np.int16 or fortran:
         raise ValueError("%s: need a C-ordered 2-D int16 array, got %s %s" % (path, dtype, shape))
     R, M = shape
+    if os.environ.get("SK_I16_BLOCK_MB"):
+        block_bytes = max(1, int(os.environ["SK_I16_BLOCK_MB"])) << 20
     per = max(1, block_bytes // max(1, M * 2))
     fd = os.open(path, os.O_RDONLY)
     def alloc():
-        try:
-            return api.pinned_empty((min(per, max(R, 1)), M), np.int16)
-        except Exception:                                            # noqa: BLE001 -- no device yet / no pinned memory
-            return np.empty((min(per, max(R, 1)), M), dtype=np.int16)
+        if os.environ.get("SK_I16_PIN", "0") == "1":
+            try:
+                return api.pinned_empty((min(per, max(R, 1)), M), np.int16)
+            except Exception:                                        # noqa: BLE001 -- no device yet / no pinned memory
+                pass
+        return np.empty((min(per, max(R, 1)), M), dtype=np.int16)
     # three buffers: the caller may still have a GPU call in flight on the previous block while it holds the
     # current one and the next is being read
     nbuf = 3 if R > 2 * per else (2 if R > per else 1)
@@ -239,6 +288,8 @@ def iter_npy_blocks_i16(path, block_bytes=256 << 20, nthreads=8):
     finally:
         ex.shutdown(wait=True)
         os.close(fd)
+        if keep is not None:                                         # (see iter_blow5_blocks_i16)
+            keep.append(bufs)
 
 
 def write_blow5(path, reads, read_ids=None, compress=False):

@@ -16,6 +16,9 @@ import sys
 import numpy as np
 
 from . import api, fastio, tsvio
+from ._warm import mark as _mark
+
+_KEEP = []       # input mappings / page-locked buffers of a finished reader: released with the process
 
 VERSION = "1.3.0"          # the reference's MotifSeq version string (MotifSeq.py:84)
 HEADER = ["fast5", "readID", "model", "start", "end", "length", "distance_score", "model_mean",
@@ -73,14 +76,6 @@ def build_parser():
     p.add_argument("--strict-compat", action="store_true",
                    help="[extension] keep the reference's -m defect (empty model order: header only)")
     return p
-
-
-def _mark(label):
-    """Stage timestamps on stderr when SK_T0 (launch time, seconds since the epoch) is set: tools/cli_throughput.py."""
-    t0 = os.environ.get("SK_T0")
-    if t0:
-        import time
-        sys.stderr.write("[t+%.3f s] %s\n" % (time.time() - float(t0), label))
 
 
 def norm_cdf(z):
@@ -236,7 +231,14 @@ class _Batcher:
         if self._worker is None:
             from concurrent.futures import ThreadPoolExecutor
             self._worker = ThreadPoolExecutor(1)
-        job = self._worker.submit(api.motifseq_multi_batch, rows, nsamp, motifs, a.scale, a.scale_low, a.scale_hi)
+        _mark("block of %d reads to the GPU worker" % len(nsamp))
+        def call():
+            _mark("GPU call starts")
+            try:
+                return api.motifseq_multi_batch(rows, nsamp, motifs, a.scale, a.scale_low, a.scale_hi)
+            finally:
+                _mark("GPU call ends")
+        job = self._worker.submit(call)
         prev, self._pending = self._pending, (job, rows, nsamp, fast5_col, id_col, name_of, id_of)
         if prev is not None:
             self._finish(prev)
@@ -251,7 +253,9 @@ class _Batcher:
     def _finish(self, p):
         job, rows, nsamp, fast5_col, id_col, name_of, id_of = p
         hits = job.result()
+        _mark("block of %d reads back from the GPU" % len(nsamp))
         if self.table(len(nsamp), fast5_col, id_col, hits):
+            _mark("table written")
             return
         for i in range(len(nsamp)):
             self.emit(name_of(i), id_of(i), [hits[c][i] for c in range(len(self.order))],
@@ -353,6 +357,7 @@ def main(argv=None):
 
     _mark("main() entered")
     models, order, lens = load_models(args)
+    _mark("models loaded")
     print("\t".join(HEADER + (["normalised_signal"] if args.sig_extract else [])
                     + (["search_from"] if args.after_stall else [])))                  # MotifSeq.py:160-163
 
@@ -390,7 +395,7 @@ def main(argv=None):
     elif args.blow5:
         # [extension] BLOW5: records decoded natively into int16 rows (raw ADC values, as the fast5 branches use)
         fast5 = os.path.basename(args.blow5).encode()
-        for blk in fastio.iter_blow5_blocks_i16(args.blow5):
+        for blk in fastio.iter_blow5_blocks_i16(args.blow5, keep=_KEEP):
             bad = np.flatnonzero(blk.flags & 2)
             for i in bad:
                 sys.stderr.write("MotifSeq: unreadable BLOW5 record {} in {}; skipped\n".format(int(i), args.blow5))
@@ -406,7 +411,7 @@ def main(argv=None):
         # [extension] packed reads: int16 [reads, samples] in a .npy file, memory mapped
         fast5 = os.path.basename(args.i16).encode()
         try:
-            blocks = fastio.iter_npy_blocks_i16(args.i16)
+            blocks = fastio.iter_npy_blocks_i16(args.i16, keep=_KEEP)
             for lo, part in blocks:
                 ns = np.full(part.shape[0], part.shape[1], dtype=np.int32)
                 out.rows(part, ns, ("const", fast5), ("i32", np.arange(lo, lo + part.shape[0], dtype=np.int32)),

@@ -12,6 +12,9 @@ import sys
 import numpy as np
 
 from . import api, fastio, tsvio
+from ._warm import mark as _mark
+
+_KEEP = []       # input mappings / page-locked buffers of a finished reader: released with the process
 from ._lib import SegParams
 
 
@@ -116,6 +119,7 @@ class _Batcher:
         if self._worker is None:
             from concurrent.futures import ThreadPoolExecutor
             self._worker = ThreadPoolExecutor(1)
+        _mark("block of %d reads to the GPU worker" % len(nsamp))
         job = self._worker.submit(api.segment_batch, rows, lens, self.params)
         prev, self._pending = self._pending, (job, len(nsamp), name_col, name_of)
         if prev is not None:
@@ -129,6 +133,7 @@ class _Batcher:
     def _finish(self, p):
         job, n, name_col, name_of = p
         segs, nsegs = job.result()
+        _mark("block of %d reads back from the GPU" % n)
         if self.args.test:
             for i in range(n):
                 nm = name_of(i)
@@ -142,6 +147,7 @@ class _Batcher:
         vals = segs[keep].ravel()                                                   # [start, end] pairs, read order
         text = fastio.fmt_rows(n, [name_col, ("i32list", vals, off)], skip=(nsegs == 0).astype(np.uint8))
         fastio.write_stdout(text)
+        _mark("table written")
 
     def block(self, blk, path):
         """A parsed TSV chunk (tsvio.TsvBlock): the integer lines go to the GPU as ONE int16 batch straight from
@@ -192,6 +198,7 @@ def main(argv=None):
     if args.view:
         sys.stderr.write("segmenter: -v/--view plotting is not part of this build; ignoring\n")
 
+    _mark("main() entered")
     if not (args.f5_path or args.ind or args.signal or args.blow5 or args.i16):
         sys.stderr.write("Unknown file or path input")
         parser.print_help(sys.stderr)
@@ -223,7 +230,7 @@ def main(argv=None):
                 out.add(name, sig[:args.Num])
             out.flush()
     elif args.blow5 and args.raw_signal:
-        for blk in fastio.iter_blow5_blocks_i16(args.blow5):
+        for blk in fastio.iter_blow5_blocks_i16(args.blow5, keep=_KEEP):
             ok = np.flatnonzero((blk.flags & 2) == 0)
             if ok.size != blk.n:
                 blk = fastio.Blow5Block(blk.rows[ok], blk.nsamp[ok], blk.ids[ok], blk.calib[ok], blk.flags[ok])
@@ -233,7 +240,7 @@ def main(argv=None):
                      lambda i, b=blk: b.ids[i].decode())
     elif args.i16:
         try:
-            for lo, part in fastio.iter_npy_blocks_i16(args.i16):
+            for lo, part in fastio.iter_npy_blocks_i16(args.i16, keep=_KEEP):
                 ns = np.full(part.shape[0], part.shape[1], dtype=np.int32)
                 out.rows(part, ns, ("i32", np.arange(lo, lo + part.shape[0], dtype=np.int32)), lambda i, lo=lo: str(lo + i))
         except ValueError as e:
@@ -264,6 +271,7 @@ def main(argv=None):
                     out.add(read, np.array(sig[:args.Num], dtype=float), miss_name=label)
     out.drain()
     out.flush()
+    _mark("end of main()")
     sys.stderr.write("Done")                        # segmenter.py:297
 
 

@@ -28,6 +28,13 @@ def run(label, cmd, reads, size_mb, out):
         assert p.returncode == 0, (label, p.returncode)
         best = dt if best is None else min(best, dt)
     rows = p.stdout.count(b"\n")
+    if os.environ.get("SK_CLI_MARKS"):                   # one more run with the tools' stage timestamps shown
+        env = dict(os.environ, SK_T0=repr(time.time()))
+        q = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
+        marks = [ln for ln in q.stderr.decode(errors="replace").splitlines() if ln.startswith("[t+")]
+        nshow = int(os.environ["SK_CLI_MARKS"])
+        shown = marks if len(marks) <= nshow + 6 else marks[:nshow] + ["[..."] + marks[-6:]
+        print("    " + label + " stages: " + " | ".join(m[1:].replace(" s] ", "s ") for m in shown), flush=True)
     print("%-34s %8d reads (%6.0f MB in): %.2f s -> %9.0f reads/s, %5.0f MB/s in; %d output lines"
           % (label, reads, size_mb, best, reads / best, size_mb / best, rows), flush=True)
     out[label] = {"reads": reads, "seconds": best, "reads_per_s": reads / best, "input_mb": size_mb, "output_lines": rows}
