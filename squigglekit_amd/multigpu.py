@@ -242,6 +242,35 @@ def _want_rccl():
     return os.environ.get("SK_COMM", "rccl").lower() != "host"
 
 
+def _comm_timeout():
+    try:
+        return max(1.0, float(os.environ.get("SK_COMM_TIMEOUT", "180")))
+    except ValueError:
+        return 180.0
+
+
+def _bounded(fn, what):
+    """fn() on a helper thread, waited for at most $SK_COMM_TIMEOUT seconds (180): (True, result) or (False, why).
+    Creating an RCCL communicator is the one step of the multi-GPU path that can block for ever (a wedged peer, a
+    fabric that never answers); the job is better served by the host gather than by a hung launch.  A helper that
+    never returns is a daemon thread and dies with the process."""
+    box = {}
+
+    def run():
+        try:
+            box["r"] = fn()
+        except BaseException as e:                                   # noqa: BLE001 -- reported to the caller
+            box["e"] = e
+    t = threading.Thread(target=run, name="sk-comm-init", daemon=True)
+    t.start()
+    t.join(_comm_timeout())
+    if t.is_alive():
+        return False, "%s did not return within %.0f s (SK_COMM_TIMEOUT)" % (what, _comm_timeout())
+    if "e" in box:
+        raise box["e"]
+    return True, box["r"]
+
+
 class ThreadGroup:
     """One process driving `devices`, one host thread each.  run(fn) calls fn(comm) on every rank's thread
     (bound to its device) and returns the results in rank order."""
@@ -267,13 +296,16 @@ class ThreadGroup:
         elif _want_rccl():
             L = _lib.load()
             arr = np.array(self.devices, dtype=np.int32)
-            rc = L.sk_comm_init_all(arr.ctypes.data_as(C.POINTER(C.c_int32)), n)
-            if rc == 0:
+            done, rc = _bounded(lambda: (L.sk_comm_init_all(arr.ctypes.data_as(C.POINTER(C.c_int32)), n),
+                                         L.sk_last_error().decode(errors="replace")), "ncclCommInitAll")
+            if not done:
+                self.why_host = rc
+            elif rc[0] == 0:
                 self.backend = "rccl"
-            elif rc == -5:                                           # SK_ERR_UNSUPPORTED: no RCCL here
-                self.why_host = L.sk_last_error().decode(errors="replace")
+            elif rc[0] == -5:                                        # SK_ERR_UNSUPPORTED: no RCCL here
+                self.why_host = rc[1]
             else:
-                check(rc)
+                raise _lib.SquiggleKitError(rc[0], rc[1])
         else:
             self.why_host = "SK_COMM=host"
         self._bar = threading.Barrier(n)
@@ -355,10 +387,15 @@ class ProcessGroup:
             self.why_host = "SK_COMM=host"
         elif bind and blob[:1] == b"\1":
             L = _lib.load()
-            rc = L.sk_comm_init_rank(blob[1:1 + UID_BYTES], world, rank)
-            mine = 1 if rc == 0 else 0
+            dev = local_rank if shared is None else shared
+
+            def init_rank():                                         # (the helper thread binds the device itself)
+                _lib.init(dev)
+                return L.sk_comm_init_rank(blob[1:1 + UID_BYTES], world, rank), L.sk_last_error().decode(errors="replace")
+            done, rc = _bounded(init_rank, "ncclCommInitRank")
+            mine = 1 if (done and rc[0] == 0) else 0
             if not mine:
-                self.why_host = L.sk_last_error().decode(errors="replace")
+                self.why_host = rc if not done else rc[1]
             votes = self.store.allgather(bytes([mine]))               # all or nothing
             if all(v == b"\x01" for v in votes):
                 self.backend = "rccl"

@@ -174,3 +174,21 @@ def test_process_group_file_store_world2(total, tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
     assert outs[0][0].split() == ["RESULT", "True", str(total), "1.0"]
     assert not [d for d in os.listdir(tmp_path) if d.startswith("sk_rdzv_")]      # the store cleaned up after itself
+
+
+def test_bounded_comm_init_gives_up(monkeypatch):
+    """A communicator that never comes up (wedged peer) must not hang the launch: the helper is abandoned after
+    SK_COMM_TIMEOUT and the caller falls back to the host gather; a quick one passes its result (or its exception)."""
+    import time
+    from squigglekit_amd import multigpu
+    monkeypatch.setenv("SK_COMM_TIMEOUT", "1")
+    t0 = time.monotonic()
+    done, why = multigpu._bounded(lambda: time.sleep(5), "ncclCommInitAll")
+    assert not done and "ncclCommInitAll" in why and time.monotonic() - t0 < 3
+    assert multigpu._bounded(lambda: 7, "x") == (True, 7)
+    try:
+        multigpu._bounded(lambda: 1 // 0, "x")
+    except ZeroDivisionError:
+        pass
+    else:
+        raise AssertionError("the helper's exception must reach the caller")
