@@ -245,6 +245,9 @@ typedef struct sk_fmt_col {
 void *sk_fmt_rows(int64_t nrows, int32_t ncols, const sk_fmt_col *cols, const uint8_t *skip, int32_t nthreads,
                   int64_t *out_len);
 void  sk_fmt_free(void *p);
+/* out[i] = the standard normal CDF of z[i], the very double scipy.special.ndtr returns (MotifSeq.py:444 prints
+ * scipy.stats.norm.cdf(z) digit for digit): the Cephes ndtr, restated in csrc/sk_io.cpp. */
+void  sk_ndtr(const double *z, double *out, int64_t n);
 
 /* BLOW5 (binary SLOW5: what the reference reads through pyslow5, segmenter.py:321-396, dRNA_segmenter.py:85-100).
  * sk_blow5_index walks the records of a file image from byte `first` (just behind the ASCII header): payload offset

@@ -132,6 +132,7 @@ ABI = {
                                    _vp, C.c_int32]),
     "sk_fmt_rows": (_vp, [C.c_int64, C.c_int32, _vp, _vp, C.c_int32, _i64p]),
     "sk_fmt_free": (None, [_vp]),
+    "sk_ndtr": (None, [_vp, _vp, C.c_int64]),
     "sk_blow5_index": (C.c_int64, [_vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int64]),
     "sk_blow5_index_some": (C.c_int64, [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp]),
     "sk_blow5_rows_i16": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int32, C.c_int64, _vp, _vp, _vp, C.c_int32, _vp, _vp,

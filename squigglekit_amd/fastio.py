@@ -85,6 +85,16 @@ def fmt_rows(nrows, cols, skip=None, nthreads=0):
         L.sk_fmt_free(p)
 
 
+def ndtr(z):
+    """scipy.special.ndtr without scipy (csrc/sk_io.cpp restates the Cephes routine; the same doubles, bit for bit):
+    an array or a scalar in, the same shape out."""
+    a = np.asarray(z, dtype=np.float64)
+    flat = np.ascontiguousarray(a).reshape(-1)
+    out = np.empty_like(flat)
+    _lib.load().sk_ndtr(flat.ctypes.data, out.ctypes.data, flat.size)
+    return out.reshape(a.shape) if a.ndim else np.float64(out[0])
+
+
 def write_stdout(text):
     """Bytes to stdout behind whatever print() already queued (a redirected / captured stdout may be a text-only
     stream without a byte layer)."""

@@ -123,3 +123,23 @@ def test_prefetch_keeps_order_and_hands_errors_over():
         for x in tsvio._prefetched(gen(20, fail_at=7)):
             got.append(x)
     assert got == list(range(7))
+
+
+def test_ndtr_is_scipys_bit_for_bit():
+    """MotifSeq prints norm.cdf(z) with every digit: the native restatement of the Cephes ndtr (csrc/sk_io.cpp) must
+    return scipy.special.ndtr's double, not a nearby one -- both branches of erf / erfc, the seams, the tails."""
+    sp = pytest.importorskip("scipy.special")
+    rng = np.random.default_rng(7)
+    r2 = np.sqrt(2.0)
+    z = np.concatenate([
+        np.linspace(-45, 45, 1500001), rng.normal(0, 1, 500000), rng.normal(0, 6, 500000), rng.uniform(-1.5, 1.5, 300000),
+        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1e-300, 1.0, -1.0, r2, -r2, 8 * r2, -8 * r2,
+                  37.6, -37.6, 38.5, -38.5, 1e308, -1e308]),
+        np.nextafter(r2, [0, 2]), np.nextafter(-r2, [0, -2]), np.nextafter(8 * r2, [0, 20])])
+    from squigglekit_amd import fastio
+    got, want = fastio.ndtr(z), sp.ndtr(z)
+    same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), (z[~same][:5], got[~same][:5], want[~same][:5])
+    one = fastio.ndtr(0.3)                                           # a scalar stays a scalar (emit()'s per-row use)
+    assert isinstance(one, np.float64) and one == sp.ndtr(0.3)
+    assert fastio.ndtr(np.zeros((2, 3))).shape == (2, 3)
