@@ -287,6 +287,29 @@ int sk_tsv_parse_i16(const char *buf, size_t len, int32_t start_col, int64_t nli
             const char *s = p;
             while (true) {
                 const char *te = s;
+                if (col >= start_col && e - s >= 8) {
+                    // the common token -- one to five digits and a tab -- eight bytes at a time: where the first
+                    // non-digit sits, then the digits as one multiply-and-shift cascade (what follows handles
+                    // everything else, and the last tokens of a line)
+                    uint64_t w;
+                    memcpy(&w, s, 8);
+                    const uint64_t d = w ^ 0x3030303030303030ull;                 // digits -> 0 .. 9
+                    const uint64_t nd = (((d & 0x7f7f7f7f7f7f7f7full) + 0x7676767676767676ull) | d) & 0x8080808080808080ull;
+                    const int n = nd ? (__builtin_ctzll(nd) >> 3) : 8;            // bytes before the first non-digit
+                    if (n >= 1 && n <= 5 && ((w >> (8 * n)) & 0xff) == '\t') {
+                        uint64_t v8 = d << (8 * (8 - n));                          // right-aligned, leading zeros
+                        v8 = (v8 * 2561) >> 8;
+                        v8 = ((v8 & 0x00FF00FF00FF00FFull) * 6553601) >> 16;
+                        v8 = ((v8 & 0x0000FFFF0000FFFFull) * 42949672960001ull) >> 32;
+                        const int v = (int)v8;
+                        if (v > 32767 || k >= stride) ok = false;
+                        else { row[k] = (int16_t)v; anynz = anynz || v != 0; }
+                        k++;
+                        col++;
+                        s += n + 1;                                                // (s + n < e: not the line's end)
+                        continue;
+                    }
+                }
                 if (col >= start_col) {                     // integer token, converted while looking for its end
                     bool neg = false;
                     if (te < e && (*te == '-' || *te == '+')) { neg = (*te == '-'); te++; }

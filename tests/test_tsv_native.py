@@ -122,6 +122,12 @@ def test_int16_block_parser_agrees_with_python(tmp_path):
             vals[-1] = vals[-1] + "\r"
         elif kind == 6:
             vals = vals[:0]                                                    # no data column at all
+        elif kind == 7 and n:                                                  # five digits and more: around int16's edge
+            for j in rng.integers(0, n, 3):
+                vals[int(j)] = str(int(rng.choice([9999, 10000, 32767, 32768, 65535, 99999, 100000, 1234567, 12345678])))
+        elif kind == 8 and n:                                                  # leading zeros, widths 1 .. 9
+            for j in rng.integers(0, n, 3):
+                vals[int(j)] = "0" * int(rng.integers(1, 6)) + str(int(rng.integers(0, 2000)))
         head = ["f%d.fast5" % i, "id-%d" % i, "a", "b"]
         if kind == 6 and rng.random() < 0.5:
             head = head[:int(rng.integers(1, 4))]
