@@ -443,44 +443,64 @@ def e2e_all_ranks(a, w, comm):
 
 
 def cli_block(a, L, main):
-    """N = 1 extras: the drop-in command-line tools end to end, process start and text output included (the full-size
-    runs are tools/cli_throughput.py -> profiles/r03_cli_throughput.txt).  200 000 of the batch's reads as a packed
-    int16 .npy (--i16), 4 000 as the SquigglePull-style TSV the reference reads."""
+    """N = 1 extras: the drop-in command-line tools end to end, process start and text output included, on the
+    batch's own reads: all of them (up to 1 M) as a packed int16 .npy (--i16) and as a BLOW5 file (--blow5), 200 000
+    lines (3.2 GB) of the SquigglePull-style TSV the reference reads (-s; 256 distinct reads cycled: the tokenizer does
+    not care).
+    tools/cli_throughput.py is the same thing stand-alone (profiles/r03_cli_throughput.txt)."""
     import shutil
     import subprocess
     import tempfile
+    from squigglekit_amd import fastio
     from squigglekit_amd._lib import check, ptr
     d = tempfile.mkdtemp()
     out = {"note": "wall clock of the whole process (interpreter start, HIP start-up, ingest, kernels, text out), best "
-                   "of 2; at these sizes start-up (~0.35 s) dominates -- see profiles/r03_cli_throughput.txt for 1 M reads"}
+                   "of 2; ~0.1 s of interpreter start and ~0.1 s of process exit are in every figure, the HIP start-up "
+                   "(~0.25 s) runs beside the first chunks"}
     try:
-        Rp = min(main.R, 200_000)
+        Rp = min(main.R, 1_000_000)
         host = np.empty((Rp, main.stride), dtype=np.int16)
         check(L.sk_dev_download(ptr(host), main.d_sig, host.nbytes))
-        np.save(os.path.join(d, "r.npy"), host[:, :main.M])
+        reads = host[:, :main.M]
         model = os.path.join(ROOT, "tests", "golden", "CATCTATCCAGGGTTAAATT.model")
-        Rt = min(Rp, 4000)
-        for name, ncols in (("s.tsv", 4), ("m.tsv", 8)):
-            with open(os.path.join(d, name), "w") as fh:
+        seg, mot = os.path.join(ROOT, "segmenter.py"), os.path.join(ROOT, "MotifSeq.py")
+
+        def timed_runs(runs):
+            for label, n, cmd in runs:
+                best, lines = None, 0
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    p = subprocess.run([sys.executable] + cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+                    dt = time.perf_counter() - t0
+                    if p.returncode != 0:
+                        best = None
+                        break
+                    best = dt if best is None else min(best, dt)
+                    lines = p.stdout.count(b"\n")
+                    del p
+                out[label] = {"reads": n, "seconds": best, "reads_per_s": n / best if best else None, "output_lines": lines}
+
+        # one input file at a time on the scratch disk (8 GB each at C4)
+        f = os.path.join(d, "r.npy")
+        np.save(f, reads)
+        timed_runs((("segmenter_i16", Rp, [seg, "--i16", f]), ("motifseq_i16", Rp, [mot, "--i16", f, "-m", model])))
+        os.remove(f)
+        f = os.path.join(d, "r.blow5")
+        fastio.write_blow5(f, reads)
+        timed_runs((("segmenter_blow5", Rp, [seg, "--blow5", f, "--raw_signal"]),
+                    ("motifseq_blow5", Rp, [mot, "--blow5", f, "-m", model])))
+        os.remove(f)
+        Rt = min(Rp, 200_000)
+        texts = ["\t".join(str(v) for v in reads[r].tolist()) for r in range(min(Rt, 256))]
+        del host, reads
+        for label, ncols, cmd in (("segmenter_tsv", 4, [seg, "-s"]), ("motifseq_tsv", 8, [mot, "-m", model, "-s"])):
+            f = os.path.join(d, label)
+            with open(f, "w") as fh:
                 for r in range(Rt):
-                    fh.write("\t".join(["read%d.fast5" % r, "id%d" % r] + ["x"] * (ncols - 2)
-                                       + [str(v) for v in host[r, :main.M].tolist()]) + "\n")
-        runs = (("segmenter_i16", Rp, [os.path.join(ROOT, "segmenter.py"), "--i16", os.path.join(d, "r.npy")]),
-                ("motifseq_i16", Rp, [os.path.join(ROOT, "MotifSeq.py"), "--i16", os.path.join(d, "r.npy"), "-m", model]),
-                ("segmenter_tsv", Rt, [os.path.join(ROOT, "segmenter.py"), "-s", os.path.join(d, "s.tsv")]),
-                ("motifseq_tsv", Rt, [os.path.join(ROOT, "MotifSeq.py"), "-s", os.path.join(d, "m.tsv"), "-m", model]))
-        for label, n, cmd in runs:
-            best, lines = None, 0
-            for _ in range(2):
-                t0 = time.perf_counter()
-                p = subprocess.run([sys.executable] + cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
-                dt = time.perf_counter() - t0
-                if p.returncode != 0:
-                    best = None
-                    break
-                best = dt if best is None else min(best, dt)
-                lines = p.stdout.count(b"\n")
-            out[label] = {"reads": n, "seconds": best, "reads_per_s": n / best if best else None, "output_lines": lines}
+                    fh.write("\t".join(["read%d.fast5" % r, "id%d" % r] + ["x"] * (ncols - 2)) + "\t"
+                             + texts[r % len(texts)] + "\n")
+            timed_runs(((label, Rt, cmd + [f]),))
+            os.remove(f)
     except Exception as e:                                            # noqa: BLE001 -- report, keep the line
         out["error"] = repr(e)
     finally:

@@ -303,3 +303,34 @@ def test_packed_and_blow5_inputs_equal_the_tsv_route(gpu, tmp_path):
     got, _, _ = run_cli(smain, ["--i16", str(tmp_path / "r.npy"), "-u", "-k"])          # -u: the per-read checks
     want, _, _ = run_cli(smain, ["-s", str(tmp_path / "s.tsv"), "-u", "-k"])
     assert cols(got, 1) == cols(want, 1)
+
+
+@pytest.mark.gpu
+def test_launchers_as_processes_flush_everything_before_the_fast_exit(gpu, tmp_path):
+    """The root launchers leave through os._exit once main() has returned (no interpreter / HIP teardown): everything
+    printed must still arrive -- through a pipe, the case in which Python block-buffers stdout -- with exit code 0,
+    and equal what main() prints in-process; a usage error keeps its ordinary exit code."""
+    import subprocess
+    from squigglekit_amd import synth
+    from squigglekit_amd.motifseq_cli import main as mmain
+    from squigglekit_amd.segmenter_cli import main as smain
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    R, M = 500, 2000
+    sig = synth.squiggle_batch(R, M, 4711, motif=synth.synthetic_motif(60, seed=3))
+    np.save(tmp_path / "r.npy", sig)
+    with open(tmp_path / "s.tsv", "w") as fs:
+        for i in range(40):
+            fs.write("\t".join(["id%d" % i, "a", "b", "c"]) + "\t" + "\t".join(str(int(v)) for v in sig[i]) + "\n")
+    model = os.path.join(GOLD, "CATCTATCCAGGGTTAAATT.model")
+    for tool, main, argv in (("MotifSeq.py", mmain, ["--i16", str(tmp_path / "r.npy"), "-m", model]),
+                             ("segmenter.py", smain, ["--i16", str(tmp_path / "r.npy")]),
+                             ("segmenter.py", smain, ["-s", str(tmp_path / "s.tsv")])):
+        want, _, code = run_cli(main, argv)
+        assert code == 0
+        p = subprocess.run([sys.executable, os.path.join(root, tool)] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=300)
+        assert p.returncode == 0, p.stderr.decode()[-500:]
+        assert p.stdout.decode() == want, tool
+    p = subprocess.run([sys.executable, os.path.join(root, "MotifSeq.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=300)
+    assert p.returncode == 1 and b"usage" in p.stderr.lower()

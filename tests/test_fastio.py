@@ -89,6 +89,26 @@ def test_blow5_native_decoder_reads_the_reference_example():
     assert np.array_equal(blks[0].rows[0, :36978], want["signal"]) and blks[0].ids[0].decode() == want["read_id"]
 
 
+def test_blow5_edges_truncated_empty_and_exact_multiple(tmp_path):
+    """A file cut inside a record is an error, not a short result; a header-only file yields nothing; a record count
+    that is an exact multiple of the chunk size ends cleanly; `keep` takes over the mapping and the buffers."""
+    from squigglekit_amd import fastio
+    rng = np.random.default_rng(9)
+    reads = [rng.integers(0, 1000, 500).astype(np.int16) for _ in range(64)]
+    path = fastio.write_blow5(str(tmp_path / "t.blow5"), reads)
+    keep = []
+    blks = list(fastio.iter_blow5_blocks_i16(path, block_reads=16, keep=keep))
+    assert [b.n for b in blks] == [16, 16, 16, 16] and len(keep) == 1
+    assert np.array_equal(blks[3].rows[15, :500], reads[63])
+    data = open(path, "rb").read()
+    cut = tmp_path / "cut.blow5"
+    cut.write_bytes(data[:len(data) - 700])                          # the last record loses its tail (and the EOF mark)
+    with pytest.raises(ValueError):
+        list(fastio.iter_blow5_blocks_i16(str(cut), block_reads=16))
+    empty = fastio.write_blow5(str(tmp_path / "e.blow5"), [])
+    assert list(fastio.iter_blow5_blocks_i16(empty)) == []
+
+
 def test_npy_block_reader_equals_numpy(tmp_path):
     """iter_npy_blocks_i16 (parallel preads into reused buffers; page-locked ones when a GPU is there, plain memory
     here): every row arrives once, in order, whatever the block size; wrong dtypes are refused."""

@@ -12,6 +12,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 "$R/tools/ubench/valu_rate" > "$OUT/valu_rate.txt" 2>&1
+"$R/tools/ubench/hbm_stream" 8 > "$OUT/hbm_stream.txt" 2>&1
 python "$R/bench.py" > "$OUT/bench_motifseq.json" 2> "$OUT/bench_motifseq.err"
 python "$R/bench.py" --workload segmenter --no-extras > "$OUT/bench_segmenter.json" 2> "$OUT/bench_segmenter.err"
 python "$R/bench.py" --reads 10000 --motif 163 --no-extras --steps 20 --warmup 3 > "$OUT/bench_c3_10k_x_163pt.json" 2>/dev/null
@@ -44,6 +45,6 @@ for WL in motifseq segmenter; do
     rm -rf "$OUT/kt_$WL" "$OUT/pmc_FETCH_SIZE_$WL" "$OUT/pmc_WRITE_SIZE_$WL"
     unset SK_SEG_CHUNKS
 done
-python "$R/tools/cli_throughput.py" 100000 1000000 > "$OUT/cli_throughput.txt" 2>&1
+python "$R/tools/cli_throughput.py" 200000 1000000 > "$OUT/cli_throughput.txt" 2>&1
 (cd "$R" && python tools/parity_at_scale.py 400000 128 && python tools/parity_at_scale.py segmenter 1000000 128) > "$OUT/parity_at_scale.txt" 2>&1
 ls -la "$OUT"
