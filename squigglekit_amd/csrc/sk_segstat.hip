@@ -659,8 +659,8 @@ bool sk_segment_fast_applies(const void *d_sig, int64_t stride, int32_t lo, int3
 }
 
 // Streaming statistics, the numpy-order redo of the (almost always empty) list of uncertified reads, then the walk.
-// With SK_SEG_CHUNKS > 1 the batch goes in chunks and the walk of chunk i runs on a second stream beside the
-// statistics of chunk i + 1 (kept as a switch; it does not pay, see below).
+// Large batches go in SK_SEG_CHUNKS chunks (4), the walk of chunk i on a second stream beside the statistics of
+// chunk i + 1 (see below; folding the walk into the statistics kernel itself was built and measured too: DESIGN 4.0).
 // d_retry: nreads + 16 ints (per chunk: [0] = count, [1 ..] = list; zeroed here).  Records ev[0..3] like the
 // other segment paths: ev[0]..ev[1] statistics of all chunks, ev[2]..ev[3] what is left of the walks after that.
 int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
