@@ -40,6 +40,16 @@ def main():
         motif = synth.synthetic_motif(N, seed=int(rng.integers(1000)))
         lo, hi = [(0, 1200), (0, 900), (-50, 2500), (400, 650)][int(rng.integers(4))]
         scale = ["medmad", "zscale"][int(rng.integers(2))]
+        # the lanes-per-read layout of the screening scheme (8 is what large batches get by themselves: these batches
+        # are small, so it is asked for), the fused / separate filter + statistics, the early / late exact retry
+        import os
+        ql = [None, "8", "16", "64"][int(rng.integers(4))]
+        for key, val in (("SK_DTW_QL", ql), ("SK_DTW_NOFUSE", "1" if rng.random() < 0.3 else None),
+                         ("SK_DTW_NO_EARLY", "1" if rng.random() < 0.3 else None)):
+            if val is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = val
         got = api.motifseq_batch(sig, lens, motif, scale=scale, scale_low=lo, scale_hi=hi)
         want = ora.motifseq_batch_i16(sig, lens, motif, scale_mode=0 if scale == "medmad" else 1, lo=lo, hi=hi)
         ok = ((got["flags"] & 2) == 0) & np.isfinite(want["dist"]) | (want["n"] == 0)   # MAD == 0 / std == 0 rows aside
@@ -49,8 +59,8 @@ def main():
         if not np.all(same[ok]):
             bad += 1
             r = int(np.nonzero(~same & ok)[0][0])
-            print("MOTIFSEQ mismatch R=%d M=%d N=%d %s lo=%d hi=%d read %d: got %s want %s"
-                  % (R, M, N, scale, lo, hi, r, got[r], want[r]))
+            print("MOTIFSEQ mismatch R=%d M=%d N=%d %s lo=%d hi=%d QL=%s read %d: got %s want %s"
+                  % (R, M, N, scale, lo, hi, ql, r, got[r], want[r]))
         # ---- segmenter ----
         kw = [dict(), dict(error=10, corrector=3), dict(window=20, seg_dist=5), dict(std_scale=1.5, stall_len=0.9),
               dict(lim_low=300, lim_hi=800)][int(rng.integers(5))]
