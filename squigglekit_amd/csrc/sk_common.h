@@ -63,6 +63,8 @@ struct sk_ctx {
     sk_buf lsum;      // screening pass: last-row minima per checkpoint interval and lane
     sk_buf wstate;    // window pass: restart state per read (pass P -> pass W)
     sk_buf wrec;      // window pass: restart point per read {tbase, jlo, jhi, flags}
+    sk_buf wrecq;     // screening pass epilogue: candidate columns per read (first tier of pass P)
+    sk_buf order;     // [1024] sort cursors, then the chunk's reads in the order the window passes take them
     sk_buf motifw;    // the motif (doubles) in the screening scheme's own per-lane layout
     std::vector<double> motifw_host;
     int    motifq_L = 0;   // lanes per read of the layouts in motifq / motifw

@@ -75,7 +75,9 @@ struct sdtw_kargs {
     int            wmax;        // widest candidate-column range the window pass accepts
     unsigned      *lsum;        // [slot][nck+1][L]: minimum of the last-row columns a lane stored per checkpoint interval
     unsigned      *wstate;      // [slot][L][R+2]: restart state of the window pass (pass P -> pass W)
-    void          *wrec;        // [slot] {tbase, jlo, jhi, flags}
+    void          *wrec;        // [slot] {tbase, jlo, jhi, flags}: pass P -> pass W
+    void          *wrec_q;      // [read - read0] {-, jlo, jhi, -}: pass Q's epilogue -> the first tier of pass P
+    int32_t        tier2;       // pass P: look for the candidate columns again (second tier) instead of taking pass Q's
     // pass Q with the filter + medmad statistics fused in as a prologue (int16 reads): the wave preps its own reads
     const int16_t *fz_raw;      // raw rows (same stride), or nullptr: prep / samples were filled by an earlier kernel
     const int32_t *fz_len;

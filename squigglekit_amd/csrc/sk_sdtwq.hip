@@ -346,13 +346,13 @@ void k_sdtw_q(const sdtw_kargs a)
     }
     const unsigned bq = bad ? QINF : qmin;
     if (live && l == 0) a.qflag[r - a.read0] = (int32_t)bq;
-    if (a.wrec) {                                   // epilogue: the candidate columns, for the first tier of pass P
+    if (a.wrec_q) {                                 // epilogue: the candidate columns, for the first tier of pass P
         int jlo, jhi;
         candidate_columns<L>(a, r, n, bq, l, jlo, jhi);
         if (live && l == 0) {
             wrec w;
             w.tbase = 0; w.jlo = jlo; w.jhi = jhi; w.flags = 0;
-            ((wrec *)a.wrec)[slot] = w;
+            ((wrec *)a.wrec_q)[r - a.read0] = w;
             // a read the window passes cannot take (no usable minimum, candidates too far apart) goes to the exact
             // retry -- which starts now, beside the window passes, instead of behind them
             const bool screened = (bq < QSAFE) && (jhi >= jlo) && (jhi - jlo <= a.wmax);
@@ -412,8 +412,8 @@ void k_sdtw_p(const sdtw_kargs a)
     // latency that the other waves' sweeps hide); a second-tier launch looks again (its reads come from a list).
     const unsigned b = (unsigned)a.qflag[r - a.read0];   // the screening minimum (pass Q), QINF: not usable
     int jlo, jhi;
-    if (a.wl_list == nullptr) {
-        const wrec q = ((const wrec *)a.wrec)[slot];
+    if (!a.tier2) {
+        const wrec q = ((const wrec *)a.wrec_q)[r - a.read0];
         jlo = q.jlo; jhi = q.jhi;
     } else {
         candidate_columns<L>(a, r, n, b, l, jlo, jhi);
@@ -793,6 +793,82 @@ static void screen_layout(int N, int64_t nreads, int *L, int *R)
     *R = (N + l - 1) / l;
 }
 
+// ---------------------------------------------------------------------------------------------
+// the order in which the window passes take a chunk's reads
+// ---------------------------------------------------------------------------------------------
+// The read groups of a wavefront step together: pass P runs as many pre-roll blocks, pass W as many window blocks, as
+// the neediest of its 8 (4, 1) reads asks for.  In file order that is 13.6 pre-roll blocks where a read needs 7.3 on
+// average (the distance from the checkpoint to the window start is uniform in [0, ck)) and 29.8 window blocks for 28.2
+// (1 M C4 reads).  A counting sort of the reads by (window blocks, pre-roll blocks) -- three small kernels on pass Q's
+// epilogue records -- puts reads with the same needs into the same wavefront; nothing else changes, the reads are
+// independent and every pass addresses them through the list.
+constexpr int ORDER_BINS = 1024;                       // 64 classes of window blocks x 16 of pre-roll blocks
+
+struct order_args {
+    const wrec    *rec;                                // pass Q's epilogue records, [read - read0]
+    const int32_t *qflag;
+    int nreads, read0, span, ck, nck, L, wmax;
+    int32_t *hist;                                     // [ORDER_BINS] counts, then (in place) running cursors
+    int32_t *order;                                    // out: read indices (absolute), sorted by key
+};
+
+__device__ __forceinline__ int order_key(const order_args &a, int i)
+{
+    const wrec q = a.rec[i];
+    const unsigned b = (unsigned)a.qflag[i];
+    if (!((b < QSAFE) && (q.jhi >= q.jlo) && (q.jhi - q.jlo <= a.wmax))) return 0;   // not screened: no work in P / W
+    const int tx = max(0, q.jlo - a.span);             // (pass P's arithmetic)
+    int c0 = tx / a.ck;
+    if (c0 > a.nck) c0 = a.nck;
+    const int npre = c0 > 0 ? (tx - c0 * a.ck) / a.L : 0;
+    const int tbase = c0 * a.ck + npre * a.L;
+    const int nblk = (q.jhi + a.L - tbase + a.L - 1) / a.L;
+    return min(max(nblk, 1), 63) * 16 + min(npre, 15);
+}
+
+__global__ __launch_bounds__(256) void k_order_count(const order_args a)
+{
+    __shared__ int h[ORDER_BINS];
+    for (int b = threadIdx.x; b < ORDER_BINS; b += 256) h[b] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.nreads) atomicAdd(&h[order_key(a, i)], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < ORDER_BINS; b += 256)
+        if (h[b]) atomicAdd(&a.hist[b], h[b]);
+}
+
+__global__ __launch_bounds__(ORDER_BINS) void k_order_scan(int32_t *hist)   // counts -> exclusive prefix sums, in place
+{
+    __shared__ int s[ORDER_BINS];
+    const int t = threadIdx.x;
+    const int v = hist[t];
+    s[t] = v;
+    __syncthreads();
+    for (int d = 1; d < ORDER_BINS; d <<= 1) {
+        const int add = t >= d ? s[t - d] : 0;
+        __syncthreads();
+        s[t] += add;
+        __syncthreads();
+    }
+    hist[t] = s[t] - v;
+}
+
+__global__ __launch_bounds__(256) void k_order_scatter(const order_args a)
+{
+    __shared__ int h[ORDER_BINS];                      // the block's counts, then its base per bin
+    for (int b = threadIdx.x; b < ORDER_BINS; b += 256) h[b] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int key = 0, rank = 0;
+    if (i < a.nreads) { key = order_key(a, i); rank = atomicAdd(&h[key], 1); }
+    __syncthreads();
+    for (int b = threadIdx.x; b < ORDER_BINS; b += 256)
+        if (h[b]) h[b] = atomicAdd(&a.hist[b], h[b]);  // one global reservation per non-empty bin and block
+    __syncthreads();
+    if (i < a.nreads) a.order[h[key] + rank] = a.read0 + i;
+}
+
 // Screening + certified window over all reads; fills out[] and the retry list (device).
 // The caller (sk_launch_sdtw) runs the exact pass on the listed reads.
 // span / span2: look-back of the window pass's first tier (every read) and of its second tier (the reads whose
@@ -848,6 +924,12 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
     if (rc) return rc;
     if ((rc = sk_reserve(c, &c->qflag, (size_t)chunk * sizeof(int32_t)))) return rc;
     if ((rc = sk_reserve(c, &c->wrec, (size_t)chunk * sizeof(wrec)))) return rc;
+    if ((rc = sk_reserve(c, &c->wrecq, (size_t)chunk * sizeof(wrec)))) return rc;
+    // the window passes take large chunks in sorted order (SK_DTW_NOSORT=1: file order; small ones: not worth 3 launches)
+    int sort_min = 32768;
+    if (const char *e = getenv("SK_DTW_SORT_MIN")) { const int v = atoi(e); if (v > 0) sort_min = v; }   // (tests: small batches too)
+    const bool sorted = chunk >= sort_min && getenv("SK_DTW_NOSORT") == nullptr;
+    if (sorted && (rc = sk_reserve(c, &c->order, ((size_t)chunk + ORDER_BINS) * sizeof(int32_t)))) return rc;
     const bool tiers = span2 > span;
     if (tiers && (rc = sk_reserve(c, &c->wsoft, ((size_t)chunk + 1) * sizeof(int32_t)))) return rc;
 
@@ -864,7 +946,7 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
     k.nck = nck; k.ck = ck; k.span = span; k.retry = d_retry; k.retry_cnt = d_retry_cnt;
     k.ckq = (unsigned *)c->ckpt.p; k.lastq = (unsigned *)c->lastq.p; k.lq_stride = (int64_t)lq_stride;
     k.qflag = (int32_t *)c->qflag.p; k.lsum = (unsigned *)c->lsum.p;
-    k.wstate = (unsigned *)c->wstate.p; k.wrec = c->wrec.p;
+    k.wstate = (unsigned *)c->wstate.p; k.wrec = c->wrec.p; k.wrec_q = c->wrecq.p;
     k.early_cnt = d_early_cnt; k.early = d_early;
     k.qerr = (unsigned)(N + maxlen + 2);
     k.wmax = 4 * ck;
@@ -903,15 +985,33 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
         if (d_early_cnt && r0 + chunk >= a->nreads) SK_HIP(hipEventRecord(c->ev_r[0], c->stream));   // last pass Q done
         SK_HIP(hipGetLastError());
         SK_HIP(hipEventRecord(ev[1], c->stream));
+        const int32_t *order = nullptr;
+        if (sorted && k.nreads >= sort_min) {
+            order_args oa;
+            oa.rec = (const wrec *)c->wrecq.p; oa.qflag = (const int32_t *)c->qflag.p;
+            oa.nreads = k.nreads; oa.read0 = k.read0; oa.span = span; oa.ck = ck; oa.nck = nck; oa.L = L; oa.wmax = k.wmax;
+            oa.hist = (int32_t *)c->order.p; oa.order = oa.hist + ORDER_BINS;
+            SK_HIP(hipMemsetAsync(oa.hist, 0, ORDER_BINS * sizeof(int32_t), c->stream));
+            const int og = (k.nreads + 255) / 256;
+            hipLaunchKernelGGL(k_order_count, dim3(og), dim3(256), 0, c->stream, oa);
+            hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORDER_BINS), 0, c->stream, oa.hist);
+            hipLaunchKernelGGL(k_order_scatter, dim3(og), dim3(256), 0, c->stream, oa);
+            SK_HIP(hipGetLastError());
+            order = oa.order;
+        }
+        k.tier2 = 0;
         if (tiers) {
             int32_t *soft = (int32_t *)c->wsoft.p;
             SK_HIP(hipMemsetAsync(soft, 0, sizeof(int32_t), c->stream));
-            k.span = span; k.wl_list = nullptr; k.wl_count = nullptr; k.soft = soft + 1; k.soft_cnt = soft;
+            k.span = span; k.wl_list = order; k.wl_count = nullptr; k.soft = soft + 1; k.soft_cnt = soft;
             hipLaunchKernelGGL(fp, dim3(grid), dim3(256), 0, c->stream, k);
             hipLaunchKernelGGL(fw, dim3(grid), dim3(256), 0, c->stream, k);
             SK_HIP(hipGetLastError());
             k.span = span2; k.wl_list = soft + 1; k.wl_count = soft; k.soft = nullptr; k.soft_cnt = nullptr;
+            k.tier2 = 1;
             k.total_ptr = (int32_t *)c->dtwcnt.p + 1;       // reads that needed the second tier (sk_last_dtw_tier2)
+        } else {
+            k.wl_list = order; k.wl_count = nullptr;
         }
         hipLaunchKernelGGL(fp, dim3(grid), dim3(256), 0, c->stream, k);
         k.total_ptr = nullptr;

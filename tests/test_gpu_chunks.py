@@ -166,3 +166,32 @@ def test_early_retry_equals_late_retry(gpu, ora, monkeypatch):
     # (where the doubled copy holds the minimum at all, the FIRST of the two equal columns wins: first argmin)
     assert np.array_equal(got["end"][twice], want["end"][twice]) and np.mean(want["end"][twice] < 600) > 0.8
     assert not np.any((want["end"][twice] > 3000) & (want["end"][twice] < 3200))
+
+
+@pytest.mark.parametrize("lanes", [None, "8", "64"])
+def test_sorted_window_passes_equal_file_order(gpu, ora, monkeypatch, lanes):
+    """Large chunks go through the window passes sorted by how many blocks they need (a counting sort on pass Q's
+    epilogue records).  Forced onto a small ragged batch (SK_DTW_SORT_MIN=1) -- reads of many lengths, reads that are
+    not screened at all, more reads than a multiple of 8, several chunks -- the records must equal the file-order run
+    byte for byte, and the oracle."""
+    from squigglekit_amd import api, synth
+    R, M = 2003, 4000
+    motif = synth.synthetic_motif(200, seed=5)
+    sig = synth.squiggle_batch(R, M, 99017, motif=motif)
+    rng = np.random.default_rng(4)
+    lens = rng.integers(900, M + 1, R).astype(np.int32)
+    lens[::97] = rng.integers(0, 300, lens[::97].size)              # too short for the screening scheme's window
+    sig[5, :] = 500                                                  # MAD = 0
+    if lanes:
+        monkeypatch.setenv("SK_DTW_QL", lanes)
+    monkeypatch.setenv("SK_DTW_NOSORT", "1")
+    plain = api.motifseq_batch(sig, lens, motif)
+    monkeypatch.delenv("SK_DTW_NOSORT")
+    monkeypatch.setenv("SK_DTW_SORT_MIN", "1")
+    got = api.motifseq_batch(sig, lens, motif)
+    assert got.tobytes() == plain.tobytes()
+    monkeypatch.setenv("SK_DTW_SCRATCH_MB", "8")                     # several chunks, each sorted by itself
+    assert api.motifseq_batch(sig, lens, motif).tobytes() == plain.tobytes()
+    want = oracle_motifseq_threaded(ora, sig, lens, motif)
+    ok = (got["flags"] & 2) == 0
+    _same(got[ok], want[ok], "sorted window passes")

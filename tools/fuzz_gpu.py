@@ -45,7 +45,8 @@ def main():
         import os
         ql = [None, "8", "16", "64"][int(rng.integers(4))]
         for key, val in (("SK_DTW_QL", ql), ("SK_DTW_NOFUSE", "1" if rng.random() < 0.3 else None),
-                         ("SK_DTW_NO_EARLY", "1" if rng.random() < 0.3 else None)):
+                         ("SK_DTW_NO_EARLY", "1" if rng.random() < 0.3 else None),
+                         ("SK_DTW_SORT_MIN", "1" if rng.random() < 0.5 else None)):     # window passes in sorted order
             if val is None:
                 os.environ.pop(key, None)
             else:
