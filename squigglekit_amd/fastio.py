@@ -210,15 +210,19 @@ def iter_blow5_blocks_i16(path, block_reads=16384, id_width=64, nthreads=0, keep
     # A decoded chunk's pages are dropped from this process's mapping at once (they stay in the page cache), on a
     # thread of their own: left mapped, 8 GB of page-table entries are torn down when the process exits, serially,
     # while whoever started the tool waits (0.15-0.2 s per million 4 000-sample reads).
-    libc = C.CDLL(None, use_errno=True)
-    libc.madvise.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
     page = mmap.PAGESIZE
+    try:
+        libc = C.CDLL(None, use_errno=True)
+        libc.madvise.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+        dontneed = mmap.MADV_DONTNEED
+    except (OSError, AttributeError):                          # no madvise here: the pages go when the process does
+        libc = None
 
     def forget(a, b):
         a = (a + page - 1) // page * page
         b = b // page * page
-        if b > a and os.environ.get("SK_BLOW5_ZAP", "1") != "0":
-            libc.madvise(base + a, b - a, mmap.MADV_DONTNEED)
+        if libc is not None and b > a and os.environ.get("SK_BLOW5_ZAP", "1") != "0":
+            libc.madvise(base + a, b - a, dontneed)
 
     with ThreadPoolExecutor(1) as ex, ThreadPoolExecutor(1) as zapper:
         k = 0
