@@ -351,6 +351,7 @@ def main(argv=None):
         sys.stderr.write("MotifSeq: -v/--save plotting is not part of this build; ignoring\n")
 
     _mark("main() entered")
+    del _KEEP[:]                                     # (a previous call in this process: its buffers can go now)
     models, order, lens = load_models(args)
     _mark("models loaded")
     print("\t".join(HEADER + (["normalised_signal"] if args.sig_extract else [])

@@ -199,6 +199,7 @@ def main(argv=None):
         sys.stderr.write("segmenter: -v/--view plotting is not part of this build; ignoring\n")
 
     _mark("main() entered")
+    del _KEEP[:]                                     # (a previous call in this process: its buffers can go now)
     if not (args.f5_path or args.ind or args.signal or args.blow5 or args.i16):
         sys.stderr.write("Unknown file or path input")
         parser.print_help(sys.stderr)
