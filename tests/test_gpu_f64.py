@@ -145,11 +145,13 @@ def test_f64_selection_corners(gpu, ora):
 @pytest.mark.parametrize("scale,lanes", [("medmad", None), ("zscale", None), ("medmad", "8"), ("zscale", "64")])
 def test_motifseq_f64_batch_through_the_screening_scheme(gpu, ora, example_model, scale, lanes, monkeypatch):
     """Enough float64 (pA) reads for the default scheme -- fixed-point screening, pre-roll, certified window -- on the
-    normalise-on-the-fly feed, in the lane layout a batch of this size gets and in the other two."""
+    normalise-on-the-fly feed, in the lane layout a batch of this size gets and in the other two (those two also with
+    the window passes taking the reads sorted by need, which large chunks get by themselves)."""
     from concurrent.futures import ThreadPoolExecutor
     from squigglekit_amd import api
     if lanes:
         monkeypatch.setenv("SK_DTW_QL", lanes)
+        monkeypatch.setenv("SK_DTW_SORT_MIN", "1")                   # ... and the window passes in sorted order
     reads = _pa_reads(288, 2900, 11)
     rng = np.random.default_rng(4)
     for r in range(0, 288, 9):
