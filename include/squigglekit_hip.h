@@ -90,6 +90,9 @@ int  sk_init_slot(int slot, int device);
 int  sk_shutdown(void);                     /* free every per-device context              */
 int  sk_sync(void);                         /* wait for the bound device's stream         */
 int  sk_device_name(char *buf, int cap);    /* marketing/gcn name of the bound device     */
+/* "0000:c1:00.0" of the bound device (cap >= 16): the key of /sys/bus/pci/devices/<id>/local_cpulist -- a multi-GPU
+ * host binds each rank's feeder thread to the CPUs next to its GPU (squigglekit_amd/multigpu.py) */
+int  sk_device_pci_bus_id(char *buf, int cap);
 
 /* ---- device memory (for *_dev entry points) --------------------------- */
 void *sk_dev_alloc(size_t bytes);           /* NULL on failure                            */

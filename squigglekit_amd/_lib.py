@@ -99,6 +99,7 @@ ABI = {
     "sk_shutdown": (C.c_int, []),
     "sk_sync": (C.c_int, []),
     "sk_device_name": (C.c_int, [C.c_char_p, C.c_int]),
+    "sk_device_pci_bus_id": (C.c_int, [C.c_char_p, C.c_int]),
     "sk_dev_alloc": (_vp, [C.c_size_t]),
     "sk_dev_free": (C.c_int, [_vp]),
     "sk_dev_upload": (C.c_int, [_vp, _vp, C.c_size_t]),

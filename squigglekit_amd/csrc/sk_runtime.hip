@@ -174,6 +174,16 @@ int sk_device_name(char *buf, int cap)
     return SK_OK;
 }
 
+// "0000:c1:00.0" of the bound device: what /sys/bus/pci/devices/<id>/local_cpulist and numa_node are keyed on
+int sk_device_pci_bus_id(char *buf, int cap)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (!buf || cap < 16) return sk_fail(SK_ERR_INVALID, "bad buffer");
+    SK_HIP(hipDeviceGetPCIBusId(buf, cap, c->device));
+    return SK_OK;
+}
+
 void *sk_dev_alloc(size_t bytes)
 {
     sk_ctx *c = sk_cur();

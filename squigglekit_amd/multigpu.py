@@ -238,6 +238,40 @@ class RankComm:
             check(_lib.load().sk_comm_destroy())
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def bind_thread_near_device():
+    """Pin the calling thread (and the threads it starts: the tokenizer's, the formatter's) to the CPUs the bound GPU
+    hangs off -- /sys/bus/pci/devices/<bus id>/local_cpulist -- so that a rank's host buffers are first touched, and
+    its copies fed, from the GPU's own NUMA node instead of wherever the scheduler put the thread.  Best effort: no
+    such file, an empty intersection with the allowed CPUs, SK_NUMA_BIND=0 -> nothing happens.  Returns the set used."""
+    if os.environ.get("SK_NUMA_BIND", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        L = _lib.load()
+        buf = C.create_string_buffer(64)
+        if L.sk_device_pci_bus_id(buf, 64) != 0:
+            return None
+        with open("/sys/bus/pci/devices/%s/local_cpulist" % buf.value.decode().lower()) as fh:
+            near = _parse_cpulist(fh.read())
+        allowed = os.sched_getaffinity(0)
+        use = near & allowed
+        if not use or use == allowed:
+            return None
+        os.sched_setaffinity(0, use)                                 # (pid 0: the calling thread)
+        return use
+    except (OSError, ValueError):
+        return None
+
+
 def _want_rccl():
     return os.environ.get("SK_COMM", "rccl").lower() != "host"
 
@@ -330,6 +364,8 @@ class ThreadGroup:
                     # ranks sharing a device each take their own context slot, counted down from the top so that
                     # they never collide with a plain sk_init(device) (slot == device)
                     _lib.init(self.devices[rank], slot=(15 - rank) if self.shared else None)
+                    if self.world > 1 and not self.shared:
+                        bind_thread_near_device()
                 res[rank] = fn(RankComm(rank, n, self.backend, self._exchange(rank)))
             except BaseException as e:                               # noqa: BLE001 -- re-raised below
                 err[rank] = e
@@ -366,6 +402,8 @@ class ProcessGroup:
         shared = oversubscribed(environ) if world > 1 else None      # every rank on one device (dry run)
         if bind:
             _lib.init(local_rank if shared is None else shared)
+            if world > 1 and shared is None:
+                bind_thread_near_device()
         want = _want_rccl() and shared is None
         if shared is not None:
             self.why_host = "ranks share device %d (oversubscribed dry run): RCCL needs one device per rank" % shared

@@ -2,6 +2,7 @@
 library-loaded librccl, ncclCommInitAll / ncclCommInitRank, the device all-gather of hit records, and
 bench.py's self-launched gather path.  The N > 1 structure itself is covered on CPU (test_multigpu_host.py,
 test_distributed_gloo.py)."""
+import ctypes as C
 import json
 import os
 import subprocess
@@ -170,3 +171,29 @@ def test_bench_under_torch_distributed_run_one_rank(gpu):
     assert line["config"]["launch"].startswith("one process per GPU")
     assert line["config"]["gather_backend"] == "rccl" and line["config"]["ranks_seen"] == 1
     assert line["parity"]["dist_bit_identical"]
+
+
+@pytest.mark.gpu
+def test_rank_thread_binds_to_the_gpus_cpus(gpu):
+    """A rank's feeder thread is pinned to the CPUs next to its GPU (local_cpulist of the device's PCI function), only
+    that thread, and only when that narrows anything; SK_NUMA_BIND=0 leaves the affinity alone."""
+    import threading
+    from squigglekit_amd import multigpu
+    L = gpu.load()
+    buf = C.create_string_buffer(64)
+    assert L.sk_device_pci_bus_id(buf, 64) == 0 and buf.value.count(b":") == 2
+    before = os.sched_getaffinity(0)
+    out = {}
+
+    def body():
+        gpu.init(0)
+        out["use"] = multigpu.bind_thread_near_device()
+        out["after"] = os.sched_getaffinity(0)
+    t = threading.Thread(target=body)
+    t.start()
+    t.join()
+    assert os.sched_getaffinity(0) == before                     # the calling thread keeps its own
+    if out["use"] is not None:
+        assert out["after"] == out["use"] and out["use"] < before
+    else:
+        assert out["after"] == before

@@ -192,3 +192,10 @@ def test_bounded_comm_init_gives_up(monkeypatch):
         pass
     else:
         raise AssertionError("the helper's exception must reach the caller")
+
+
+def test_cpulist_parsing():
+    from squigglekit_amd import multigpu
+    assert multigpu._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert multigpu._parse_cpulist("\n") == set()
+    assert multigpu._parse_cpulist("5") == {5}
