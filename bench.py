@@ -67,6 +67,8 @@ def parse(argv=None):
                     help="skip the N = 1 extras (secondary segmenter line, exact-only schemes, end-to-end ingest)")
     ap.add_argument("--no-sensitivity", action="store_true",
                     help="skip the N = 1 sensitivity block (real-signal windows, retry-fraction sweep)")
+    ap.add_argument("--only-other-paths", action="store_true",
+                    help="N = 1: after the timed region run only the other_paths block of the extras")
     ap.add_argument("--ranks-on-device", type=int, default=None, metavar="D",
                     help="dry run: all --gpus ranks share device D (own context slot each, host-backend gather)")
     ap.add_argument("--force-comm", action="store_true",
@@ -570,6 +572,187 @@ def sensitivity_block(a, L, main):
     return out
 
 
+PA_OFFSET, PA_RANGE, PA_DIGITISATION = 16.0, 1493.94, 8192.0      # channel constants of the pA image (as tests/test_gpu_f64.py)
+
+
+def other_paths_block(a, L, main):
+    """N = 1 extras: the paths the headline does not take, each device resident, kernels only, with a roofline and a
+    parity sample against the oracle.
+      segmenter_f64_pA   -- the segmenter on float64 pA reads (segmenter.py:198-201; the values SquigglePull.py:183-189
+                            writes for the batch's reads: np.round((raw + offset) * range / digitisation, 2))
+      motifseq_f64_medmad-- MotifSeq on the same float64 reads (MotifSeq.py:270 parses every sample as float)
+      motifseq_i16_zscale-- MotifSeq -l zscale on the C4 batch (MotifSeq.py:186-191,275-280)
+      motifseq_multi_k4  -- four motifs against the C4 batch (the `for name in m_order` loop, MotifSeq.py:436)"""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as ora
+    from squigglekit_amd import synth
+    from squigglekit_amd._lib import HIT_DTYPE, SegParams, check, ptr
+    out = {"note": "HBM resident, kernels only (as the headline): wall clock of the best of 3 steps after a warm-up, "
+                   "HIP-event kernel times beside it"}
+    M, N = main.M, main.N
+    T = max(1, min(32, os.cpu_count() or 1))
+    nominal = WAVE_ISSUE_SLOTS / 8.0
+
+    def best_of(fn, n=3):
+        fn()
+        check(L.sk_sync())
+        ts, ev = [], None
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            check(L.sk_sync())
+            ts.append(time.perf_counter() - t0)
+            if ts[-1] == min(ts):
+                ev = main.kernel_ms()
+        return min(ts), ev
+
+    def dtw_view(R, cells_per_read, secs):
+        ach = R * cells_per_read / secs
+        return {"bound": "valu_issue", "achieved": ach / 1e12, "unit": "T cell-updates/s",
+                "peak_at_2.4_ghz": nominal / 1e12, "frac_at_2.4_ghz": ach / nominal,
+                "note": "whole step against the screening pass's 8-issue-cycles-per-cell roof (DESIGN.md 4.3)"}
+
+    bufs = []
+
+    def alloc(nbytes):
+        q = L.sk_dev_alloc(nbytes)
+        if not q:
+            check(-4)
+        bufs.append(q)
+        return q
+
+    try:
+        # ---------------- float64 pA reads: segmenter and MotifSeq --------------------------------------------
+        Rf = min(main.R, 250_000)
+        Mf = M - 1                                                    # segmenter.py:207 with the default -n: sig[:-1]
+        total = Rf * Mf
+        d_pa, d_off = alloc(total * 8), alloc((Rf + 1) * 8)
+        check(L.sk_synth_pa_dev(main.d_sig, main.stride, Rf, Mf, PA_OFFSET, PA_RANGE, PA_DIGITISATION, d_pa, d_off))
+        d_segs, d_nsegs = alloc(Rf * MAX_SEGS * 2 * 4), alloc(Rf * 4)
+        sp = SegParams()
+        secs, ev = best_of(lambda: check(L.sk_segment_dev_f64(d_pa, d_off, Rf, total, Mf, C.byref(sp), d_segs, d_nsegs,
+                                                              MAX_SEGS)))
+        rows = strided_rows(Rf, 512)
+        pa = download_rows(L, d_pa, Mf * 8, rows, np.float64, Mf)
+        segs = np.empty((Rf, MAX_SEGS, 2), dtype=np.int32)
+        nsegs = np.empty(Rf, dtype=np.int32)
+        check(L.sk_dev_download(ptr(segs), d_segs, segs.nbytes))
+        check(L.sk_dev_download(ptr(nsegs), d_nsegs, nsegs.nbytes))
+        op = ora.SegParams(sp.error, sp.corrector, sp.window, sp.seg_dist, sp.std_scale, sp.stall_len)
+
+        def seg_ok(k):
+            want = ora.get_segs(ora.scale_outliers(pa[k], sp.lim_low, sp.lim_hi), op) or []
+            r = rows[k]
+            return nsegs[r] == len(want) and segs[r, :nsegs[r]].tolist() == want
+        with ThreadPoolExecutor(T) as ex:
+            ok = all(ex.map(seg_ok, range(len(rows))))
+        alg = Rf * (8 * Mf + 4 + 16)
+        out["segmenter_f64_pA"] = {
+            "workload": "%d reads x %d float64 pA samples (2 decimals), default flags" % (Rf, Mf),
+            "value": Rf / secs, "unit": "reads/s", "ms_per_step": secs * 1e3,
+            "kernel_ms": {"statistics": ev[0], "walk": ev[1]},
+            "roofline": {"bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
+                         "statistics_kernel_frac": (alg / (ev[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ev[0] > 0 else None},
+            "parity": {"reads_checked": int(len(rows)), "segments_bit_exact": bool(ok),
+                       "segments_in_sample": int(nsegs[rows].sum())}}
+
+        d_hits = alloc(max(Rf, main.R) * HIT_BYTES * 4)
+
+        def hits_ok(rows_, got, want_fn):
+            with ThreadPoolExecutor(T) as ex:
+                want = list(ex.map(want_fn, range(len(rows_))))
+            d_ok = all(got["dist"][k] == w[0] for k, w in enumerate(want))
+            se_ok = all((got["start"][k], got["end"][k]) == (w[1], w[2]) for k, w in enumerate(want))
+            return {"reads_checked": int(len(rows_)), "dist_bit_identical": bool(d_ok), "start_end_exact": bool(se_ok)}
+
+        secs, ev = best_of(lambda: check(L.sk_motifseq_dev_f64(d_pa, d_off, Rf, total, Mf, ptr(main.motif), N, 0, 0, 1200,
+                                                               d_hits)))
+        hits = np.empty(Rf, dtype=HIT_DTYPE)
+        check(L.sk_dev_download(ptr(hits), d_hits, hits.nbytes))
+        rows2 = rows[::4]
+        pa2 = pa[::4]
+
+        def want_f64(k):
+            y = ora.medmad(ora.scale_outliers(pa2[k], 0, 1200))[0]
+            return ora.dtw_subsequence(main.motif, y)
+        alg = Rf * (8 * Mf + HIT_BYTES)
+        out["motifseq_f64_medmad"] = {
+            "workload": "%d reads x %d float64 pA samples vs %d-pt motif, medmad" % (Rf, Mf, N),
+            "value": Rf / secs, "unit": "reads/s", "ms_per_step": secs * 1e3,
+            "kernel_ms": {"prep": ev[0], "dtw": ev[1]},
+            "roofline": {"bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
+                         "prep_kernel_frac": (alg / (ev[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ev[0] > 0 else None,
+                         "valu": dtw_view(Rf, float(N) * float(np.mean(hits["n"])), secs)},
+            "parity": hits_ok(rows2, hits[rows2], want_f64)}
+        for q in (d_pa, d_off, d_segs, d_nsegs):
+            L.sk_dev_free(q)
+            bufs.remove(q)
+
+        # ---------------- int16, zscale ------------------------------------------------------------------------
+        R = main.R
+        secs, ev = best_of(lambda: check(L.sk_motifseq_dev_i16(main.d_sig, main.stride, main.d_len, R, ptr(main.motif), N,
+                                                               1, 0, 1200, d_hits)))
+        hits = np.empty(R, dtype=HIT_DTYPE)
+        check(L.sk_dev_download(ptr(hits), d_hits, hits.nbytes))
+        rows3 = strided_rows(R, 256)
+        sample = download_rows(L, main.d_sig, main.stride * 2, rows3, np.int16, main.stride)
+        parts = [(i, min(len(rows3), i + 8)) for i in range(0, len(rows3), 8)]
+
+        def ora_i16(motif, mode):
+            with ThreadPoolExecutor(T) as ex:
+                return np.concatenate(list(ex.map(lambda ab: ora.motifseq_batch_i16(
+                    sample[ab[0]:ab[1]], main.lens[rows3[ab[0]:ab[1]]], motif, scale_mode=mode), parts)))
+        want = ora_i16(main.motif, 1)
+        got = hits[rows3]
+        alg = R * (2 * M + HIT_BYTES)
+        out["motifseq_i16_zscale"] = {
+            "workload": workload_name("motifseq", R, M, N, "weak", "zscale"),
+            "value": R / secs, "unit": "reads/s", "ms_per_step": secs * 1e3,
+            "kernel_ms": {"prep": ev[0], "dtw": ev[1]},
+            "roofline": {"bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
+                         "prep_kernel_frac": (alg / (ev[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ev[0] > 0 else None,
+                         "valu": dtw_view(R, float(N) * float(np.mean(hits["n"])), secs)},
+            "parity": {"reads_checked": int(len(rows3)), "dist_bit_identical": bool(np.array_equal(got["dist"], want["dist"])),
+                       "start_end_exact": bool(np.array_equal(got["start"], want["start"])
+                                               and np.array_equal(got["end"], want["end"]))}}
+
+        # ---------------- int16, medmad, four motifs ------------------------------------------------------------
+        motifs = [main.motif] + [synth.synthetic_motif(n, seed=sd) for n, sd in ((N, 11), (max(8, N - 37), 12), (N + 40, 13))]
+        flat = np.concatenate(motifs)
+        moff = np.concatenate([[0], np.cumsum([m.size for m in motifs])]).astype(np.int32)
+        K = len(motifs)
+        secs, ev = best_of(lambda: check(L.sk_motifseq_multi_dev_i16(main.d_sig, main.stride, main.d_len, R, ptr(flat),
+                                                                     ptr(moff), K, 0, 0, 1200, d_hits)))
+        hits = np.empty((K, R), dtype=HIT_DTYPE)
+        check(L.sk_dev_download(ptr(hits), d_hits, hits.nbytes))
+        ok_d = ok_se = True
+        for k in range(K):
+            want = ora_i16(motifs[k], 0)
+            got = hits[k][rows3]
+            ok_d = ok_d and np.array_equal(got["dist"], want["dist"])
+            ok_se = ok_se and np.array_equal(got["start"], want["start"]) and np.array_equal(got["end"], want["end"])
+        cells = float(np.mean(hits[0]["n"])) * float(flat.size)
+        out["motifseq_multi_k4"] = {
+            "workload": "%d reads x %d int16 samples vs %d motifs (%s points), medmad" % (
+                R, M, K, ", ".join(str(m.size) for m in motifs)),
+            "value": R / secs, "unit": "reads/s", "read_motif_pairs_per_s": R * K / secs, "ms_per_step": secs * 1e3,
+            "kernel_ms": {"prep": ev[0], "dtw_last_motif": ev[1]},
+            "roofline": {"bound": "valu_issue", **dtw_view(R, cells, secs),
+                         "hbm_frac": R * (2 * M + K * HIT_BYTES) / secs / 1e9 / HBM_PEAK_GBS},
+            "parity": {"reads_checked": int(len(rows3)) * K, "dist_bit_identical": bool(ok_d), "start_end_exact": bool(ok_se)}}
+    except Exception as e:                                            # noqa: BLE001 -- report, keep the line
+        import traceback
+        out["error"] = repr(e) + " | " + traceback.format_exc(limit=2).replace("\n", " / ")
+    finally:
+        for q in bufs:
+            L.sk_dev_free(q)
+    return out
+
+
+
 def traffic_from_profiles(workload, pattern):
     """HBM bytes per read of one kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, collected
     separately with rocprofv3 --pmc: a bench run cannot read hardware counters itself)."""
@@ -877,9 +1060,12 @@ def rank_body(a, comm, rank, world, shape):
                               "note": "every rank at once: pinned host arrays -> sk_motifseq_batch_i16 (H2D of one "
                                       "sub-batch under the kernels of the previous one) -> host records; one feeder "
                                       "thread / process per GPU, slowest rank's wall clock, best of 2 after a warm-up"}
-    if world == 1 and not a.no_extras:
+    if world == 1 and a.only_other_paths:
+        line["other_paths"] = other_paths_block(a, L, w)
+    elif world == 1 and not a.no_extras:
         line.update(extras_single_gpu(a, L, w))
         if a.workload == "motifseq" and not a.no_sensitivity:
+            line["other_paths"] = other_paths_block(a, L, w)
             line["cli"] = cli_block(a, L, w)
             line["sensitivity"] = sensitivity_block(a, L, w)
     w.free()

@@ -126,6 +126,10 @@ int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
 /* device-resident form of sk_segment_batch_i16 (all pointers device). */
 int sk_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
                        const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs);
+/* device-resident form of sk_segment_batch_f64: d_off holds nreads + 1 ZERO-BASED offsets, total = d_off[nreads]
+ * (the library cannot look), max_len >= the longest read. */
+int sk_segment_dev_f64(const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t total, int64_t max_len,
+                       const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs);
 
 /* ---- dRNA adapter segmenter (dRNA_segmenter.py, slow5 branch :85-176) ---- */
 /* The script hard-codes these (dRNA_segmenter.py:80-104); they are parameters here. */
@@ -184,6 +188,14 @@ int sk_motifseq_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
                           int32_t scale_low, int32_t scale_hi, sk_hit *out);
 /* device-resident form (d_sig, d_len, d_out device; motif host). */
 int sk_motifseq_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                        const double *motif, int32_t nmotif, int32_t scale_mode,
+                        int32_t scale_low, int32_t scale_hi, sk_hit *d_out);
+/* device-resident forms of the multi-motif and float64 entry points (motifs / motif_off host; d_out is
+ * [nmotifs][nreads]; d_off zero based, total = d_off[nreads], max_len >= the longest read). */
+int sk_motifseq_multi_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                              const double *motifs, const int32_t *motif_off, int32_t nmotifs,
+                              int32_t scale_mode, int32_t scale_low, int32_t scale_hi, sk_hit *d_out);
+int sk_motifseq_dev_f64(const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t total, int64_t max_len,
                         const double *motif, int32_t nmotif, int32_t scale_mode,
                         int32_t scale_low, int32_t scale_hi, sk_hit *d_out);
 
@@ -323,6 +335,12 @@ typedef struct sk_synth_opts {
 } sk_synth_opts;
 int sk_synth_variant_dev(int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples, uint64_t seed,
                          const double *motif, int32_t nmotif, const sk_synth_opts *o);
+/* The float64 pA image of a device-resident int16 batch, value for value what SquigglePull writes for it
+ * (SquigglePull.py:183-189,238-240: np.round((raw + offset) * range / digitisation, 2)) -- input for the float64
+ * entry points (bench / tests; not a reference function of the hot path).  d_out: nreads * nsamples doubles,
+ * d_off: nreads + 1 zero-based offsets (read r at r * nsamples). */
+int sk_synth_pa_dev(const int16_t *d_raw, int64_t stride, int32_t nreads, int32_t nsamples,
+                    double offset, double range, double digitisation, double *d_out, int64_t *d_off);
 
 #ifdef __cplusplus
 }

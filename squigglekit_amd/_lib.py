@@ -111,6 +111,7 @@ ABI = {
     "sk_segment_batch_f64": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(SegParams), _vp, _vp, C.c_int32]),
     "sk_segment_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, C.POINTER(SegParams),
                                      _vp, _vp, C.c_int32]),
+    "sk_segment_dev_f64": (C.c_int, [_vp, _vp, C.c_int32, C.c_int64, C.c_int64, C.POINTER(SegParams), _vp, _vp, C.c_int32]),
     "sk_drna_segment_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32]),
     "sk_drna_roll_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, _vp]),
     "sk_motifseq_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
@@ -120,6 +121,10 @@ ABI = {
     "sk_motifseq_batch_f64": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, _vp]),
     "sk_motifseq_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, _vp]),
+    "sk_motifseq_multi_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_int32, _vp]),
+    "sk_motifseq_dev_f64": (C.c_int, [_vp, _vp, C.c_int32, C.c_int64, C.c_int64, _vp, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, _vp]),
     "sk_dtw_subsequence_batch": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, _vp]),
     "sk_dtw_subsequence": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _dp, _i32p, _i32p, _vp]),
@@ -152,6 +157,7 @@ ABI = {
     "sk_last_dtw_profile": (C.c_int, [C.POINTER(C.c_float), _i32p, C.POINTER(C.c_float), _i32p, _i32p]),
     "sk_synth_squiggles_dev": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, _vp, C.c_int32]),
     "sk_synth_variant_dev": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, _vp, C.c_int32, _vp]),
+    "sk_synth_pa_dev": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, _vp, _vp]),
 }
 
 

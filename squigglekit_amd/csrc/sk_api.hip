@@ -212,6 +212,71 @@ int sk_motifseq_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len
     return SK_OK;
 }
 
+// One (sub-)batch of the multi-motif path, everything device resident: filter + statistics once (as the prologue of
+// the first motif's screening pass when that applies), then one DTW launch set per motif.  Motif k's records go to
+// d_out + k * out_stride.
+static int motifseq_multi_dev(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nr,
+                              int16_t *d_comp, sk_prep *d_prep, const double *motifs, const int32_t *motif_off,
+                              int32_t nmotifs, int32_t scale_mode, int32_t scale_low, int32_t scale_hi,
+                              sk_hit *d_out, int64_t out_stride, int later_batch)
+{
+    int rc;
+    const bool fuse = scale_mode == SK_SCALE_MEDMAD && sk_sdtw_fuse_ok(scale_low, scale_hi);
+    sk_prep_fuse fz;
+    fz.raw = d_sig; fz.len = d_len; fz.lo = scale_low; fz.hi = scale_hi;
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    if (!fuse) {
+        rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nr, scale_low, scale_hi,
+                                scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE, 0.0, d_comp, d_prep,
+                                nullptr, 0);
+        if (rc) return rc;
+    }
+    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+    for (int32_t k = 0; k < nmotifs; k++) {
+        sk_sdtw_args a;
+        a.feed = SK_FEED_I16; a.samples = d_comp; a.stride = stride; a.off = nullptr;
+        a.prep = d_prep; a.nreads = nr; a.motif = motifs + motif_off[k];
+        a.nmotif = motif_off[k + 1] - motif_off[k]; a.out = d_out + (size_t)k * (size_t)out_stride;
+        a.last_row = nullptr; a.max_len = stride; a.force_single = 0;
+        a.accumulate = (later_batch || k > 0) ? 1 : 0;
+        a.fuse = (fuse && k == 0) ? &fz : nullptr;      // (the later motifs find the samples / statistics in place)
+        if ((rc = sk_launch_sdtw(c, &a))) return rc;
+    }
+    return SK_OK;
+}
+
+static int check_multi(const double *motifs, const int32_t *motif_off, int32_t nmotifs, int32_t scale_mode)
+{
+    if (!motifs || !motif_off || nmotifs <= 0) return sk_fail(SK_ERR_INVALID, "no motifs");
+    for (int32_t k = 0; k < nmotifs; k++)
+        if (motif_off[k + 1] <= motif_off[k]) return sk_fail(SK_ERR_INVALID, "motif %d is empty", k);
+    if (scale_mode != SK_SCALE_MEDMAD && scale_mode != SK_SCALE_ZSCALE)
+        return sk_fail(SK_ERR_INVALID, "unknown scale mode %d", scale_mode);
+    return SK_OK;
+}
+
+// device-resident form: d_out is [nmotifs][nreads]
+int sk_motifseq_multi_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                              const double *motifs, const int32_t *motif_off, int32_t nmotifs,
+                              int32_t scale_mode, int32_t scale_low, int32_t scale_hi, sk_hit *d_out)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    int rc = check_i16(d_sig, stride, d_len, nreads);
+    if (rc) return rc;
+    if ((rc = check_multi(motifs, motif_off, nmotifs, scale_mode))) return rc;
+    if (nreads == 0) return SK_OK;
+    if (!d_out) return sk_fail(SK_ERR_INVALID, "NULL out");
+    clamp_limits(&scale_low, &scale_hi);
+    if ((rc = sk_reserve(c, &c->comp, (size_t)nreads * (size_t)stride * sizeof(int16_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
+    rc = motifseq_multi_dev(c, d_sig, stride, d_len, nreads, (int16_t *)c->comp.p, (sk_prep *)c->prep.p, motifs,
+                            motif_off, nmotifs, scale_mode, scale_low, scale_hi, d_out, nreads, 0);
+    if (rc) return rc;
+    c->ev_valid = true;
+    return SK_OK;
+}
+
 // Several motifs against the same reads (the `for name in m_order` loop of MotifSeq.py:436):
 // filter + statistics once, one DTW launch set per motif.  out is [nmotifs][nreads].
 int sk_motifseq_multi_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
@@ -223,11 +288,7 @@ int sk_motifseq_multi_batch_i16(const int16_t *sig, int64_t stride, const int32_
     int rc = check_i16(sig, stride, len, nreads);
     if (rc) return rc;
     if ((rc = check_len_host(len, nreads, stride))) return rc;
-    if (!motifs || !motif_off || nmotifs <= 0) return sk_fail(SK_ERR_INVALID, "no motifs");
-    for (int32_t k = 0; k < nmotifs; k++)
-        if (motif_off[k + 1] <= motif_off[k]) return sk_fail(SK_ERR_INVALID, "motif %d is empty", k);
-    if (scale_mode != SK_SCALE_MEDMAD && scale_mode != SK_SCALE_ZSCALE)
-        return sk_fail(SK_ERR_INVALID, "unknown scale mode %d", scale_mode);
+    if ((rc = check_multi(motifs, motif_off, nmotifs, scale_mode))) return rc;
     if (nreads == 0) return SK_OK;
     if (!out) return sk_fail(SK_ERR_INVALID, "NULL out");
     clamp_limits(&scale_low, &scale_hi);
@@ -241,7 +302,6 @@ int sk_motifseq_multi_batch_i16(const int16_t *sig, int64_t stride, const int32_
     // sub-batches as in sk_motifseq_batch_i16: the H2D copy of one runs on the second stream under the kernels of the
     // previous one; filter + statistics once per sub-batch (as the prologue of the first motif's screening pass when
     // that applies), then one DTW launch set per motif
-    const bool fuse = scale_mode == SK_SCALE_MEDMAD && sk_sdtw_fuse_ok(scale_low, scale_hi);
     const SubBatches B = sub_batches(nreads, stride);
     if (B.n > 1 && (rc = second_stream(c))) return rc;
     for (int32_t bi = 0; bi < B.n; bi++) {
@@ -260,26 +320,9 @@ int sk_motifseq_multi_batch_i16(const int16_t *sig, int64_t stride, const int32_
             SK_HIP(hipEventRecord(c->ev_chunk[bi & 7], cs));
             SK_HIP(hipStreamWaitEvent(c->stream, c->ev_chunk[bi & 7], 0));
         }
-        sk_prep_fuse fz;
-        fz.raw = d_sig; fz.len = d_len; fz.lo = scale_low; fz.hi = scale_hi;
-        SK_HIP(hipEventRecord(c->ev[0], c->stream));
-        if (!fuse) {
-            rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nr, scale_low, scale_hi,
-                                    scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE, 0.0, d_comp, d_prep,
-                                    nullptr, 0);
-            if (rc) return rc;
-        }
-        SK_HIP(hipEventRecord(c->ev[1], c->stream));
-        for (int32_t k = 0; k < nmotifs; k++) {
-            sk_sdtw_args a;
-            a.feed = SK_FEED_I16; a.samples = d_comp; a.stride = stride; a.off = nullptr;
-            a.prep = d_prep; a.nreads = nr; a.motif = motifs + motif_off[k];
-            a.nmotif = motif_off[k + 1] - motif_off[k]; a.out = (sk_hit *)c->out.p + (size_t)k * nreads + r0;
-            a.last_row = nullptr; a.max_len = stride; a.force_single = 0;
-            a.accumulate = (bi > 0 || k > 0) ? 1 : 0;
-            a.fuse = (fuse && k == 0) ? &fz : nullptr;      // (the later motifs find the samples / statistics in place)
-            if ((rc = sk_launch_sdtw(c, &a))) return rc;
-        }
+        rc = motifseq_multi_dev(c, d_sig, stride, d_len, nr, d_comp, d_prep, motifs, motif_off, nmotifs, scale_mode,
+                                scale_low, scale_hi, (sk_hit *)c->out.p + r0, nreads, bi > 0);
+        if (rc) return rc;
     }
     c->ev_valid = true;
     SK_HIP(hipMemcpyAsync(out, c->out.p, ob, hipMemcpyDeviceToHost, c->stream));
@@ -312,6 +355,29 @@ static int stage_ragged_f64(sk_ctx *c, const double *sig, const int64_t *off, in
     return SK_OK;
 }
 
+// device-resident core of the float64 MotifSeq path: d_sig / d_off (zero based, nreads + 1) are device pointers
+static int motifseq_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t total,
+                            int64_t maxlen, const double *motif, int32_t nmotif, int32_t scale_mode,
+                            int32_t scale_low, int32_t scale_hi, sk_hit *d_out)
+{
+    int rc;
+    if ((rc = sk_reserve(c, &c->comp, (size_t)(total > 0 ? total : 1) * sizeof(double)))) return rc;
+    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    rc = sk_launch_prep_f64(c, d_sig, d_off, nreads, (double)scale_low,
+                            (double)scale_hi, scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE,
+                            0.0, (double *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
+    if (rc) return rc;
+    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+    sk_sdtw_args a;
+    a.feed = SK_FEED_F64_NORM; a.samples = c->comp.p; a.stride = 0; a.off = d_off;
+    a.prep = (const sk_prep *)c->prep.p; a.nreads = nreads; a.motif = motif; a.nmotif = nmotif;
+    a.out = d_out; a.last_row = nullptr; a.max_len = maxlen; a.force_single = 0;
+    if ((rc = sk_launch_sdtw(c, &a))) return rc;
+    c->ev_valid = true;
+    return SK_OK;
+}
+
 int sk_motifseq_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
                           const double *motif, int32_t nmotif, int32_t scale_mode,
                           int32_t scale_low, int32_t scale_hi, sk_hit *out)
@@ -327,24 +393,29 @@ int sk_motifseq_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
     int64_t total, maxlen;
     int rc = stage_ragged_f64(c, sig, off, nreads, &total, &maxlen);
     if (rc) return rc;
-    if ((rc = sk_reserve(c, &c->comp, (size_t)(total > 0 ? total : 1) * sizeof(double)))) return rc;
-    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
     if ((rc = sk_reserve(c, &c->out, (size_t)nreads * sizeof(sk_hit)))) return rc;
-    SK_HIP(hipEventRecord(c->ev[0], c->stream));
-    rc = sk_launch_prep_f64(c, (const double *)c->sig.p, (const int64_t *)c->off.p, nreads, (double)scale_low,
-                            (double)scale_hi, scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE,
-                            0.0, (double *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
+    rc = motifseq_dev_f64(c, (const double *)c->sig.p, (const int64_t *)c->off.p, nreads, total, maxlen, motif, nmotif,
+                          scale_mode, scale_low, scale_hi, (sk_hit *)c->out.p);
     if (rc) return rc;
-    SK_HIP(hipEventRecord(c->ev[1], c->stream));
-    sk_sdtw_args a;
-    a.feed = SK_FEED_F64_NORM; a.samples = c->comp.p; a.stride = 0; a.off = (const int64_t *)c->off.p;
-    a.prep = (const sk_prep *)c->prep.p; a.nreads = nreads; a.motif = motif; a.nmotif = nmotif;
-    a.out = (sk_hit *)c->out.p; a.last_row = nullptr; a.max_len = maxlen; a.force_single = 0;
-    if ((rc = sk_launch_sdtw(c, &a))) return rc;
-    c->ev_valid = true;
     SK_HIP(hipMemcpyAsync(out, c->out.p, (size_t)nreads * sizeof(sk_hit), hipMemcpyDeviceToHost, c->stream));
     SK_HIP(hipStreamSynchronize(c->stream));
     return SK_OK;
+}
+
+int sk_motifseq_dev_f64(const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t total, int64_t max_len,
+                        const double *motif, int32_t nmotif, int32_t scale_mode,
+                        int32_t scale_low, int32_t scale_hi, sk_hit *d_out)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (nreads < 0 || total < 0 || max_len < 0 || max_len > 0x7fffff00) return sk_fail(SK_ERR_INVALID, "bad sizes");
+    if (!motif || nmotif <= 0) return sk_fail(SK_ERR_INVALID, "empty motif");
+    if (scale_mode != SK_SCALE_MEDMAD && scale_mode != SK_SCALE_ZSCALE)
+        return sk_fail(SK_ERR_INVALID, "unknown scale mode %d", scale_mode);
+    if (nreads == 0) return SK_OK;
+    if (!d_sig || !d_off || !d_out) return sk_fail(SK_ERR_INVALID, "NULL sig/off/out");
+    return motifseq_dev_f64(c, d_sig, d_off, nreads, total, max_len, motif, nmotif, scale_mode, scale_low, scale_hi,
+                            d_out);
 }
 
 // ------------------------------------------------------------------ mlpy boundary (pre-normalised f64)
@@ -577,6 +648,30 @@ int sk_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len,
     return SK_OK;
 }
 
+// device-resident core of the float64 segmenter path (d_off zero based; d_segs zeroed here)
+static int segment_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t total,
+                           int64_t maxlen, const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs)
+{
+    int rc;
+    const int64_t words = (maxlen + 63) / 64 > 0 ? (maxlen + 63) / 64 : 1;
+    const size_t gb = (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t);
+    if ((rc = sk_reserve(c, &c->comp, (size_t)(total > 0 ? total : 1) * sizeof(double)))) return rc;
+    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
+    if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * sizeof(uint64_t)))) return rc;
+    SK_HIP(hipMemsetAsync(d_segs, 0, gb, c->stream));
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    rc = sk_launch_prep_f64(c, d_sig, d_off, nreads, (double)p->lim_low,
+                            (double)p->lim_hi, SK_PREP_SEGMENT, p->std_scale, (double *)c->comp.p,
+                            (sk_prep *)c->prep.p, (uint64_t *)c->mask.p, nreads);
+    if (rc) return rc;
+    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+    rc = sk_launch_segment_walk(c, (const uint64_t *)c->mask.p, nreads, nullptr, (const sk_prep *)c->prep.p,
+                                nreads, p, d_segs, d_nsegs, max_segs);
+    if (rc) return rc;
+    c->ev_valid = true;
+    return SK_OK;
+}
+
 int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads, const sk_seg_params *p,
                          int32_t *segs, int32_t *nsegs, int32_t max_segs)
 {
@@ -590,24 +685,12 @@ int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads, 
     if (!segs || !nsegs) return sk_fail(SK_ERR_INVALID, "NULL segs/nsegs");
     int64_t total, maxlen;
     if ((rc = stage_ragged_f64(c, sig, off, nreads, &total, &maxlen))) return rc;
-    const int64_t words = (maxlen + 63) / 64 > 0 ? (maxlen + 63) / 64 : 1;
     const size_t gb = (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t);
-    if ((rc = sk_reserve(c, &c->comp, (size_t)(total > 0 ? total : 1) * sizeof(double)))) return rc;
-    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
-    if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * sizeof(uint64_t)))) return rc;
     if ((rc = sk_reserve(c, &c->out, gb))) return rc;
     if ((rc = sk_reserve(c, &c->out2, (size_t)nreads * sizeof(int32_t)))) return rc;
-    SK_HIP(hipMemsetAsync(c->out.p, 0, gb, c->stream));
-    SK_HIP(hipEventRecord(c->ev[0], c->stream));
-    rc = sk_launch_prep_f64(c, (const double *)c->sig.p, (const int64_t *)c->off.p, nreads, (double)p->lim_low,
-                            (double)p->lim_hi, SK_PREP_SEGMENT, p->std_scale, (double *)c->comp.p,
-                            (sk_prep *)c->prep.p, (uint64_t *)c->mask.p, nreads);
+    rc = segment_dev_f64(c, (const double *)c->sig.p, (const int64_t *)c->off.p, nreads, total, maxlen, p,
+                         (int32_t *)c->out.p, (int32_t *)c->out2.p, max_segs);
     if (rc) return rc;
-    SK_HIP(hipEventRecord(c->ev[1], c->stream));
-    rc = sk_launch_segment_walk(c, (const uint64_t *)c->mask.p, nreads, nullptr, (const sk_prep *)c->prep.p,
-                                nreads, p, (int32_t *)c->out.p, (int32_t *)c->out2.p, max_segs);
-    if (rc) return rc;
-    c->ev_valid = true;
     SK_HIP(hipMemcpyAsync(segs, c->out.p, gb, hipMemcpyDeviceToHost, c->stream));
     SK_HIP(hipMemcpyAsync(nsegs, c->out2.p, (size_t)nreads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     SK_HIP(hipStreamSynchronize(c->stream));
@@ -615,6 +698,20 @@ int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads, 
         if (nsegs[r] > max_segs)
             return sk_fail(SK_ERR_OVERFLOW, "read %d has %d segments, max_segs is %d", r, nsegs[r], max_segs);
     return SK_OK;
+}
+
+int sk_segment_dev_f64(const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t total, int64_t max_len,
+                       const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (nreads < 0 || total < 0 || max_len < 0 || max_len > 0x7fffff00) return sk_fail(SK_ERR_INVALID, "bad sizes");
+    int rc = check_seg_params(p);
+    if (rc) return rc;
+    if (max_segs <= 0) return sk_fail(SK_ERR_INVALID, "max_segs must be positive");
+    if (nreads == 0) return SK_OK;
+    if (!d_sig || !d_off || !d_segs || !d_nsegs) return sk_fail(SK_ERR_INVALID, "NULL sig/off/segs/nsegs");
+    return segment_dev_f64(c, d_sig, d_off, nreads, total, max_len, p, d_segs, d_nsegs, max_segs);
 }
 
 // ------------------------------------------------------------------ dRNA adapter segmenter
@@ -770,6 +867,21 @@ int sk_synth_variant_dev(int16_t *d_sig, int64_t stride, int32_t nreads, int32_t
         rc = sk_launch_synth(c, d_sig, stride, nreads, nsamples, seed, d_m, nmotif, o->row0, o->hit_permille,
                              o->stretch_permille, o->stretch);
     }
+    if (rc) return rc;
+    SK_HIP(hipStreamSynchronize(c->stream));
+    return SK_OK;
+}
+
+// The float64 pA image of an int16 batch, as SquigglePull.py:183-189,238-240 writes it (bench / test input for the
+// float64 entry points): d_out[nreads * nsamples] doubles, d_off[nreads + 1] zero-based offsets.
+int sk_synth_pa_dev(const int16_t *d_raw, int64_t stride, int32_t nreads, int32_t nsamples,
+                    double offset, double range, double digitisation, double *d_out, int64_t *d_off)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (!d_raw || !d_out || !d_off || stride < nsamples || nreads < 0 || nsamples < 0 || !(digitisation > 0))
+        return sk_fail(SK_ERR_INVALID, "bad arguments");
+    int rc = sk_launch_raw_to_pa(c, d_raw, stride, nreads, nsamples, offset, range / digitisation, d_out, d_off);
     if (rc) return rc;
     SK_HIP(hipStreamSynchronize(c->stream));
     return SK_OK;

@@ -191,3 +191,5 @@ int sk_launch_synth(sk_ctx *c, int16_t *d_sig, int64_t stride, int32_t nreads, i
                     int hit_pm = 500, int stretch_pm = 0, int stretch = 1);
 int sk_launch_synth_windows(sk_ctx *c, int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
                             uint64_t seed, int64_t row0, const int16_t *d_tmpl, int32_t ntmpl, float sigma);
+int sk_launch_raw_to_pa(sk_ctx *c, const int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
+                        double offset, double raw_unit, double *d_out, int64_t *d_off);

@@ -128,7 +128,35 @@ void k_synth(int16_t *__restrict__ sig, int64_t stride, int nreads, int M, uint6
     }
 }
 
+// int16 raw rows -> the float64 pA values SquigglePull writes (SquigglePull.py:183-189,238-240):
+// np.round((raw + offset) * (range / digitisation), 2) = rint(v * 100) / 100 -- three correctly rounded operations --
+// as one contiguous ragged batch: read r at out[r * nsamples ..), off[r] = r * nsamples.
+__global__ __launch_bounds__(256)
+void k_raw_to_pa(const int16_t *__restrict__ sig, int64_t stride, int nreads, int nsamples, double offset,
+                 double raw_unit, double *__restrict__ out, int64_t *__restrict__ off)
+{
+    const int64_t total = (int64_t)nreads * nsamples;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / nsamples;
+        const int k = (int)(i - r * nsamples);
+        const double v = ((double)sig[r * stride + k] + offset) * raw_unit;
+        out[i] = rint(v * 100.0) / 100.0;
+    }
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= nreads; r += (int64_t)gridDim.x * blockDim.x)
+        off[r] = r * nsamples;
+}
+
 } // namespace
+
+int sk_launch_raw_to_pa(sk_ctx *c, const int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
+                        double offset, double raw_unit, double *d_out, int64_t *d_off)
+{
+    if (nreads <= 0 || nsamples <= 0) return SK_OK;
+    hipLaunchKernelGGL(k_raw_to_pa, dim3(c->num_cu * 8), dim3(256), 0, c->stream, d_sig, stride, nreads, nsamples,
+                       offset, raw_unit, d_out, d_off);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
+}
 
 int sk_launch_synth(sk_ctx *c, int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
                     uint64_t seed, const int16_t *d_motif_i16, int32_t nmotif, int64_t row0,
