@@ -308,6 +308,10 @@ int sk_last_dtw_retries(void);
 /* Reads of the most recent DTW call whose path crossed the window pass's first (short) look-back and were redone
  * by its second tier (diagnostic; 0 when the call did not use the screening scheme). */
 int sk_last_dtw_tier2(void);
+/* Reads of the most recent float64 call (sk_segment_*_f64, sk_motifseq_*_f64 with medmad) whose comparisons /
+ * selection the streaming statistics kernel could not certify and that were redone in numpy's order (diagnostic);
+ * -1 when the call did not use the streaming kernel (reads longer than 4 096 samples, zscale). */
+int sk_last_f64_retries(void);
 /* Shader clock (GHz) the screening pass of the most recent DTW call ran at: its first wavefront counts shader cycles
  * (s_memtime) against the constant 100 MHz reference (s_memrealtime) over its whole sweep.  0 when the call did not
  * use the screening scheme.  bench.py prices the VALU-issue roofline at this clock instead of a nominal one. */

@@ -153,6 +153,7 @@ ABI = {
     "sk_last_kernel_ms": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sk_last_dtw_retries": (C.c_int, []),
     "sk_last_dtw_tier2": (C.c_int, []),
+    "sk_last_f64_retries": (C.c_int, []),
     "sk_last_dtw_clock": (C.c_int, [_dp]),
     "sk_last_dtw_profile": (C.c_int, [C.POINTER(C.c_float), _i32p, C.POINTER(C.c_float), _i32p, _i32p]),
     "sk_synth_squiggles_dev": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, _vp, C.c_int32]),

@@ -364,9 +364,24 @@ static int motifseq_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off
     if ((rc = sk_reserve(c, &c->comp, (size_t)(total > 0 ? total : 1) * sizeof(double)))) return rc;
     if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
     SK_HIP(hipEventRecord(c->ev[0], c->stream));
-    rc = sk_launch_prep_f64(c, d_sig, d_off, nreads, (double)scale_low,
-                            (double)scale_hi, scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE,
-                            0.0, (double *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
+    c->f64_stream = 0;
+    if (scale_mode == SK_SCALE_MEDMAD && sk_f64_fast_applies(maxlen, 1.0)) {
+        c->f64_stream = 1;
+        // streaming statistics (sk_f64stat.hip), then the general kernel over the (almost always empty) list of reads
+        // whose median / MAD bin it could not resolve
+        if ((rc = sk_reserve(c, &c->retry, ((size_t)nreads + 16) * sizeof(int32_t)))) return rc;
+        int32_t *retry = (int32_t *)c->retry.p;
+        rc = sk_launch_f64_stats(c, d_sig, d_off, nreads, maxlen, (double)scale_low, (double)scale_hi, SK_PREP_MEDMAD,
+                                 0.0, (sk_prep *)c->prep.p, nullptr, 0, nullptr, retry, (double *)c->comp.p);
+        if (rc) return rc;
+        rc = sk_launch_prep_f64_listed(c, d_sig, d_off, retry + 1, retry, nreads < 2 * c->num_cu ? nreads : 2 * c->num_cu,
+                                       (double)scale_low, (double)scale_hi, SK_PREP_MEDMAD, 0.0, (double *)c->comp.p, 0,
+                                       (sk_prep *)c->prep.p, nullptr, 0);
+    } else {
+        rc = sk_launch_prep_f64(c, d_sig, d_off, nreads, (double)scale_low,
+                                (double)scale_hi, scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE,
+                                0.0, (double *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
+    }
     if (rc) return rc;
     SK_HIP(hipEventRecord(c->ev[1], c->stream));
     sk_sdtw_args a;
@@ -655,6 +670,35 @@ static int segment_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off,
     int rc;
     const int64_t words = (maxlen + 63) / 64 > 0 ? (maxlen + 63) / 64 : 1;
     const size_t gb = (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t);
+    c->f64_stream = 0;
+    if (sk_f64_fast_applies(maxlen, p->std_scale)) {
+        c->f64_stream = 1;
+        // streaming statistics with certified comparisons (sk_f64stat.hip), the numpy-order kernel over the (almost
+        // always empty) list of uncertified reads, then the run-hopping walk of the int16 path over the same masks
+        const int row16 = sk_f64_row16(maxlen > 0 ? maxlen : 1);
+        const int grid = nreads < 2 * c->num_cu ? nreads : 2 * c->num_cu;
+        const int64_t srow = (maxlen + 7) & ~(int64_t)7;
+        if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
+        if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)row16 * 16))) return rc;
+        if ((rc = sk_reserve(c, &c->len, (size_t)nreads * sizeof(int32_t)))) return rc;
+        if ((rc = sk_reserve(c, &c->retry, ((size_t)nreads + 16) * sizeof(int32_t)))) return rc;
+        if ((rc = sk_reserve(c, &c->comp, (size_t)grid * (size_t)(srow > 0 ? srow : 8) * sizeof(double)))) return rc;
+        int32_t *retry = (int32_t *)c->retry.p;
+        SK_HIP(hipMemsetAsync(d_segs, 0, gb, c->stream));
+        SK_HIP(hipEventRecord(c->ev[0], c->stream));
+        rc = sk_launch_f64_stats(c, d_sig, d_off, nreads, maxlen, (double)p->lim_low, (double)p->lim_hi, SK_PREP_SEGMENT,
+                                 p->std_scale, (sk_prep *)c->prep.p, c->mask.p, row16, (int32_t *)c->len.p, retry, nullptr);
+        if (rc) return rc;
+        rc = sk_launch_prep_f64_listed(c, d_sig, d_off, retry + 1, retry, grid, (double)p->lim_low, (double)p->lim_hi,
+                                       SK_PREP_SEGMENT, p->std_scale, (double *)c->comp.p, srow, (sk_prep *)c->prep.p,
+                                       c->mask.p, row16);
+        if (rc) return rc;
+        SK_HIP(hipEventRecord(c->ev[1], c->stream));
+        rc = sk_launch_seg_walk_masks(c, c->mask.p, row16, (const int32_t *)c->len.p, nreads, p, d_segs, d_nsegs, max_segs);
+        if (rc) return rc;
+        c->ev_valid = true;
+        return SK_OK;
+    }
     if ((rc = sk_reserve(c, &c->comp, (size_t)(total > 0 ? total : 1) * sizeof(double)))) return rc;
     if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
     if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * sizeof(uint64_t)))) return rc;
@@ -885,6 +929,19 @@ int sk_synth_pa_dev(const int16_t *d_raw, int64_t stride, int32_t nreads, int32_
     if (rc) return rc;
     SK_HIP(hipStreamSynchronize(c->stream));
     return SK_OK;
+}
+
+// Reads of the most recent float64 call (segmenter or MotifSeq medmad) that the streaming statistics kernel handed
+// to the numpy-order kernel (diagnostic); -1 when that call did not take the streaming kernel.
+int sk_last_f64_retries(void)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (!c->f64_stream || !c->retry.p) return -1;
+    int32_t n = 0;
+    SK_HIP(hipStreamSynchronize(c->stream));
+    SK_HIP(hipMemcpy(&n, c->retry.p, sizeof n, hipMemcpyDeviceToHost));
+    return n;
 }
 
 } // extern "C"

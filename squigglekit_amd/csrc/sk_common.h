@@ -73,6 +73,7 @@ struct sk_ctx {
     bool   retry_dev = false;   // the last DTW call left its retry count on the device (read lazily)
     std::vector<unsigned> motifq_host;
     bool   motifq_valid = false;
+    int    f64_stream = 0;   // the last float64 call took the streaming statistics kernel (its retry count: retry[0])
     int    last_retry = 0;   // reads that needed the exact single-pass retry in the last DTW call
     std::vector<hipEvent_t> evpool;   // per-launch events of the two-pass DTW (3 per chunk)
     int    prof_chunks = 0;  // chunks of the last two-pass DTW call (0: single pass)
@@ -193,3 +194,16 @@ int sk_launch_synth_windows(sk_ctx *c, int16_t *d_sig, int64_t stride, int32_t n
                             uint64_t seed, int64_t row0, const int16_t *d_tmpl, int32_t ntmpl, float sigma);
 int sk_launch_raw_to_pa(sk_ctx *c, const int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
                         double offset, double raw_unit, double *d_out, int64_t *d_off);
+
+// ---- float64 reads, streaming statistics (sk_f64stat.hip) + the numpy-order redo of its uncertified reads ----
+bool sk_f64_fast_applies(int64_t maxlen, double std_scale);
+int  sk_f64_row16(int64_t maxlen);
+int  sk_launch_f64_stats(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t maxlen,
+                         double lo, double hi, int mode, double std_scale, sk_prep *d_prep, void *d_mask2, int row16,
+                         int32_t *d_len, int32_t *d_retry, double *d_comp);
+int  sk_launch_prep_f64_listed(sk_ctx *c, const double *d_sig, const int64_t *d_off, const int32_t *d_list,
+                               const int32_t *d_count, int grid, double lo, double hi, int mode, double std_scale,
+                               double *d_comp_or_scratch, int64_t scratch_stride, sk_prep *d_prep, void *d_mask2,
+                               int row16);
+int  sk_launch_seg_walk_masks(sk_ctx *c, const void *d_mask2, int row16, const int32_t *d_len, int32_t nreads,
+                              const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs);

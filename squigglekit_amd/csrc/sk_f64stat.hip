@@ -1,0 +1,441 @@
+// sk_f64stat.hip -- filter + statistics of FLOAT64 reads as one streaming pass (gfx950).
+//
+// The float64 twin of sk_segstat.hip (segmenter) and sk_prepw.hip (MotifSeq medmad) for the reads the reference
+// parses as floats: pA TSVs (segmenter.py:198-201; SquigglePull.py:183-189 writes np.round(pA, 2)) and every
+// MotifSeq --signal read (MotifSeq.py:270).  Per read:
+//   scale_outliers      segmenter.py:311-318 / MotifSeq.py:317-324    strict lo < x < hi
+//   np.median           segmenter.py:410 / MotifSeq.py:194            exact (a sample, or the mean of two)
+//   segmenter:  np.std -> top / bot (:412-414), `a < top and a > bot` (:431) as two bit masks in RAW coordinates
+//               ({in band, kept}, the layout k_seg_walk3 of sk_segstat.hip walks)
+//   MotifSeq:   MAD = median(|x - med|) (:195-196), the filtered samples in order for the DTW feed
+//
+// One wavefront owns one read of up to 64 NJ samples from its first load to its last store: lane l keeps samples
+// 64 j + l (j < NJ) in registers -- 8-byte loads, 512 contiguous bytes per instruction, rows need no alignment
+// beyond the doubles' own -- so every v_cmp over slot j yields, as its lane mask, the mask word of samples
+// 64 j .. 64 j + 63.  No workgroup barrier, no second look at memory.
+//
+// Median of arbitrary doubles without sorting: a 2048-bin LDS histogram over [min, max] of the kept samples
+// (bin = (x - min) * scale, monotone in x), a rank select on it, then the members of the selected bin (a handful:
+// for pA data on the 0.01 grid one bin holds at most one distinct value) are gathered and ranked exactly.  Reads
+// whose selected bin holds more than 64 members that are not all equal go to the retry list.
+//
+// Segmenter thresholds WITHOUT numpy's summation order (the float64 analogue of sk_segstat.hip's certificate):
+// the state machine only sees the comparisons x < top, x > bot.  std is computed from shifted sums in any order
+// with a rigorous error bound; numpy's top / bot lie within delta of ours; a sample is classified from
+// u = |x - median| as "in band" when u < spread - delta and "out" when u > spread + delta.  If some kept sample
+// falls between the two the read is UNCERTIFIED and goes to the retry list, which the numpy-order kernel
+// (k_prep_f64<LISTED>, sk_prep.hip) redoes, rewriting the read's masks in place.  For pA reads that happens about
+// once per 10^6 reads; all-equal reads (std = 0, where numpy's own rounding decides) always take it.
+//
+// Algorithmic HBM traffic per read: 8 M in; segmenter: M / 4 out (masks) + 52 B; MotifSeq: 8 n out (the filtered
+// samples for the DTW kernels) + 48 B.
+#include "sk_common.h"
+#include <math.h>
+#include <stdlib.h>
+
+// v_writelane_b32: this clang has no builtin for it; the LLVM intrinsic is reachable through an asm label
+extern "C" __device__ int sk_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+namespace {
+
+constexpr int WPB = 4;                  // wavefronts (= reads in flight) per workgroup
+constexpr int NB = 2048;                // histogram bins per round
+constexpr int PER = NB / 64;            // bins a lane owns in the first sweep of the rank select
+constexpr int CAP = 64;                 // members of the selected bin that are ranked exactly (one per lane)
+constexpr int MODE_SEG = 0, MODE_MEDMAD = 1;
+constexpr double U53 = 1.1102230246251565e-16;   // 2^-53
+
+struct F64StatArgs {
+    const double  *sig;
+    const int64_t *off;                 // zero based, nreads + 1
+    int            nreads;
+    double         lo, hi;              // outlier limits (strict)
+    double         std_scale;           // segmenter
+    double         delta_scale;         // 1.0; tests raise it to push reads onto the retry list
+    sk_prep       *prep;
+    uint4         *mask2;               // segmenter: [nreads][row16] of {in band lo, hi, kept lo, hi}
+    int            row16;
+    int32_t       *len_out;             // segmenter: the read's length (the walk's `len`)
+    int32_t       *retry;               // [0] = count, [1 ..] = reads the numpy-order kernel has to redo
+    double        *comp;                // MotifSeq: filtered samples of read r at comp + off[r]
+};
+
+__device__ __forceinline__ double vmin64(double a, double b)    // one v_min_f64 (operands are never NaN here)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmax64(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// inclusive scan inside each half of 32 lanes
+__device__ __forceinline__ int half_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    return v;
+}
+__device__ __forceinline__ double wave_min64(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = vmin64(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ double wave_max64(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = vmax64(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ double wave_sum64(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ double readlane64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// Bin, count and exclusive prefix of the bin that holds rank k (0 <= k < sum of the counts); b < 0: inconsistent.
+struct RankSel { int b, pre, c; };
+
+__device__ __forceinline__ void rank_select2(const unsigned *hist, int lane, int k1, int k2, RankSel &r1, RankSel &r2)
+{
+    const int hb0 = lane * PER;
+    int local = 0;
+#pragma unroll
+    for (int q = 0; q < PER / 4; q += 2) {               // two 16-byte reads in flight (all eight: 32 registers)
+        const uint4 v = *(const uint4 *)(hist + hb0 + 4 * q);
+        const uint4 u = *(const uint4 *)(hist + hb0 + 4 * q + 4);
+        local += (int)(v.x + v.y + v.z + v.w) + (int)(u.x + u.y + u.z + u.w);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int inc = wave_incl_scan(local), pre = inc - local;
+    // the lane whose 32 bins hold the rank is found from the scan; then ALL lanes look at that lane's bins, one
+    // bin per lane (both halves of the wave do the same work), instead of every lane scanning its own 32
+    auto one = [&](int k) -> RankSel {
+        const unsigned long long own = __ballot(k >= pre && k < inc);
+        const int ol = own ? (int)__builtin_ctzll(own) : 0;
+        const int opre = __builtin_amdgcn_readlane(pre, ol);
+        const int c = (int)hist[ol * PER + (lane & (PER - 1))];
+        const int acc = opre + half_incl_scan(c);
+        const unsigned hit = (unsigned)__ballot(acc > k);           // (low half)
+        const int bi = hit ? (int)__builtin_ctz(hit) : 0;
+        RankSel rs;
+        rs.b = (own != 0ull && hit != 0u) ? ol * PER + bi : -1;
+        rs.c = __builtin_amdgcn_readlane(c, bi);
+        rs.pre = __builtin_amdgcn_readlane(acc - c, bi);
+        return rs;
+    };
+    r1 = one(k1);
+    r2 = r1;
+    if (k2 != k1) r2 = one(k2);
+}
+
+template <int NJ, int MODE, int OCC>
+__global__ __launch_bounds__(64 * WPB, OCC)
+void k_f64_stats(const F64StatArgs a)
+{
+    __shared__ __align__(16) unsigned hist_all[WPB][NB + 64];       // [NB]: dump bin (dropped samples)
+    __shared__ __align__(16) double list_all[WPB][CAP];
+    __shared__ unsigned cnt_all[WPB][2];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned *hist = hist_all[w];
+    double *list = list_all[w];
+    unsigned *cnt = cnt_all[w];
+    const double INF = __builtin_huge_val();
+
+    auto clear_hist = [&]() {
+#pragma unroll
+        for (int q = 0; q < PER / 4; q++) *(uint4 *)(hist + lane * PER + 4 * q) = make_uint4(0u, 0u, 0u, 0u);
+        hist[NB + lane] = 0u;
+    };
+    clear_hist();
+
+    const int nwaves = gridDim.x * WPB;
+    for (int r = blockIdx.x * WPB + w; r < a.nreads; r += nwaves) {
+        const int64_t o0 = a.off[r];
+        const int M = __builtin_amdgcn_readfirstlane((int)min(max(a.off[r + 1] - o0, (int64_t)0), (int64_t)(64 * NJ)));
+        const double *row = a.sig + o0;
+
+        // ---- the read into registers: lane l holds samples 64 j + l; slots past the end read as +inf ----------
+        // (the validity test is `lane < M - 64 j` with a scalar right-hand side: written as `64 j + lane < M` the
+        // compiler keeps all NJ lane indices in vector registers across the whole kernel)
+        double x[NJ];
+        const double *prow = row + lane;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            int rem = M - 64 * j;
+            asm("" : "+s"(rem));                        // (opaque: else it is folded back into 64 j + lane < M)
+            x[j] = (lane < rem) ? prow[64 * j] : INF;
+        }
+
+        // ---- first look: filter (lane mask of the compare = the "kept" word), extremes, shifted sums -----------
+        // dropped samples are overwritten with +inf: every later pass sees them fall out by themselves
+        unsigned kplo = 0u, kphi = 0u;                  // lane j: the kept word of slot j
+        unsigned long long anydrop = 0ull;              // bit j: slot j holds dropped samples (or the read's end)
+        int n = 0;
+        double mn = INF, mx = -INF, S1 = 0.0, S2 = 0.0;
+        double K = readlane64(x[0], 0);                 // shift of the sums (any finite value near the data)
+        if (!(K > a.lo && K < a.hi)) K = 0.5 * (a.lo + a.hi);
+        if (!(fabs(K) < 1e300)) K = 0.0;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            if (64 * j >= M) continue;                  // (wave-uniform)
+            const bool k = x[j] > a.lo && x[j] < a.hi;
+            const unsigned long long km = __ballot(k);
+            kplo = (unsigned)sk_writelane_i32((int)(unsigned)km, j, (int)kplo);
+            kphi = (unsigned)sk_writelane_i32((int)(unsigned)(km >> 32), j, (int)kphi);
+            n += __popcll(km);
+            if (km != ~0ull) { anydrop |= 1ull << j; x[j] = k ? x[j] : INF; }
+            if (k) {
+                mn = vmin64(mn, x[j]);
+                mx = vmax64(mx, x[j]);
+                if (MODE == MODE_SEG) {
+                    const double d = x[j] - K;
+                    S1 += d;
+                    S2 = fma(d, d, S2);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);          // one slot after the other: interleaved, the slots' temporaries add up
+        }
+        // (wave-uniform from here on: into scalar registers, the vector ones are needed for the samples)
+        mn = readlane64(wave_min64(mn), 0);
+        mx = readlane64(wave_max64(mx), 0);
+        if (MODE == MODE_SEG) {
+            S1 = readlane64(wave_sum64(S1), 0);
+            S2 = readlane64(wave_sum64(S2), 0);
+        }
+
+        sk_prep pr;
+        pr.n = n; pr.flags = 0; pr.center = 0.0; pr.scale = 1.0; pr.top = 0.0; pr.bot = 0.0;
+        bool ok = true;
+        unsigned inlo = 0u, inhi = 0u;
+
+        // exact order statistics k1 <= k2 <= k1 + 1 of val(j) over the kept samples, val in [vlo, vhi], vlo < vhi:
+        // histogram over [vlo, vhi], rank select, members of the selected bin ranked exactly
+        auto select2 = [&](auto val, double vlo, double vhi, int k1, int k2, double &v1, double &v2) -> bool {
+            const double sc = ((double)NB - 0.5) / (vhi - vlo);
+            if (!(sc > 0.0 && sc < 1e300)) return false;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                if (64 * j >= M) continue;
+                unsigned b = (unsigned)((val(j) - vlo) * sc);               // v_cvt_u32_f64 saturates: +inf -> 2^32 - 1
+                if ((anydrop >> j) & 1ull) b = min(b, (unsigned)NB);        // dropped -> the dump bin
+                atomicAdd(&hist[b], 1u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            RankSel r1, r2;
+            rank_select2(hist, lane, k1, k2, r1, r2);
+            clear_hist();
+            if (lane == 0) cnt[0] = 0u;
+            if (r1.b < 0 || r2.b < 0) return false;
+            const bool two = r2.b != r1.b;
+            double mnm = INF, mxm = -INF, mn2 = INF;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                if (64 * j >= M) continue;
+                const double v = val(j);
+                const unsigned b = (unsigned)((v - vlo) * sc);
+                if (b == (unsigned)r1.b) {
+                    const unsigned slot = atomicAdd(&cnt[0], 1u);
+                    if (slot < (unsigned)CAP) list[slot] = v;
+                    mnm = vmin64(mnm, v);
+                    mxm = vmax64(mxm, v);
+                }
+                if (two && b == (unsigned)r2.b) mn2 = vmin64(mn2, v);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mnm = readlane64(wave_min64(mnm), 0);
+            mxm = readlane64(wave_max64(mxm), 0);
+            if (two) mn2 = readlane64(wave_min64(mn2), 0);
+            const int j1 = k1 - r1.pre;                 // rank of k1 inside its bin
+            if (mnm == mxm) {                           // one distinct value in the bin (the usual case on gridded data)
+                v1 = mnm;
+                v2 = two ? mn2 : mnm;
+                return true;
+            }
+            if (r1.c > CAP) return false;
+            // exact ranks among the <= 64 members: lane l takes member l and counts the members ordered before it
+            const double m = (lane < r1.c) ? list[lane] : INF;
+            int rk = 0;
+            for (int k = 0; k < r1.c; k++) {
+                const double mk = list[k];
+                rk += (mk < m || (mk == m && k < lane)) ? 1 : 0;
+            }
+            const unsigned long long h1 = __ballot(lane < r1.c && rk == j1);
+            if (h1 == 0ull) return false;
+            v1 = readlane64(m, (int)__builtin_ctzll(h1));
+            if (two) v2 = mn2;                          // k2 is the first element of the next occupied bin
+            else if (k2 != k1) {
+                const unsigned long long h2 = __ballot(lane < r1.c && rk == j1 + 1);
+                if (h2 == 0ull) return false;
+                v2 = readlane64(m, (int)__builtin_ctzll(h2));
+            } else v2 = v1;
+            return true;
+        };
+
+        if (n == 0) {
+            pr.flags = SK_FLAG_EMPTY;
+            const double qnan = __builtin_nan("");
+            pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
+        } else {
+            // ---- median ------------------------------------------------------------------------------------------
+            const int k1 = (n - 1) / 2, k2 = n / 2;
+            double v1 = mn, v2 = mn;
+            if (mn != mx) ok = select2([&](int j) { return x[j]; }, mn, mx, k1, k2, v1, v2);
+            const double median = (k1 == k2) ? v1 : (v1 + v2) / 2.0;         // np.median: mean of the two middle elements
+
+            if (MODE == MODE_MEDMAD) {
+                // ---- MAD = median(|x - med|)   MotifSeq.py:195 ---------------------------------------------------
+                double w1 = 0.0, w2 = 0.0;
+                const double umax = vmax64(fabs(mn - median), fabs(mx - median));
+                if (ok && umax > 0.0)
+                    ok = select2([&](int j) { return fabs(x[j] - median); }, 0.0, umax, k1, k2, w1, w2);
+                const double mad = (k1 == k2) ? w1 : (w1 + w2) / 2.0;
+                pr.center = median;
+                pr.scale = mad * 1.4826;                                     // MotifSeq.py:196
+                if (mad == 0.0) pr.flags |= SK_FLAG_DEGENERATE;
+            } else {
+                // ---- thresholds + certificate (file header) ------------------------------------------------------
+                const double dn = (double)n;
+                const double md = S1 / dn, Q = S2 / dn;
+                const double var = Q - md * md;
+                const double Ev = 8.0 * (dn + 8.0) * U53 * Q;                // |var - var_true|
+                const double sd = sqrt(var);
+                const double A = vmax64(fabs(mn), fabs(mx));
+                const double dstd = Ev / sd + dn * U53 * A + sd * (dn + 8.0) * U53;     // |sd - numpy's std|
+                const double spread = sd * a.std_scale;                      // segmenter.py:413-414
+                const double dlt = a.delta_scale * 4.0 *
+                                   (fabs(a.std_scale) * dstd + U53 * (4.0 * fabs(spread) + fabs(median) + 2.0 * A));
+                if (!(var > 4.0 * Ev)) ok = false;                           // (also NaN; all-equal reads)
+                const double s_lo = spread - dlt, s_hi = spread + dlt;
+                pr.center = median; pr.scale = sd; pr.top = median + spread; pr.bot = median - spread;
+                // ---- second look: in band / out of band / undecided -------------------------------------------
+                unsigned long long unc = 0ull;
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    if (64 * j >= M) continue;
+                    const double u = fabs(x[j] - median);                    // dropped samples: +inf, out of band
+                    const unsigned long long im = __ballot(u < s_lo);
+                    unc |= ~(im | __ballot(u > s_hi));
+                    inlo = (unsigned)sk_writelane_i32((int)(unsigned)im, j, (int)inlo);
+                    inhi = (unsigned)sk_writelane_i32((int)(unsigned)(im >> 32), j, (int)inhi);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (unc != 0ull) ok = false;
+            }
+        }
+
+        if (MODE == MODE_MEDMAD) {
+            // the filtered samples, in order, for the DTW feed
+            double *crow = a.comp + o0;
+            if (n == M) {                               // nothing dropped: a plain copy
+                double *pc = crow + lane;
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    int rem = M - 64 * j;
+                    asm("" : "+s"(rem));
+                    if (lane < rem) pc[64 * j] = x[j];
+                }
+            } else {
+                int base = 0;
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    if (64 * j >= M) continue;
+                    const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)kplo, j);
+                    const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)kphi, j);
+                    const unsigned long long km = ((unsigned long long)khi << 32) | klo;
+                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi(khi, __builtin_amdgcn_mbcnt_lo(klo, 0u));
+                    if ((km >> lane) & 1ull) crow[pos] = x[j];
+                    base += __popcll(km);
+                }
+            }
+        } else {
+            const int nent = (M + 63) >> 6;
+            if (lane < nent) a.mask2[(int64_t)r * a.row16 + lane] = make_uint4(inlo, inhi, kplo, kphi);
+        }
+        if (lane == 0) {
+            a.prep[r] = pr;
+            if (MODE == MODE_SEG) a.len_out[r] = M;
+            if (!ok) a.retry[1 + atomicAdd(&a.retry[0], 1)] = r;
+        }
+    }
+}
+
+typedef void (*f64stat_fn)(const F64StatArgs);
+
+f64stat_fn pick(int mode, int64_t maxlen)
+{
+    const bool seg = mode == MODE_SEG;
+    if (maxlen <= 1024) return seg ? k_f64_stats<16, MODE_SEG, 6> : k_f64_stats<16, MODE_MEDMAD, 6>;
+    if (maxlen <= 2048) return seg ? k_f64_stats<32, MODE_SEG, 4> : k_f64_stats<32, MODE_MEDMAD, 4>;
+    return seg ? k_f64_stats<64, MODE_SEG, 3> : k_f64_stats<64, MODE_MEDMAD, 3>;
+}
+
+} // namespace
+
+// Is (longest read, std_scale) inside the streaming float64 path's range?  (else: k_prep_f64 for every read)
+bool sk_f64_fast_applies(int64_t maxlen, double std_scale)
+{
+    if (getenv("SK_F64_OLD")) return false;                  // A/B switch: the numpy-order kernel for everything
+    if (maxlen > 4096) return false;
+    if (!(std_scale == std_scale) || fabs(std_scale) > 1e6) return false;
+    return true;
+}
+
+int sk_f64_row16(int64_t maxlen)
+{
+    const int64_t e = (maxlen + 63) / 64;
+    return (int)((e + 7) & ~(int64_t)7);                     // whole 128-byte lines per read
+}
+
+// mode: SK_PREP_SEGMENT (masks + len_out) or SK_PREP_MEDMAD (comp).  d_retry: nreads + 16 ints, zeroed here; the
+// caller runs the numpy-order kernel over that list next.
+int sk_launch_f64_stats(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t maxlen,
+                        double lo, double hi, int mode, double std_scale, sk_prep *d_prep, void *d_mask2, int row16,
+                        int32_t *d_len, int32_t *d_retry, double *d_comp)
+{
+    if (nreads <= 0) return SK_OK;
+    F64StatArgs a;
+    a.sig = d_sig; a.off = d_off; a.nreads = nreads; a.lo = lo; a.hi = hi; a.std_scale = std_scale;
+    a.delta_scale = 1.0;
+    if (const char *e = getenv("SK_SEG_DELTA_SCALE")) { const double v = atof(e); if (v > 0) a.delta_scale = v; }
+    a.prep = d_prep; a.mask2 = (uint4 *)d_mask2; a.row16 = row16; a.len_out = d_len; a.retry = d_retry; a.comp = d_comp;
+    f64stat_fn fn = pick(mode == SK_PREP_SEGMENT ? MODE_SEG : MODE_MEDMAD, maxlen);
+    SK_HIP(hipMemsetAsync(d_retry, 0, 16 * sizeof(int32_t), c->stream));
+    int resident = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *)fn, 64 * WPB, 0) != hipSuccess || resident < 1)
+        resident = 2;
+    int rounds = 8;
+    if (const char *e = getenv("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
+    const long long g = (long long)c->num_cu * resident * rounds;
+    const long long need = ((long long)nreads + WPB - 1) / WPB;
+    const int grid = (int)(g > need ? need : g);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * WPB), 0, c->stream, a);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
+}

@@ -743,24 +743,40 @@ __device__ double median_select(int n, Scratch *sc, unsigned *hist256, unsigned 
     return (a + b) / 2.0;
 }
 
-__global__ __launch_bounds__(TPB)
-void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off, int nreads,
-                double lo, double hi, int mode, double std_scale,
-                double *__restrict__ comp, sk_prep *__restrict__ prep,
-                uint64_t *__restrict__ maskT, int64_t mask_rows)
-{
-    __shared__ Scratch sc_;
-    __shared__ unsigned hist256[256];
-    __shared__ unsigned long long mm[2 * NWAVE];
-    __shared__ unsigned long long sel_list[SEL_LIST];
-    Scratch *sc = &sc_;
+// LISTED: the reads are list[0 .. *count) -- the streaming float64 kernel's uncertified reads (sk_f64stat.hip).
+// Segmenter mode then compacts into one scratch row per workgroup and writes the masks as {in band, kept} bytes
+// in RAW sample coordinates into that path's per-read entries; medmad mode writes comp / prep as usual.
+struct ListedF64 {
+    const int32_t *list;
+    const int32_t *count;
+    unsigned char *mask2;
+    int            row16;
+    int64_t        scratch_stride;      // doubles per scratch row (segmenter mode)
+};
 
-    const int r = blockIdx.x;
+struct PrepF64Shared {
+    Scratch sc;
+    unsigned hist256[256];
+    unsigned long long mm[2 * NWAVE];
+    unsigned long long sel_list[SEL_LIST];
+};
+
+template <bool LISTED>
+__device__ void prep_f64_read(PrepF64Shared *sh, int r, const double *__restrict__ sig, const int64_t *__restrict__ off,
+                              double lo, double hi, int mode, double std_scale,
+                              double *__restrict__ comp, sk_prep *__restrict__ prep,
+                              uint64_t *__restrict__ maskT, int64_t mask_rows, const ListedF64 &la)
+{
+    Scratch *sc = &sh->sc;
+    unsigned *hist256 = sh->hist256;
+    unsigned long long *mm = sh->mm;
+    unsigned long long *sel_list = sh->sel_list;
+
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t o0 = off[r];
     const int M = (int)(off[r + 1] - o0);
     const double *row = sig + o0;
-    double *crow = comp + o0;
+    double *crow = (LISTED && mode == SK_PREP_SEGMENT) ? comp + (int64_t)blockIdx.x * la.scratch_stride : comp + o0;
     if (tid < 4) sc->sel[tid] = 0;
     if (tid == 0) sc->tree_m = -1;
 
@@ -867,6 +883,25 @@ void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off,
     const double bot = median - spread;
     pr.center = median; pr.scale = sd; pr.top = top; pr.bot = bot;
     if (tid == 0) prep[r] = pr;
+    if constexpr (LISTED) {                                // raw coordinates: one byte of each mask per 8 samples
+        unsigned char *mb = la.mask2 + (int64_t)r * la.row16 * 16;
+        for (int base = 0; base < M; base += TPB * 8) {
+            const int i0 = base + tid * 8;
+            if (i0 < M) {
+                unsigned in8 = 0, kp8 = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const double a = (i0 + k < M) ? row[i0 + k] : 0.0;
+                    const bool kept = i0 + k < M && a > lo && a < hi;
+                    kp8 |= (kept ? 1u : 0u) << k;
+                    in8 |= ((kept && a < top && a > bot) ? 1u : 0u) << k;
+                }
+                mb[(i0 >> 6) * 16 + ((i0 & 63) >> 3)] = (unsigned char)in8;
+                mb[(i0 >> 6) * 16 + 8 + ((i0 & 63) >> 3)] = (unsigned char)kp8;
+            }
+        }
+        return;
+    }
     for (int base = 0; base < n; base += TPB) {
         const int i = base + tid;
         bool in = false;
@@ -876,6 +911,25 @@ void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off,
         }
         const unsigned long long bits = __ballot(in);
         if (lane == 0) maskT[(int64_t)(i >> 6) * mask_rows + r] = bits;
+    }
+}
+
+template <bool LISTED>
+__global__ __launch_bounds__(TPB)
+void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off, int nreads,
+                double lo, double hi, int mode, double std_scale,
+                double *__restrict__ comp, sk_prep *__restrict__ prep,
+                uint64_t *__restrict__ maskT, int64_t mask_rows, ListedF64 la)
+{
+    __shared__ PrepF64Shared sh;
+    if constexpr (LISTED) {
+        const int cnt = *la.count;
+        for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
+            __syncthreads();                               // the previous read is done with the shared scratch
+            prep_f64_read<true>(&sh, la.list[k], sig, off, lo, hi, mode, std_scale, comp, prep, maskT, mask_rows, la);
+        }
+    } else {
+        prep_f64_read<false>(&sh, blockIdx.x, sig, off, lo, hi, mode, std_scale, comp, prep, maskT, mask_rows, la);
     }
 }
 
@@ -1026,8 +1080,27 @@ int sk_launch_prep_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int
                        double *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_rows)
 {
     if (nreads <= 0) return SK_OK;
-    hipLaunchKernelGGL(k_prep_f64, dim3(nreads), dim3(TPB), 0, c->stream, d_sig, d_off, nreads, lo, hi, mode,
-                       std_scale, d_comp, d_prep, d_mask, mask_rows);
+    ListedF64 la;
+    la.list = nullptr; la.count = nullptr; la.mask2 = nullptr; la.row16 = 0; la.scratch_stride = 0;
+    hipLaunchKernelGGL(k_prep_f64<false>, dim3(nreads), dim3(TPB), 0, c->stream, d_sig, d_off, nreads, lo, hi, mode,
+                       std_scale, d_comp, d_prep, d_mask, mask_rows, la);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
+}
+
+// The same statistics in numpy's order for the reads of a device-side list (the streaming float64 kernel's
+// uncertified reads): segmenter mode rewrites those reads' {in band, kept} entries in place (d_scratch: `grid` rows of
+// scratch_stride doubles), medmad mode their prep records and comp rows.
+int sk_launch_prep_f64_listed(sk_ctx *c, const double *d_sig, const int64_t *d_off, const int32_t *d_list,
+                              const int32_t *d_count, int grid, double lo, double hi, int mode, double std_scale,
+                              double *d_comp_or_scratch, int64_t scratch_stride, sk_prep *d_prep, void *d_mask2, int row16)
+{
+    if (grid <= 0) return SK_OK;
+    ListedF64 la;
+    la.list = d_list; la.count = d_count; la.mask2 = (unsigned char *)d_mask2; la.row16 = row16;
+    la.scratch_stride = scratch_stride;
+    hipLaunchKernelGGL(k_prep_f64<true>, dim3(grid), dim3(TPB), 0, c->stream, d_sig, d_off, 0, lo, hi, mode,
+                       std_scale, d_comp_or_scratch, d_prep, (uint64_t *)nullptr, (int64_t)0, la);
     SK_HIP(hipGetLastError());
     return SK_OK;
 }

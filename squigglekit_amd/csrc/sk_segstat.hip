@@ -616,6 +616,34 @@ void k_seg_walk3(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
     if (live) nsegs[r] = st.nseg;
 }
 
+void launch_walk(hipStream_t ws, const uint4 *mask2, int row16, const int32_t *len, int64_t stride, int nr,
+                 const WalkParams &wp, bool fast, bool by_runs, int32_t *d_segs, int32_t *d_nsegs, int max_segs)
+{
+    const int wgrid = (nr + 63) / 64;
+    if (fast && by_runs)
+        hipLaunchKernelGGL(k_seg_walk3, dim3(wgrid), dim3(64), 0, ws, mask2, row16, len, stride, nr, wp, d_segs, d_nsegs,
+                           max_segs);
+    else if (fast)
+        hipLaunchKernelGGL(k_seg_walk2<true>, dim3(wgrid), dim3(64), 0, ws, mask2, row16, len, stride, nr, wp, d_segs,
+                           d_nsegs, max_segs);
+    else
+        hipLaunchKernelGGL(k_seg_walk2<false>, dim3(wgrid), dim3(64), 0, ws, mask2, row16, len, stride, nr, wp, d_segs,
+                           d_nsegs, max_segs);
+}
+
+WalkParams walk_params(const sk_seg_params *p, bool *fast)
+{
+    WalkParams wp;
+    wp.error = p->error; wp.corrector = p->corrector; wp.window = p->window; wp.seg_dist = p->seg_dist;
+    const double fl = (double)p->window * p->stall_len;            // segmenter.py:448
+    if (!(fl == fl))           wp.first_len = 0x7fffffff;          // NaN: never true
+    else if (fl > 2147483000.) wp.first_len = 0x7fffffff;
+    else if (fl < -2147483000.) wp.first_len = -0x7fffffff;
+    else                       wp.first_len = (int)ceil(fl);
+    *fast = wp.error < wp.corrector && wp.window >= 1 && wp.first_len >= 1 && getenv("SK_WALK_GENERAL") == nullptr;
+    return wp;
+}
+
 typedef void (*segstat_fn)(const SegStatArgs);
 
 segstat_fn pick_stats(int64_t stride, int nbins)
@@ -674,15 +702,8 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
     if (const char *e = getenv("SK_SEG_DELTA_SCALE")) { const double v = atof(e); if (v > 0) a.delta_scale = v; }
     a.row16 = sk_segment_fast_row16(stride);
 
-    WalkParams wp;
-    wp.error = p->error; wp.corrector = p->corrector; wp.window = p->window; wp.seg_dist = p->seg_dist;
-    const double fl = (double)p->window * p->stall_len;            // segmenter.py:448
-    if (!(fl == fl))           wp.first_len = 0x7fffffff;          // NaN: never true
-    else if (fl > 2147483000.) wp.first_len = 0x7fffffff;
-    else if (fl < -2147483000.) wp.first_len = -0x7fffffff;
-    else                       wp.first_len = (int)ceil(fl);
-    const bool fast = wp.error < wp.corrector && wp.window >= 1 && wp.first_len >= 1 &&
-                      getenv("SK_WALK_GENERAL") == nullptr;
+    bool fast;
+    const WalkParams wp = walk_params(p, &fast);
 
     const bool by_runs = getenv("SK_WALK_STEP") == nullptr;       // A/B switch: the per-sample straight-line walk
     // Large batches go in four chunks, the walk of one on a second stream beside the statistics of the next -- which
@@ -746,16 +767,8 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
             SK_HIP(hipEventRecord(c->ev[1], c->stream));
             SK_HIP(hipEventRecord(c->ev[2], c->stream));
         }
-        const int wgrid = (nr + 63) / 64;
-        if (fast && by_runs)
-            hipLaunchKernelGGL(k_seg_walk3, dim3(wgrid), dim3(64), 0, ws, (const uint4 *)a.mask2, a.row16,
-                               a.len, stride, nr, wp, d_segs + (int64_t)r0 * 2 * max_segs, d_nsegs + r0, max_segs);
-        else if (fast)
-            hipLaunchKernelGGL(k_seg_walk2<true>, dim3(wgrid), dim3(64), 0, ws, (const uint4 *)a.mask2, a.row16,
-                               a.len, stride, nr, wp, d_segs + (int64_t)r0 * 2 * max_segs, d_nsegs + r0, max_segs);
-        else
-            hipLaunchKernelGGL(k_seg_walk2<false>, dim3(wgrid), dim3(64), 0, ws, (const uint4 *)a.mask2, a.row16,
-                               a.len, stride, nr, wp, d_segs + (int64_t)r0 * 2 * max_segs, d_nsegs + r0, max_segs);
+        launch_walk(ws, (const uint4 *)a.mask2, a.row16, a.len, stride, nr, wp, fast, by_runs,
+                    d_segs + (int64_t)r0 * 2 * max_segs, d_nsegs + r0, max_segs);
         SK_HIP(hipGetLastError());
     }
     if (nchunks > 1) {
@@ -764,6 +777,22 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
         SK_HIP(hipEventRecord(c->ev_chunk[8], c->stream2));        // the caller's stream continues behind the walks
         SK_HIP(hipStreamWaitEvent(c->stream, c->ev_chunk[8], 0));
     }
+    SK_HIP(hipEventRecord(c->ev[3], c->stream));
+    return SK_OK;
+}
+
+// The walk alone, over {in band, kept} entries somebody else wrote (the float64 statistics kernel, sk_f64stat.hip):
+// read r has d_len[r] samples (clamped to 64 row16), its entries at d_mask2 + r * row16.  Records ev[2] .. ev[3].
+int sk_launch_seg_walk_masks(sk_ctx *c, const void *d_mask2, int row16, const int32_t *d_len, int32_t nreads,
+                             const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs)
+{
+    if (nreads <= 0) return SK_OK;
+    bool fast;
+    const WalkParams wp = walk_params(p, &fast);
+    SK_HIP(hipEventRecord(c->ev[2], c->stream));
+    launch_walk(c->stream, (const uint4 *)d_mask2, row16, d_len, (int64_t)row16 * 64, nreads, wp, fast,
+                getenv("SK_WALK_STEP") == nullptr, d_segs, d_nsegs, max_segs);
+    SK_HIP(hipGetLastError());
     SK_HIP(hipEventRecord(c->ev[3], c->stream));
     return SK_OK;
 }

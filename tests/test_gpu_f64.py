@@ -172,3 +172,73 @@ def test_motifseq_f64_batch_through_the_screening_scheme(gpu, ora, example_model
             assert got["flags"][r] & 2
         else:
             assert (got["dist"][r], got["start"][r], got["end"][r], got["n"][r]) == w, (scale, lanes, r)
+
+
+def _stream_reads(rng):
+    """Reads of at most 4 096 samples (the streaming float64 kernel's range) that stress its median selection and its
+    certificate: ungridded doubles, heavy ties, an outlier that stretches the histogram range, all-equal and
+    two-valued reads, tiny spreads, NaN / inf samples, every length around the 64-sample slots."""
+    reads = []
+    for n in (1, 2, 3, 63, 64, 65, 127, 128, 129, 1000, 2047, 2048, 2049, 3999, 4000, 4095, 4096):
+        reads.append(rng.normal(96.0, 15.0, n))                                       # ungridded
+        reads.append(np.round(rng.normal(96.0, 15.0, n), 2))                          # pA grid
+        reads.append(rng.choice([80.25, 95.5, 95.51, 120.0], n))                      # four distinct values
+        x = np.round(rng.normal(90.0, 6.0, n), 2)
+        x[rng.integers(0, n)] = 899.99                                                # one far outlier inside the limits
+        reads.append(x)
+        reads.append(np.full(n, 77.77))                                               # std == 0
+        reads.append(90.0 + rng.integers(0, 3, n) * 2.0 ** -40)                       # tiny spread
+        y = rng.normal(96.0, 15.0, n)
+        y[rng.integers(0, n, 3)] = [np.nan, np.inf, -np.inf]
+        reads.append(y)
+        reads.append(np.round(np.abs(rng.standard_cauchy(n)) * 40.0, 3))              # heavy tail, many dropped at 900
+    return reads
+
+
+def test_f64_streaming_segmenter_vs_oracle(gpu, ora, monkeypatch):
+    from squigglekit_amd import api
+    from squigglekit_amd._lib import SegParams
+    reads = _stream_reads(np.random.default_rng(77))
+    reads += _pa_reads(64, 4000, 5)
+    for kw in (dict(), dict(lim_low=60, lim_hi=130, error=9, corrector=2, window=40), dict(std_scale=0.1, window=20),
+               dict(lim_low=-1000, lim_hi=1000, std_scale=-0.5)):
+        p = SegParams(**kw)
+        op = ora.SegParams(p.error, p.corrector, p.window, p.seg_dist, p.std_scale, p.stall_len)
+        want = [ora.get_segs(f, op) if f.size else False
+                for f in (ora.scale_outliers(sig, p.lim_low, p.lim_hi) for sig in reads)]
+        for delta in (None, "1e13"):                       # as shipped / every read through the numpy-order redo
+            if delta:
+                monkeypatch.setenv("SK_SEG_DELTA_SCALE", delta)
+            got = api.segment_reads_f64(reads, p)
+            retried = gpu.load().sk_last_f64_retries()
+            monkeypatch.delenv("SK_SEG_DELTA_SCALE", raising=False)
+            assert retried >= 0, "the batch did not take the streaming kernel"
+            if delta:
+                assert retried >= len(reads) // 2
+            bad = [r for r in range(len(reads)) if got[r] != want[r]]
+            assert not bad, (kw, delta, bad[:8], retried)
+
+
+def test_f64_streaming_medmad_vs_oracle(gpu, ora, example_model):
+    from squigglekit_amd import api
+    reads = _stream_reads(np.random.default_rng(78))
+    reads += _pa_reads(300, 3000, 6)                       # enough for the screening scheme
+    got = api.motifseq_reads_f64(reads, example_model, scale="medmad", scale_low=0, scale_hi=900)
+    assert gpu.load().sk_last_f64_retries() >= 0, "the batch did not take the streaming kernel"
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(sig):
+        f = ora.scale_outliers(sig, 0, 900)
+        if f.size == 0:
+            return None
+        y = ora.medmad(f)[0]
+        return (ora.dtw_subsequence(example_model, y) + (f.size,)) if np.all(np.isfinite(y)) else (f.size,)
+    with ThreadPoolExecutor(16) as ex:
+        want = list(ex.map(one, reads))
+    for r, w in enumerate(want):
+        if w is None:
+            assert got["n"][r] == 0 and got["flags"][r] & 1, r
+        elif len(w) == 1:
+            assert got["n"][r] == w[0] and got["flags"][r] & 2, r
+        else:
+            assert (got["dist"][r], got["start"][r], got["end"][r], got["n"][r]) == w, r
