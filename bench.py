@@ -1074,6 +1074,7 @@ def rank_body(a, comm, rank, world, shape):
 
 def main(argv=None):
     a = parse(argv)
+    os.environ["SK_TUNING"] = "1"                             # the A/B legs of the extras flip tuning switches
     os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # RCCL logs to stdout by default: the JSON line stands alone
     from squigglekit_amd import _lib, multigpu
     _lib.load()

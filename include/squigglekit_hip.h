@@ -298,6 +298,12 @@ int sk_comm_allgather_dev(const void *d_send, void *d_recv, size_t bytes);
 int sk_comm_allgather_host(const void *send, void *recv, size_t bytes);
 int sk_comm_destroy(void);
 
+/* ---- tuning switches --------------------------------------------------- */
+/* Every environment switch the library reads, as text: one line per switch, "name<TAB>values the parity test flips it
+ * to<TAB>description".  None changes results; all are ignored unless SK_TUNING=1 is set too.  Returns the bytes needed
+ * (including the terminating NUL); buf may be NULL. */
+int sk_tunables(char *buf, int cap);
+
 /* ---- instrumentation -------------------------------------------------- */
 /* HIP-event durations (ms) of the kernels of the most recent *_dev / batch
  * call on this thread's device: prep (filter+stats), main (DTW or segment walk). */

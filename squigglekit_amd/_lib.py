@@ -150,6 +150,7 @@ ABI = {
     "sk_comm_allgather_dev": (C.c_int, [_vp, _vp, C.c_size_t]),
     "sk_comm_allgather_host": (C.c_int, [_vp, _vp, C.c_size_t]),
     "sk_comm_destroy": (C.c_int, []),
+    "sk_tunables": (C.c_int, [C.c_char_p, C.c_int]),
     "sk_last_kernel_ms": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sk_last_dtw_retries": (C.c_int, []),
     "sk_last_dtw_tier2": (C.c_int, []),
@@ -249,3 +250,35 @@ def ensure_init():
 
 def ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+# Host-side tuning switches (the native ones live in csrc/sk_runtime.hip: SK_TUNABLES): name -> (values the parity
+# test flips it to, description).  Like the native ones they are read only when SK_TUNING=1 is set as well.
+PY_TUNABLES = {
+    "SK_BLOW5_PIN": ("1", "BLOW5 reader: page-locked streaming buffers"),
+    "SK_BLOW5_BLOCK": ("64 5000", "BLOW5 reader: records per block"),
+    "SK_BLOW5_ZAP": ("0", "BLOW5 reader: keep the consumed pages of the file map"),
+    "SK_I16_PIN": ("1", "--i16 reader: page-locked streaming buffers"),
+    "SK_I16_BLOCK_MB": ("1 8", "--i16 reader: block size in MB"),
+}
+
+
+def tune(name, default=None):
+    """Value of a host-side tuning switch, or `default` when it is unset or SK_TUNING=1 is not set."""
+    if os.environ.get("SK_TUNING", "")[:1] != "1" or name not in PY_TUNABLES:
+        return default
+    return os.environ.get(name, default)
+
+
+def tunables():
+    """Every tuning switch: {name: (test values, description)} -- the native table plus PY_TUNABLES."""
+    L = load()
+    n = L.sk_tunables(None, 0)
+    buf = C.create_string_buffer(n)
+    L.sk_tunables(buf, n)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, vals, what = line.split("\t")
+        out[name] = (vals, what)
+    out.update(PY_TUNABLES)
+    return out

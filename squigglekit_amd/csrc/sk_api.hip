@@ -67,7 +67,7 @@ SubBatches sub_batches(int32_t nreads, int64_t stride)
 {
     SubBatches sb;
     int64_t target = (int64_t)256 << 20;                    // bytes of samples per sub-batch
-    if (const char *e = getenv("SK_INGEST_MB")) { const long v = atol(e); if (v > 0) target = (int64_t)v << 20; }
+    if (const char *e = sk_tune("SK_INGEST_MB")) { const long v = atol(e); if (v > 0) target = (int64_t)v << 20; }
     int64_t per = target / (stride * (int64_t)sizeof(int16_t));
     if (per < 4096) per = 4096;
     if (per * 2 > nreads) { sb.per = nreads; sb.n = 1; return sb; }

@@ -85,6 +85,13 @@ struct sk_ctx {
     sk_buf commbuf;                   // staging for the small host-side exchanges
 };
 
+// ---- tuning switches (sk_runtime.hip) ----
+// Every environment switch the library reads is listed in ONE table (SK_TUNABLES in sk_runtime.hip, exported as text by
+// sk_tunables()); none changes results.  They are read only when SK_TUNING=1 is set as well (tests, tools/, bench.py
+// set it): a stray SK_* variable in a user's shell cannot move a production job onto a slow or rarely used path.
+// sk_tune() returns the variable's value, or nullptr when it is unset, tuning is off, or the name is not in the table.
+const char *sk_tune(const char *name);
+
 // ---- runtime (sk_runtime.hip) ----
 sk_ctx *sk_cur(void);                       // bound context or nullptr (error set)
 sk_ctx *sk_ctx_of(int device);              // context slot of a device (ready or not)

@@ -401,7 +401,7 @@ f64stat_fn pick(int mode, int64_t maxlen)
 // Is (longest read, std_scale) inside the streaming float64 path's range?  (else: k_prep_f64 for every read)
 bool sk_f64_fast_applies(int64_t maxlen, double std_scale)
 {
-    if (getenv("SK_F64_OLD")) return false;                  // A/B switch: the numpy-order kernel for everything
+    if (sk_tune("SK_F64_OLD")) return false;                  // A/B switch: the numpy-order kernel for everything
     if (maxlen > 4096) return false;
     if (!(std_scale == std_scale) || fabs(std_scale) > 1e6) return false;
     return true;
@@ -423,7 +423,7 @@ int sk_launch_f64_stats(sk_ctx *c, const double *d_sig, const int64_t *d_off, in
     F64StatArgs a;
     a.sig = d_sig; a.off = d_off; a.nreads = nreads; a.lo = lo; a.hi = hi; a.std_scale = std_scale;
     a.delta_scale = 1.0;
-    if (const char *e = getenv("SK_SEG_DELTA_SCALE")) { const double v = atof(e); if (v > 0) a.delta_scale = v; }
+    if (const char *e = sk_tune("SK_SEG_DELTA_SCALE")) { const double v = atof(e); if (v > 0) a.delta_scale = v; }
     a.prep = d_prep; a.mask2 = (uint4 *)d_mask2; a.row16 = row16; a.len_out = d_len; a.retry = d_retry; a.comp = d_comp;
     f64stat_fn fn = pick(mode == SK_PREP_SEGMENT ? MODE_SEG : MODE_MEDMAD, maxlen);
     SK_HIP(hipMemsetAsync(d_retry, 0, 16 * sizeof(int32_t), c->stream));
@@ -431,7 +431,7 @@ int sk_launch_f64_stats(sk_ctx *c, const double *d_sig, const int64_t *d_off, in
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *)fn, 64 * WPB, 0) != hipSuccess || resident < 1)
         resident = 2;
     int rounds = 8;
-    if (const char *e = getenv("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
+    if (const char *e = sk_tune("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
     const long long g = (long long)c->num_cu * resident * rounds;
     const long long need = ((long long)nreads + WPB - 1) / WPB;
     const int grid = (int)(g > need ? need : g);

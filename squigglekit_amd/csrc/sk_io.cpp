@@ -243,6 +243,14 @@ void sk_fmt_free(void *p) { free(p); }
 // uint16 idlen | id | uint32 read_group | f64 digitisation | f64 offset | f64 range | f64 sampling_rate |
 // uint64 n | int16[n] | aux fields; the file ends with "5WOLB".
 
+// What may follow the last record: nothing, or the end marker (and nothing else worth a record: fewer than 8 bytes).
+static bool blow5_clean_end(const unsigned char *buf, int64_t len, int64_t pos)
+{
+    const int64_t left = len - pos;
+    if (left == 0) return true;
+    return left >= 5 && memcmp(buf + pos, "5WOLB", 5) == 0;
+}
+
 int64_t sk_blow5_index(const void *buf_, int64_t len, int64_t first, int64_t *rec_off, int64_t *rec_size, int64_t cap)
 {
     const unsigned char *buf = (const unsigned char *)buf_;
@@ -258,6 +266,7 @@ int64_t sk_blow5_index(const void *buf_, int64_t len, int64_t first, int64_t *re
         n++;
         pos += (int64_t)size;
     }
+    if (!blow5_clean_end(buf, len, pos)) return SK_ERR_INVALID;          // cut inside a size field / trailing junk
     return n;
 }
 
@@ -280,16 +289,17 @@ int64_t sk_blow5_index_some(const void *buf_, int64_t len, int64_t pos, int64_t 
         n++;
         pos += (int64_t)size;
     }
+    if (n < max_rec && !blow5_clean_end(buf, len, pos)) return SK_ERR_INVALID;   // (the walk stopped at the file's end)
     *next_pos = pos;
     return n;
 }
 
-int sk_blow5_rows_i16(const void *buf_, const int64_t *rec_off, const int64_t *rec_size, int64_t nrec, int32_t comp,
-                      int64_t stride, int16_t *rows, int32_t *nsamp, char *ids, int32_t id_width, double *calib,
+int sk_blow5_rows_i16(const void *buf_, int64_t len, const int64_t *rec_off, const int64_t *rec_size, int64_t nrec,
+                      int32_t comp, int64_t stride, int16_t *rows, int32_t *nsamp, char *ids, int32_t id_width, double *calib,
                       int32_t *flags, int32_t nthreads)
 {
     const unsigned char *buf = (const unsigned char *)buf_;
-    if (!buf || !rec_off || !rec_size || nrec < 0 || stride <= 0 || !rows || !nsamp || !flags || (comp != 0 && comp != 1))
+    if (!buf || len < 0 || !rec_off || !rec_size || nrec < 0 || stride <= 0 || !rows || !nsamp || !flags || (comp != 0 && comp != 1))
         return SK_ERR_INVALID;
     const int T = clamp_threads(nthreads, nrec, 256);
     auto work = [&](int t) {
@@ -297,12 +307,17 @@ int sk_blow5_rows_i16(const void *buf_, const int64_t *rec_off, const int64_t *r
         const int64_t lo = nrec * t / T, hi = nrec * (t + 1) / T;
         for (int64_t i = lo; i < hi; i++) {
             flags[i] = 0; nsamp[i] = 0;
+            if (ids && id_width > 0) memset(ids + (size_t)i * (size_t)id_width, 0, (size_t)id_width);
+            // offsets / sizes are the caller's (normally sk_blow5_index's): anything outside the buffer is unreadable
+            if (rec_off[i] < 0 || rec_size[i] < 0 || rec_off[i] > len || rec_size[i] > len - rec_off[i]) { flags[i] = 2; continue; }
             const unsigned char *p = buf + rec_off[i];
             size_t sz = (size_t)rec_size[i];
             if (comp == 1) {
+                // inflate into a buffer that grows from 4x the stored size; a record that still does not fit in 256x
+                // (or 1 GB) is not a squiggle record
                 size_t cap = sz * 4 + 4096;
                 int zr = Z_BUF_ERROR;
-                for (int tries = 0; tries < 8 && zr == Z_BUF_ERROR; tries++, cap *= 2) {
+                for (int tries = 0; tries < 7 && zr == Z_BUF_ERROR && cap <= ((size_t)1 << 30); tries++, cap *= 2) {
                     tmp.resize(cap);
                     uLongf dl = (uLongf)cap;
                     zr = uncompress(tmp.data(), &dl, p, (uLong)sz);

@@ -1064,8 +1064,8 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
     // several grid "rounds" so that the resident count (fewer than per_cu when SGPRs bind) does
     // not have to divide the grid; SK_PREP_ROUNDS is a tuning override
     int rounds = 6;
-    if (const char *e = getenv("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
-    if (const char *e = getenv("SK_PREP_PERCU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }
+    if (const char *e = sk_tune("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
+    if (const char *e = sk_tune("SK_PREP_PERCU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }
     long long g = (long long)c->num_cu * per_cu * rounds;
     int grid = g > nreads ? nreads : (int)g;
     if (listed && grid > c->num_cu) grid = c->num_cu;      // (the list is almost always empty)

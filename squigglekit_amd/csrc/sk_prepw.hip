@@ -48,7 +48,7 @@ typedef void (*prepw_fn)(const int16_t *, int64_t, const int32_t *, int, int, in
 int sk_launch_prepw_medmad(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len,
                            int32_t nreads, int32_t lo, int32_t hi, int16_t *d_comp, sk_prep *d_prep)
 {
-    if (getenv("SK_PREP_BLOCK")) return 1;                  // tuning / A-B switch: workgroup-per-read kernel
+    if (sk_tune("SK_PREP_BLOCK")) return 1;                  // tuning / A-B switch: workgroup-per-read kernel
     const int64_t nbins = (int64_t)hi - lo - 1;
     if (nbins < 1 || nbins > 2048) return 1;
     const int per_lane = (int)((nbins + 63) / 64);
@@ -61,7 +61,7 @@ int sk_launch_prepw_medmad(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
     const int vec_ok = ((((uintptr_t)d_sig & 15) == 0 && (stride % 8) == 0) ? 1 : 0) |
                        ((((uintptr_t)d_comp & 15) == 0 && (stride % 8) == 0) ? 2 : 0);
     int rounds = 4;
-    if (const char *e = getenv("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
+    if (const char *e = sk_tune("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
     const long long g = (long long)c->num_cu * per_cu * rounds;
     const long long need = ((long long)nreads + WPB - 1) / WPB;
     const int grid = (int)(g > need ? need : g);

@@ -4,6 +4,8 @@
 // or, as bench.py also does, one process per GPU.  Several slots may serve the same device
 // (sk_init_slot): that is how the N > 1 code paths are exercised on a one-GPU box.
 #include "sk_common.h"
+#include <string>
+#include <string.h>
 #include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
@@ -54,6 +56,47 @@ int sk_reserve(sk_ctx *c, sk_buf *b, size_t bytes)
     return SK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The tuning surface: every environment switch of the library, the values the parity test flips it to
+// (tests/test_gpu_tuning.py runs each one alone and compares the records byte for byte), what it does.
+// ---------------------------------------------------------------------------------------------------------------
+struct sk_tunable { const char *name, *test_values, *what; };
+static const sk_tunable SK_TUNABLES[] = {
+    {"SK_DTW_SCHEME",         "full exact2", "DTW scheme: full = one exact pass, exact2 = two exact passes (default: fixed-point screening + certified window)"},
+    {"SK_DTW_QL",             "8 16 64",     "lanes per read of the screening scheme (default: by motif length and batch size)"},
+    {"SK_DTW_NOFUSE",         "1",           "filter + medmad as their own kernel instead of the screening pass's prologue"},
+    {"SK_DTW_FORCE_RETRY_PM", "100 1000",    "per-mille of reads sent through the exact retry whatever the window pass certified (sensitivity runs)"},
+    {"SK_DTW_SPAN",           "150 300",     "look-back of the window pass in columns (one tier)"},
+    {"SK_DTW_SPAN2",          "0 500",       "look-back of the window pass's second tier (0: none)"},
+    {"SK_DTW_CK",             "64 256",      "steps between checkpoints of the screening pass (multiple of 64)"},
+    {"SK_DTW_NOSORT",         "1",           "window passes take the reads in file order"},
+    {"SK_DTW_SORT_MIN",       "1",           "window passes sort chunks of at least this many reads"},
+    {"SK_DTW_NO_EARLY",       "1",           "no early exact retry beside the window passes"},
+    {"SK_DTW_SCRATCH_MB",     "8 64",        "checkpoint scratch budget in MB (small values force many chunks)"},
+    {"SK_DTW_NO_SMALL",       "1",           "small batches keep the batch lane layout"},
+    {"SK_DTW_SMALL_MAX",      "0 100000",    "largest batch that spreads a read over 64 lanes"},
+    {"SK_PREP_BLOCK",         "1",           "medmad statistics by the workgroup-per-read kernel"},
+    {"SK_PREP_ROUNDS",        "1 3",         "grid rounds of the persistent statistics kernels"},
+    {"SK_PREP_PERCU",         "1 2",         "workgroups per CU of the persistent statistics kernels"},
+    {"SK_SEG_OLD",            "1",           "segmenter: numpy-order statistics kernels for every read"},
+    {"SK_SEG_DELTA_SCALE",    "1e13",        "segmenter: certification margin multiplier (large: every read takes the numpy-order redo)"},
+    {"SK_SEG_OCC",            "7 8",         "segmenter statistics kernel: waves per SIMD the registers are sized for"},
+    {"SK_SEG_CHUNKS",         "2 8",         "segmenter: chunks of a large batch (walk of one beside the statistics of the next)"},
+    {"SK_WALK_STEP",          "1",           "segmenter walk: per-sample straight-line step instead of run hopping"},
+    {"SK_WALK_GENERAL",       "1",           "segmenter walk: general step (corrector test live)"},
+    {"SK_INGEST_MB",          "1 4",         "sub-batch size of the host entry points in MB"},
+    {"SK_F64_OLD",            "1",           "float64 reads: numpy-order statistics kernel for every read"},
+};
+
+const char *sk_tune(const char *name)
+{
+    const char *on = getenv("SK_TUNING");
+    if (!on || on[0] != '1') return nullptr;
+    for (const sk_tunable &t : SK_TUNABLES)
+        if (strcmp(t.name, name) == 0) return getenv(name);
+    return nullptr;                                     // not in the table: not a switch
+}
+
 static thread_local int g_dtw_shrink = 0;       // halvings of the scratch budget after a failed allocation
 void sk_dtw_scratch_shrink(int reset) { g_dtw_shrink = reset ? 0 : (g_dtw_shrink < 12 ? g_dtw_shrink + 1 : 12); }
 
@@ -64,7 +107,7 @@ int64_t sk_dtw_chunk_reads(size_t per_read, int64_t nreads)
     // 72.9 ms with one chunk).  A caller short of memory gets smaller chunks (sk_dtw_scratch_shrink).
     size_t budget = (size_t)64 << 30;
     int64_t floor_reads = 1024;
-    if (const char *e = getenv("SK_DTW_SCRATCH_MB")) {
+    if (const char *e = sk_tune("SK_DTW_SCRATCH_MB")) {
         const long v = atol(e);
         if (v > 0) { budget = (size_t)v << 20; floor_reads = 64; }
     }
@@ -76,6 +119,15 @@ int64_t sk_dtw_chunk_reads(size_t per_read, int64_t nreads)
 }
 
 extern "C" {
+
+// The tuning table as text: one line per switch, "name<TAB>test values<TAB>description".  Returns the bytes needed.
+int sk_tunables(char *buf, int cap)
+{
+    std::string out;
+    for (const sk_tunable &t : SK_TUNABLES) { out += t.name; out += '\t'; out += t.test_values; out += '\t'; out += t.what; out += '\n'; }
+    if (buf && cap > 0) { const size_t n = out.size() < (size_t)cap - 1 ? out.size() : (size_t)cap - 1; memcpy(buf, out.data(), n); buf[n] = 0; }
+    return (int)out.size() + 1;
+}
 
 const char *sk_version(void) { return "squigglekit-hip 0.1.0 (gfx950)"; }
 const char *sk_last_error(void) { return g_err; }

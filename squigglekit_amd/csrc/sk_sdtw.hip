@@ -422,7 +422,7 @@ static int launch_chained(sk_ctx *c, const sk_sdtw_args *a)
 bool sk_sdtw_fuse_ok(int32_t lo, int32_t hi)
 {
     const int64_t nbins = (int64_t)hi - lo - 1;
-    return nbins > 1024 && nbins <= 1280 && !getenv("SK_PREP_BLOCK") && !getenv("SK_DTW_NOFUSE");
+    return nbins > 1024 && nbins <= 1280 && !sk_tune("SK_PREP_BLOCK") && !sk_tune("SK_DTW_NOFUSE");
 }
 
 // will this call take the screening scheme (sk_sdtwq.hip)?  (the look-back / checkpoint numbers as in sk_launch_sdtw)
@@ -431,7 +431,7 @@ static bool screens(const sk_sdtw_args *a, int span, int ck)
     const int N = a->nmotif;
     if (N > 64 * 16 || a->last_row || a->force_single || a->nreads < 256) return false;
     if (a->max_len < 4 * (int64_t)(span + ck)) return false;
-    if (const char *e = getenv("SK_DTW_SCHEME")) if (strcmp(e, "full") == 0 || strcmp(e, "exact2") == 0) return false;
+    if (const char *e = sk_tune("SK_DTW_SCHEME")) if (strcmp(e, "full") == 0 || strcmp(e, "exact2") == 0) return false;
     for (int i = 0; i < N; i++) if (!(fabs(a->motif[i]) < QLIM)) return false;
     return true;
 }
@@ -445,8 +445,8 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
     if (a->nreads <= 0) return SK_OK;
     if (a->fuse) {
         int ck0 = 128, span0 = N + N / 8 + 8;
-        if (const char *e = getenv("SK_DTW_CK")) { int v = atoi(e); if (v >= 64 && v % 64 == 0) ck0 = v; }
-        if (const char *e = getenv("SK_DTW_SPAN")) { int v = atoi(e); if (v > 0) span0 = v; }
+        if (const char *e = sk_tune("SK_DTW_CK")) { int v = atoi(e); if (v >= 64 && v % 64 == 0) ck0 = v; }
+        if (const char *e = sk_tune("SK_DTW_SPAN")) { int v = atoi(e); if (v > 0) span0 = v; }
         if (!screens(a, span0, ck0) || !sk_sdtw_fuse_ok(a->fuse->lo, a->fuse->hi)) {
             // no screening pass to carry the prologue: filter + statistics as their own kernel, now
             SK_HIP(hipEventRecord(c->ev[0], c->stream));
@@ -468,8 +468,8 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
     // Measured at 163 points x 4 000 samples: 64 reads 1.12 -> 0.54 ms, 1 024 reads 0.52 -> 0.29 ms,
     // break-even near 4 096 reads.
     int small_max = 2048;
-    if (const char *e = getenv("SK_DTW_SMALL_MAX")) { int v = atoi(e); if (v >= 0) small_max = v; }
-    if (L == 16 && N >= 32 && a->nreads <= small_max && !getenv("SK_DTW_NO_SMALL")) { L = 64; R = (N + 63) / 64; }
+    if (const char *e = sk_tune("SK_DTW_SMALL_MAX")) { int v = atoi(e); if (v >= 0) small_max = v; }
+    if (L == 16 && N >= 32 && a->nreads <= small_max && !sk_tune("SK_DTW_NO_SMALL")) { L = 64; R = (N + 63) / 64; }
     const int P = L * R - N;                 // short lanes (own R-1 rows), always < L
 
     // The laid-out motif stays resident between calls; re-upload only when it changes.
@@ -515,11 +515,11 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
     // 17.4 ms at N columns).  The exact two-pass scheme keeps one tier of N + N/8 + 8.
     int ck = 128;
     int span = N + N / 8 + 8, span_q = N + 8, span2 = 2 * N + N / 4 + 16;
-    if (const char *e = getenv("SK_DTW_CK")) { int v = atoi(e); if (v >= 64 && v % 64 == 0) ck = v; }
-    if (const char *e = getenv("SK_DTW_SPAN")) { int v = atoi(e); if (v > 0) { span = span_q = v; span2 = 0; } }
-    if (const char *e = getenv("SK_DTW_SPAN2")) { int v = atoi(e); if (v >= 0) span2 = v; }
+    if (const char *e = sk_tune("SK_DTW_CK")) { int v = atoi(e); if (v >= 64 && v % 64 == 0) ck = v; }
+    if (const char *e = sk_tune("SK_DTW_SPAN")) { int v = atoi(e); if (v > 0) { span = span_q = v; span2 = 0; } }
+    if (const char *e = sk_tune("SK_DTW_SPAN2")) { int v = atoi(e); if (v >= 0) span2 = v; }
     const int64_t maxlen = a->max_len;
-    const char *scheme = getenv("SK_DTW_SCHEME");          // A/B switch: "full" = the exact single pass
+    const char *scheme = sk_tune("SK_DTW_SCHEME");          // A/B switch: "full" = the exact single pass
     const bool two_pass = !a->last_row && !a->force_single && maxlen >= 4 * (int64_t)(span + ck) &&
                           a->nreads >= 256 && !(scheme && strcmp(scheme, "full") == 0);
     SK_HIP(hipEventRecord(c->ev[2], c->stream));
@@ -546,7 +546,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
     // two exact FP64 passes below (A/B runs).
     bool qok = true;
     for (int i = 0; i < N; i++) qok = qok && (fabs(a->motif[i]) < QLIM);
-    if (const char *e = getenv("SK_DTW_SCHEME")) qok = qok && strcmp(e, "exact2") != 0;
+    if (const char *e = sk_tune("SK_DTW_SCHEME")) qok = qok && strcmp(e, "exact2") != 0;
     // Reads the windowed pass cannot certify are appended to a device-side list and redone by the exact single
     // pass.  The host never learns the count (no sync inside the call): the retry launches are sized for the
     // worst case and return at once where the list ends.  A short list is latency-bound, so its first 8 192
@@ -602,7 +602,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
         // The reads pass Q itself finds unscreenable (on the C4 batch: all of the ~190 that retry) get their exact
         // pass on a third stream as soon as pass Q is done -- one sweep's latency (0.5 ms) that then runs beside the
         // window passes instead of behind them; what the window passes give up on follows as before.
-        const bool early = getenv("SK_DTW_NO_EARLY") == nullptr;
+        const bool early = sk_tune("SK_DTW_NO_EARLY") == nullptr;
         if (early && !c->stream3) {
             SK_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
             for (int i = 0; i < 2; i++) SK_HIP(hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming));

@@ -785,7 +785,7 @@ void *sk_sdtwq_pick_feed2(int which, int L, int R);
 static void screen_layout(int N, int64_t nreads, int *L, int *R)
 {
     int l = (N <= 8 * 32 && nreads >= 49152) ? 8 : (N <= 16 * 32) ? 16 : 64;
-    if (const char *e = getenv("SK_DTW_QL")) {
+    if (const char *e = sk_tune("SK_DTW_QL")) {
         const int v = atoi(e);
         if ((v == 8 && N <= 8 * 32) || (v == 16 && N <= 16 * 32) || v == 64) l = v;
     }
@@ -943,8 +943,8 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
     if ((rc = sk_reserve(c, &c->wrecq, (size_t)chunk * sizeof(wrec)))) return rc;
     // the window passes take large chunks in sorted order (SK_DTW_NOSORT=1: file order; small ones: not worth 3 launches)
     int sort_min = 32768;
-    if (const char *e = getenv("SK_DTW_SORT_MIN")) { const int v = atoi(e); if (v > 0) sort_min = v; }   // (tests: small batches too)
-    const bool sorted = chunk >= sort_min && getenv("SK_DTW_NOSORT") == nullptr;
+    if (const char *e = sk_tune("SK_DTW_SORT_MIN")) { const int v = atoi(e); if (v > 0) sort_min = v; }   // (tests: small batches too)
+    const bool sorted = chunk >= sort_min && sk_tune("SK_DTW_NOSORT") == nullptr;
     if (sorted && (rc = sk_reserve(c, &c->order, ((size_t)chunk + ORDER_BINS) * sizeof(int32_t)))) return rc;
     const bool tiers = span2 > span;
     if (tiers && (rc = sk_reserve(c, &c->wsoft, ((size_t)chunk + 1) * sizeof(int32_t)))) return rc;
@@ -966,7 +966,7 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
     k.early_cnt = d_early_cnt; k.early = d_early;
     k.qerr = (unsigned)(N + maxlen + 2);
     k.wmax = 4 * ck;
-    if (const char *e = getenv("SK_DTW_FORCE_RETRY_PM")) {       // sensitivity runs: per-mille of reads sent to the retry
+    if (const char *e = sk_tune("SK_DTW_FORCE_RETRY_PM")) {       // sensitivity runs: per-mille of reads sent to the retry
         const int pm = atoi(e);
         if (pm > 0) k.force_retry = pm >= 1000 ? 1024 : (pm * 1024 + 999) / 1000;
     }

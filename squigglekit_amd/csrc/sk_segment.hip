@@ -334,7 +334,7 @@ int sk_launch_segment_walk(sk_ctx *c, const uint64_t *d_mask, int64_t mask_rows,
     SK_HIP(hipEventRecord(c->ev[2], c->stream));
     // the straight-line variant needs a dead corrector test and positive report thresholds
     const bool fast = wp.error < wp.corrector && wp.window >= 1 && wp.first_len >= 1 &&
-                      getenv("SK_WALK_GENERAL") == nullptr;
+                      sk_tune("SK_WALK_GENERAL") == nullptr;
     if (fast)
         hipLaunchKernelGGL(k_segment_walk<true>, dim3(grid), dim3(64), 0, c->stream, d_mask, mask_rows, d_prep,
                            nreads, wp, d_segs, d_nsegs, max_segs);

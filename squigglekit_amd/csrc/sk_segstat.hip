@@ -640,7 +640,7 @@ WalkParams walk_params(const sk_seg_params *p, bool *fast)
     else if (fl > 2147483000.) wp.first_len = 0x7fffffff;
     else if (fl < -2147483000.) wp.first_len = -0x7fffffff;
     else                       wp.first_len = (int)ceil(fl);
-    *fast = wp.error < wp.corrector && wp.window >= 1 && wp.first_len >= 1 && getenv("SK_WALK_GENERAL") == nullptr;
+    *fast = wp.error < wp.corrector && wp.window >= 1 && wp.first_len >= 1 && sk_tune("SK_WALK_GENERAL") == nullptr;
     return wp;
 }
 
@@ -654,7 +654,7 @@ segstat_fn pick_stats(int64_t stride, int nbins)
     if (NT <= 4) return small ? k_seg_stats<4, 4, 8, false> : k_seg_stats<4, 8, 8, false>;
     if (NT > 8) return small ? k_seg_stats<8, 4, 6, true> : k_seg_stats<8, 8, 8, true>;
     if (small) {
-        if (const char *e = getenv("SK_SEG_OCC")) {         // tuning: registers per lane vs reads in flight
+        if (const char *e = sk_tune("SK_SEG_OCC")) {         // tuning: registers per lane vs reads in flight
             const int v = atoi(e);
             if (v == 8) return k_seg_stats<8, 4, 8, false>;
             if (v == 7) return k_seg_stats<8, 4, 7, false>;
@@ -678,7 +678,7 @@ int sk_segment_fast_row16(int64_t stride)
 // Is (stride, limits, std_scale) inside the streaming path's range?  (else: k_prep_i16 + k_segment_walk)
 bool sk_segment_fast_applies(const void *d_sig, int64_t stride, int32_t lo, int32_t hi, double std_scale)
 {
-    if (getenv("SK_SEG_OLD")) return false;                 // A/B switch: the numpy-order kernels for everything
+    if (sk_tune("SK_SEG_OLD")) return false;                 // A/B switch: the numpy-order kernels for everything
     const int64_t nbins = (int64_t)hi - lo - 1;
     if (nbins < 1 || nbins > MAXBINS) return false;
     if (stride > MAXLONG || (stride % 8) != 0 || ((uintptr_t)d_sig & 15) != 0) return false;
@@ -699,28 +699,28 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
     SegStatArgs a;
     a.stride = stride; a.lo = lo; a.hi = hi;
     a.std_scale = p->std_scale; a.delta_scale = 1.0;
-    if (const char *e = getenv("SK_SEG_DELTA_SCALE")) { const double v = atof(e); if (v > 0) a.delta_scale = v; }
+    if (const char *e = sk_tune("SK_SEG_DELTA_SCALE")) { const double v = atof(e); if (v > 0) a.delta_scale = v; }
     a.row16 = sk_segment_fast_row16(stride);
 
     bool fast;
     const WalkParams wp = walk_params(p, &fast);
 
-    const bool by_runs = getenv("SK_WALK_STEP") == nullptr;       // A/B switch: the per-sample straight-line walk
+    const bool by_runs = sk_tune("SK_WALK_STEP") == nullptr;       // A/B switch: the per-sample straight-line walk
     // Large batches go in four chunks, the walk of one on a second stream beside the statistics of the next -- which
     // only pays when the persistent statistics grid leaves the walk's waves room on the SIMDs: at its full six
     // workgroups per CU (78 VGPRs x 24 waves) nothing else fits and the overlap gained nothing (round 2: 3.35 / 3.33 /
     // 3.38 / 3.78 ms for 1 / 2 / 4 / 8 chunks); with four workgroups per CU the statistics kernel is as fast (it is
     // co-limited by HBM) and the step drops from 2.89 to 2.70 ms per 1 M reads (round 3, same box).
     int nchunks = nreads >= 262144 ? 4 : 1;
-    if (const char *e = getenv("SK_SEG_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 8) nchunks = v; }
+    if (const char *e = sk_tune("SK_SEG_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 8) nchunks = v; }
     if (nreads < 65536) nchunks = 1;
     if (nchunks > 1 && !c->stream2) {
         SK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         for (int i = 0; i < 9; i++) SK_HIP(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
     }
     int per_cu = nchunks > 1 ? 4 : 8, rounds = 8;
-    if (const char *e = getenv("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
-    if (const char *e = getenv("SK_PREP_PERCU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }
+    if (const char *e = sk_tune("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
+    if (const char *e = sk_tune("SK_PREP_PERCU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }
 
     SK_HIP(hipMemsetAsync(d_retry, 0, ((size_t)nreads + 16) * sizeof(int32_t), c->stream));
     SK_HIP(hipEventRecord(c->ev[0], c->stream));
@@ -791,7 +791,7 @@ int sk_launch_seg_walk_masks(sk_ctx *c, const void *d_mask2, int row16, const in
     const WalkParams wp = walk_params(p, &fast);
     SK_HIP(hipEventRecord(c->ev[2], c->stream));
     launch_walk(c->stream, (const uint4 *)d_mask2, row16, d_len, (int64_t)row16 * 64, nreads, wp, fast,
-                getenv("SK_WALK_STEP") == nullptr, d_segs, d_nsegs, max_segs);
+                sk_tune("SK_WALK_STEP") == nullptr, d_segs, d_nsegs, max_segs);
     SK_HIP(hipGetLastError());
     SK_HIP(hipEventRecord(c->ev[3], c->stream));
     return SK_OK;

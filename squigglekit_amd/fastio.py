@@ -146,8 +146,8 @@ def iter_blow5_blocks_i16(path, block_reads=16384, id_width=64, nthreads=0, keep
     and ~0.1 s more when the process exits -- 1 M reads x 4 000 samples: 0.72-0.75 s (segmenter.py) / 0.96-1.07 s
     (MotifSeq.py) unpinned against 0.98-1.03 / 1.16-1.19 s pinned, process start to exit, same box."""
     L = _lib.load()
-    if os.environ.get("SK_BLOW5_BLOCK"):
-        block_reads = max(1, int(os.environ["SK_BLOW5_BLOCK"]))
+    if _lib.tune("SK_BLOW5_BLOCK"):
+        block_reads = max(1, int(_lib.tune("SK_BLOW5_BLOCK")))
     mm, comp, first = blow5_open(path)
     base = _addr(mm)
     flen = len(mm)
@@ -161,7 +161,7 @@ def iter_blow5_blocks_i16(path, block_reads=16384, id_width=64, nthreads=0, keep
         b = pool.get(name)
         # (page-locked rows on request, once a GPU is bound: the first chunks of a tool that is still starting the
         # HIP runtime are decoded into ordinary memory meanwhile)
-        want_pinned = pinned and os.environ.get("SK_BLOW5_PIN", "0") == "1" and _lib.is_ready()
+        want_pinned = pinned and _lib.tune("SK_BLOW5_PIN", "0") == "1" and _lib.is_ready()
         if b is None or b.nbytes < need or (want_pinned and not pool.get(name + ":pinned")):
             cap = max(need + need // 8, 1)
             b = None
@@ -221,7 +221,7 @@ def iter_blow5_blocks_i16(path, block_reads=16384, id_width=64, nthreads=0, keep
     def forget(a, b):
         a = (a + page - 1) // page * page
         b = b // page * page
-        if libc is not None and b > a and os.environ.get("SK_BLOW5_ZAP", "1") != "0":
+        if libc is not None and b > a and _lib.tune("SK_BLOW5_ZAP", "1") != "0":
             libc.madvise(base + a, b - a, dontneed)
 
     with ThreadPoolExecutor(1) as ex, ThreadPoolExecutor(1) as zapper:
@@ -254,12 +254,12 @@ def iter_npy_blocks_i16(path, block_bytes=128 << 20, nthreads=8, keep=None):
     if len(shape) != 2 or dtype != np.int16 or fortran:
         raise ValueError("%s: need a C-ordered 2-D int16 array, got %s %s" % (path, dtype, shape))
     R, M = shape
-    if os.environ.get("SK_I16_BLOCK_MB"):
-        block_bytes = max(1, int(os.environ["SK_I16_BLOCK_MB"])) << 20
+    if _lib.tune("SK_I16_BLOCK_MB"):
+        block_bytes = max(1, int(_lib.tune("SK_I16_BLOCK_MB"))) << 20
     per = max(1, block_bytes // max(1, M * 2))
     fd = os.open(path, os.O_RDONLY)
     def alloc():
-        if os.environ.get("SK_I16_PIN", "0") == "1":
+        if _lib.tune("SK_I16_PIN", "0") == "1":
             try:
                 return api.pinned_empty((min(per, max(R, 1)), M), np.int16)
             except Exception:                                        # noqa: BLE001 -- no device yet / no pinned memory

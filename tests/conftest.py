@@ -12,6 +12,7 @@ import sys
 import numpy as np
 import pytest
 
+os.environ["SK_TUNING"] = "1"        # the library reads its tuning switches only with this set (tests flip them)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 if ROOT not in sys.path:

@@ -1,4 +1,5 @@
 # usage (on a GPU box, repo root): bash tools/ab_same_box.sh <tag> [bench args]  -- alternates a baseline build of the library (copy it to squigglekit_amd/libsk_alt_base.so first; picked up through SK_LIB_PATH) and the current one, twice each: boxes differ by a few per cent, so only runs on one box compare
+export SK_TUNING=1        # the library reads its tuning switches only with this set
 TAG=$1; shift
 R=$(pwd); OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 for rep in 1 2; do

@@ -43,6 +43,7 @@ def main():
         # the lanes-per-read layout of the screening scheme (8 is what large batches get by themselves: these batches
         # are small, so it is asked for), the fused / separate filter + statistics, the early / late exact retry
         import os
+os.environ["SK_TUNING"] = "1"      # this tool flips tuning switches
         ql = [None, "8", "16", "64"][int(rng.integers(4))]
         for key, val in (("SK_DTW_QL", ql), ("SK_DTW_NOFUSE", "1" if rng.random() < 0.3 else None),
                          ("SK_DTW_NO_EARLY", "1" if rng.random() < 0.3 else None),

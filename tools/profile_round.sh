@@ -5,6 +5,7 @@
 # separate --pmc passes (FETCH_SIZE / WRITE_SIZE) and two SQ passes (VALU instruction counts / issue and wait
 # cycles) -- counters always with --kernel-trace only, never with other trace domains -- the VALU issue-cost
 # microbenchmark the DTW roof rests on, the command-line tools end to end, and the multi-rank dry run.
+export SK_TUNING=1        # the library reads its tuning switches only with this set
 set -u
 TAG=${1:-r03}
 R=$(pwd)

@@ -1,5 +1,6 @@
 # One MotifSeq step dispatch by dispatch (rocprofv3 --kernel-trace): which kernels run beside which, where the tail goes.
 # usage (GPU box, repo root): bash tools/step_timeline.sh
+export SK_TUNING=1        # the library reads its tuning switches only with this set
 R=$(pwd); OUT=$R/gpurun_out/r3v; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-extras > $OUT/kt.log 2>&1
 F=$(find $OUT/kt -name "*kernel_trace.csv" | head -1)
