@@ -222,7 +222,9 @@ int sk_normalise_f64(const double *sig, int32_t len, int32_t scale_mode,
  * SquigglePull.py:243-253).  Three calls: count lines, count data tokens per line (caller turns
  * them into offsets), parse into one flat float64 array.  Conversion is exactly float()'s for
  * plain decimal tokens; lines with any other token get SK_TSV_SLOW and should be parsed by the
- * caller the slow way. */
+ * caller the slow way.  Call sk_tsv_count_lines first on every new content of a buffer: it builds the
+ * per-thread line index the other calls reuse (they re-check a cached index against the bytes -- every line
+ * start must follow a newline, the line count must match -- and rebuild it otherwise). */
 enum {
     SK_TSV_ALLINT   = 1,   /* every data token is [+-]digits                                  */
     SK_TSV_ANY      = 2,   /* some value is non-zero (the reference skips reads where none is) */
@@ -271,12 +273,15 @@ void  sk_ndtr(const double *z, double *out, int64_t n);
  * continues, fewer than max_rec records returned = end of the file (a reader indexes chunk by chunk).
  * sk_blow5_rows_i16 decodes records (comp: 0 = stored, 1 = zlib) into int16 rows of `stride` samples on all cores:
  * nsamp[i] samples, ids[i * id_width ..] the read id (NUL padded; NULL to skip), calib[3 i ..] = digitisation, offset,
- * range (NULL to skip); flags[i]: 1 = longer than a row (truncated to stride), 2 = unreadable record, 4 = id cut. */
+ * range (NULL to skip); flags[i]: 1 = longer than a row (truncated to stride), 2 = unreadable record (also: offset /
+ * size outside the `len` bytes of buf, a zlib record that inflates past 256x its size), 4 = id cut to id_width.
+ * Both index calls return SK_ERR_INVALID for a file cut inside a record or a size field, or with anything but the
+ * end marker behind the last record. */
 int64_t sk_blow5_index(const void *buf, int64_t len, int64_t first, int64_t *rec_off, int64_t *rec_size, int64_t cap);
 int64_t sk_blow5_index_some(const void *buf, int64_t len, int64_t pos, int64_t max_rec, int64_t *rec_off,
                             int64_t *rec_size, int64_t *next_pos);
-int sk_blow5_rows_i16(const void *buf, const int64_t *rec_off, const int64_t *rec_size, int64_t nrec, int32_t comp,
-                      int64_t stride, int16_t *rows, int32_t *nsamp, char *ids, int32_t id_width, double *calib,
+int sk_blow5_rows_i16(const void *buf, int64_t len, const int64_t *rec_off, const int64_t *rec_size, int64_t nrec,
+                      int32_t comp, int64_t stride, int16_t *rows, int32_t *nsamp, char *ids, int32_t id_width, double *calib,
                       int32_t *flags, int32_t nthreads);
 
 /* ---- multi-GPU: the final gather of result records (RCCL over xGMI) ------ */

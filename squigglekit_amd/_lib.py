@@ -141,7 +141,7 @@ ABI = {
     "sk_ndtr": (None, [_vp, _vp, C.c_int64]),
     "sk_blow5_index": (C.c_int64, [_vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int64]),
     "sk_blow5_index_some": (C.c_int64, [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp]),
-    "sk_blow5_rows_i16": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int32, C.c_int64, _vp, _vp, _vp, C.c_int32, _vp, _vp,
+    "sk_blow5_rows_i16": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int32, C.c_int64, _vp, _vp, _vp, C.c_int32, _vp, _vp,
                                     C.c_int32]),
     "sk_comm_unique_id": (C.c_int, [_vp]),
     "sk_comm_init_rank": (C.c_int, [_vp, C.c_int, C.c_int]),

@@ -8,12 +8,32 @@ import os
 import threading
 
 
-def start():
+def _device_from_argv(argv):
+    """The --device N (or --device=N) the tool is about to parse, if any: warming device 0 for a job bound elsewhere
+    would create a second context (memory, start-up time; a failure on a busy or exclusive GPU 0)."""
+    for i, a in enumerate(argv):
+        if a == "--device" and i + 1 < len(argv):
+            return argv[i + 1]
+        if a.startswith("--device="):
+            return a.split("=", 1)[1]
+    return None
+
+
+def start(argv=None):
+    import sys
+    want = _device_from_argv(sys.argv[1:] if argv is None else argv)
+    if want is None:
+        want = os.environ.get("SK_DEVICE", os.environ.get("LOCAL_RANK", "0")) or 0
+    try:
+        dev = int(want)
+    except ValueError:
+        return None                                              # the parser will complain; nothing to warm
+
     def run():
         try:
             hip = ctypes.CDLL("libamdhip64.so")
             hip.hipInit(0)
-            hip.hipSetDevice(int(os.environ.get("SK_DEVICE", os.environ.get("LOCAL_RANK", "0")) or 0))
+            hip.hipSetDevice(dev)
             hip.hipFree(None)                                    # forces the primary context into existence
         except Exception:                                        # noqa: BLE001 -- no runtime here: first use reports it
             pass

@@ -243,12 +243,12 @@ void sk_fmt_free(void *p) { free(p); }
 // uint16 idlen | id | uint32 read_group | f64 digitisation | f64 offset | f64 range | f64 sampling_rate |
 // uint64 n | int16[n] | aux fields; the file ends with "5WOLB".
 
-// What may follow the last record: nothing, or the end marker (and nothing else worth a record: fewer than 8 bytes).
+// What may follow the last record: nothing, or exactly the end marker.
 static bool blow5_clean_end(const unsigned char *buf, int64_t len, int64_t pos)
 {
     const int64_t left = len - pos;
     if (left == 0) return true;
-    return left >= 5 && memcmp(buf + pos, "5WOLB", 5) == 0;
+    return left == 5 && memcmp(buf + pos, "5WOLB", 5) == 0;
 }
 
 int64_t sk_blow5_index(const void *buf_, int64_t len, int64_t first, int64_t *rec_off, int64_t *rec_size, int64_t cap)

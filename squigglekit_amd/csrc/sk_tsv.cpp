@@ -121,7 +121,14 @@ const LineIndex &line_index(const char *buf, size_t len, bool fresh = false)
 {
     LineIndex &L = g_lines;
     const uint64_t fp = fingerprint(buf, len);
-    if (!fresh && L.buf == buf && L.len == len && L.print == fp && !L.off.empty()) return L;
+    if (!fresh && L.buf == buf && L.len == len && L.print == fp && !L.off.empty()) {
+        // same address, length and sampled words: still make sure every cached line start sits behind a newline of
+        // THIS content (a caller that reuses a buffer and skips sk_tsv_count_lines must not get stale offsets)
+        bool ok = true;
+        for (size_t i = 0; ok && i + 1 < L.off.size(); i++)
+            ok = L.off[i] == 0 || (L.off[i] > 0 && (size_t)L.off[i] <= len && buf[L.off[i] - 1] == '\n');
+        if (ok) return L;
+    }
     L.buf = buf; L.len = len; L.print = fp; L.off.clear();
     int T = (int)std::thread::hardware_concurrency();
     if (T > 16) T = 16;

@@ -191,17 +191,21 @@ def iter_blow5_blocks_i16(path, block_reads=16384, id_width=64, nthreads=0, keep
         # size / 2 bounds the sample count; zlib: start from the compressed size and grow if a read does not fit
         guess = int(size[:n].max()) // 2 if comp == 0 else int(size[:n].max()) * 2
         stride = max(8, (guess + 7) // 8 * 8)
+        idw = id_width
         while True:
             rows = buf(pool, "rows", (n, stride), np.int16, pinned=True)    # (valid until three blocks later)
             nsamp = buf(pool, "nsamp", (n,), np.int32)
-            ids = buf(pool, "ids", (n,), "S%d" % id_width)
+            ids = buf(pool, "ids", (n,), "S%d" % idw)
             calib = buf(pool, "calib", (n, 3), np.float64)
             flags = buf(pool, "flags", (n,), np.int32)
-            _lib.check(L.sk_blow5_rows_i16(base, off.ctypes.data, size.ctypes.data, n, comp, stride,
-                                           rows.ctypes.data, nsamp.ctypes.data, ids.ctypes.data, id_width,
+            _lib.check(L.sk_blow5_rows_i16(base, flen, off.ctypes.data, size.ctypes.data, n, comp, stride,
+                                           rows.ctypes.data, nsamp.ctypes.data, ids.ctypes.data, idw,
                                            calib.ctypes.data, flags.ctypes.data, int(nthreads)))
             if comp == 1 and np.any(flags & 1) and stride < (1 << 24):
                 stride = (int(nsamp.max()) + 7) // 8 * 8          # (nsamp holds the true lengths)
+                continue
+            if np.any(flags & 4) and idw < 65536:                 # a read id longer than the column: decode again, wider
+                idw *= 4                                          # (idlen is a uint16: 65 536 always fits)
                 continue
             break
         zapper.submit(forget, pos, nxt.value)

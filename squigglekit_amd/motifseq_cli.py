@@ -221,8 +221,15 @@ class _Batcher:
         previous block's table is written (drain() at the end); the caller keeps `rows` alive one call longer."""
         if not len(nsamp):
             return
-        motifs = [np.asarray(self.models[n_], dtype=np.float64) for n_ in self.order]
         a = self.args
+        if a.after_stall:
+            # get_segs first, then the search behind the stall: the per-read queue does that (api.motifseq_after_stall,
+            # up to --batch reads per GPU call) and prints the search_from column; `rows` is reused by the reader
+            self.drain()
+            for i in range(len(nsamp)):
+                self.add(name_of(i), id_of(i), np.array(rows[i, :nsamp[i]], dtype=np.float64))
+            return
+        motifs = [np.asarray(self.models[n_], dtype=np.float64) for n_ in self.order]
         if self._worker is None:
             from concurrent.futures import ThreadPoolExecutor
             self._worker = ThreadPoolExecutor(1)
@@ -391,18 +398,27 @@ def main(argv=None):
     elif args.blow5:
         # [extension] BLOW5: records decoded natively into int16 rows (raw ADC values, as the fast5 branches use)
         fast5 = os.path.basename(args.blow5).encode()
-        for blk in fastio.iter_blow5_blocks_i16(args.blow5, keep=_KEEP):
-            bad = np.flatnonzero(blk.flags & 2)
-            for i in bad:
-                sys.stderr.write("MotifSeq: unreadable BLOW5 record {} in {}; skipped\n".format(int(i), args.blow5))
-            if bad.size:
-                ok = np.flatnonzero((blk.flags & 2) == 0)
-                blk = fastio.Blow5Block(blk.rows[ok], blk.nsamp[ok], blk.ids[ok], blk.calib[ok], blk.flags[ok])
-            w = blk.ids.dtype.itemsize
-            st = np.arange(blk.n, dtype=np.int64) * w
-            spans = np.stack([st, st + np.char.str_len(blk.ids)], axis=1)
-            out.rows(blk.rows, blk.nsamp, ("const", fast5), ("span", blk.ids, spans),
-                     lambda i: fast5.decode(), lambda i, b=blk: b.ids[i].decode())
+        seen = 0
+        try:
+            for blk in fastio.iter_blow5_blocks_i16(args.blow5, keep=_KEEP):
+                bad = np.flatnonzero(blk.flags & 2)
+                for i in bad:
+                    sys.stderr.write("MotifSeq: unreadable BLOW5 record {} in {}; skipped\n".format(seen + int(i), args.blow5))
+                seen += blk.n
+                if bad.size:
+                    ok = np.flatnonzero((blk.flags & 2) == 0)
+                    blk = fastio.Blow5Block(blk.rows[ok], blk.nsamp[ok], blk.ids[ok], blk.calib[ok], blk.flags[ok])
+                w = blk.ids.dtype.itemsize
+                st = np.arange(blk.n, dtype=np.int64) * w
+                spans = np.stack([st, st + np.char.str_len(blk.ids)], axis=1)
+                out.rows(blk.rows, blk.nsamp, ("const", fast5), ("span", blk.ids, spans),
+                         lambda i: fast5.decode(), lambda i, b=blk: b.ids[i].decode())
+        except ValueError as e:                          # truncated file, unsupported compression: say so, no traceback
+            out.drain()
+            out.flush()
+            sys.stdout.flush()
+            sys.stderr.write("MotifSeq: --blow5: {}\n".format(e))
+            sys.exit(1)
     elif args.i16:
         # [extension] packed reads: int16 [reads, samples] in a .npy file, memory mapped
         fast5 = os.path.basename(args.i16).encode()

@@ -8,6 +8,7 @@ order.  Additive flags: --device, --batch, --blow5.  There is no CPU path.
 import argparse
 import os
 import sys
+from struct import error as struct_error
 
 import numpy as np
 
@@ -231,14 +232,24 @@ def main(argv=None):
                 out.add(name, sig[:args.Num])
             out.flush()
     elif args.blow5 and args.raw_signal:
-        for blk in fastio.iter_blow5_blocks_i16(args.blow5, keep=_KEEP):
-            ok = np.flatnonzero((blk.flags & 2) == 0)
-            if ok.size != blk.n:
-                blk = fastio.Blow5Block(blk.rows[ok], blk.nsamp[ok], blk.ids[ok], blk.calib[ok], blk.flags[ok])
-            w = blk.ids.dtype.itemsize
-            st = np.arange(blk.n, dtype=np.int64) * w
-            out.rows(blk.rows, blk.nsamp, ("span", blk.ids, np.stack([st, st + np.char.str_len(blk.ids)], axis=1)),
-                     lambda i, b=blk: b.ids[i].decode())
+        seen = 0
+        try:
+            for blk in fastio.iter_blow5_blocks_i16(args.blow5, keep=_KEEP):
+                ok = np.flatnonzero((blk.flags & 2) == 0)
+                for i in np.flatnonzero(blk.flags & 2):
+                    sys.stderr.write("segmenter: unreadable BLOW5 record {} in {}; skipped\n".format(seen + int(i), args.blow5))
+                seen += blk.n
+                if ok.size != blk.n:
+                    blk = fastio.Blow5Block(blk.rows[ok], blk.nsamp[ok], blk.ids[ok], blk.calib[ok], blk.flags[ok])
+                w = blk.ids.dtype.itemsize
+                st = np.arange(blk.n, dtype=np.int64) * w
+                out.rows(blk.rows, blk.nsamp, ("span", blk.ids, np.stack([st, st + np.char.str_len(blk.ids)], axis=1)),
+                         lambda i, b=blk: b.ids[i].decode())
+        except ValueError as e:                          # truncated file, unsupported compression: say so, no traceback
+            out.drain()
+            out.flush()
+            sys.stderr.write("segmenter: --blow5: {}\n".format(e))
+            sys.exit(1)
     elif args.i16:
         try:
             for lo, part in fastio.iter_npy_blocks_i16(args.i16, keep=_KEEP):
@@ -249,11 +260,16 @@ def main(argv=None):
             sys.exit(1)
     elif args.blow5:
         from .blow5 import read_blow5, to_pA
-        for rec in read_blow5(args.blow5):
-            sig = rec["signal"].astype(int)
-            if not args.raw_signal:
-                sig = to_pA(sig, rec["digitisation"], rec["offset"], rec["range"])
-            out.add(rec["read_id"], sig[:args.Num])
+        try:
+            for rec in read_blow5(args.blow5):
+                sig = rec["signal"].astype(int)
+                if not args.raw_signal:
+                    sig = to_pA(sig, rec["digitisation"], rec["offset"], rec["range"])
+                out.add(rec["read_id"], sig[:args.Num])
+        except (ValueError, EOFError, struct_error) as e:
+            out.flush()
+            sys.stderr.write("segmenter: --blow5: {}\n".format(e))
+            sys.exit(1)
     else:
         if args.f5_path:
             files = [os.path.join(d, f) for d, _, fs in os.walk(args.f5_path) for f in fs if f.endswith(".fast5")]

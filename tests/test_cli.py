@@ -334,3 +334,62 @@ def test_launchers_as_processes_flush_everything_before_the_fast_exit(gpu, tmp_p
     p = subprocess.run([sys.executable, os.path.join(root, "MotifSeq.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        timeout=300)
     assert p.returncode == 1 and b"usage" in p.stderr.lower()
+
+
+@pytest.mark.gpu
+def test_after_stall_with_packed_and_blow5_inputs(gpu, tmp_path):
+    """[extensions] --after_stall must mean the same thing whatever the input route: get_segs, then the search behind
+    the stall, a search_from column in every row (the packed routes used to search the whole read and print 12 columns
+    under a 13-column header)."""
+    from squigglekit_amd import fastio, synth
+    from squigglekit_amd.motifseq_cli import main as mmain
+    R, M = 120, 3000
+    motif = synth.synthetic_motif(163, seed=11)
+    sig = synth.squiggle_batch(R, M, 4242, motif=motif)
+    np.save(tmp_path / "r.npy", sig)
+    ids = ["read-%04d" % i for i in range(R)]
+    fastio.write_blow5(str(tmp_path / "r.blow5"), sig, ids)
+    with open(tmp_path / "m.tsv", "w") as fm:
+        for i in range(R):
+            fm.write("\t".join(["f.fast5", ids[i]] + ["x"] * 6) + "\t" + "\t".join(str(int(v)) for v in sig[i]) + "\n")
+    model = os.path.join(GOLD, "CATCTATCCAGGGTTAAATT.model")
+    ref, err, code = run_cli(mmain, ["-s", str(tmp_path / "m.tsv"), "-m", model, "--after_stall"])
+    assert code == 0, err[-400:]
+    rows = [ln.split("\t") for ln in ref.strip().split("\n")]
+    assert rows[0][-1] == "search_from" and all(len(r) == len(rows[0]) for r in rows)
+    assert any(int(r[-1]) > 0 for r in rows[1:]), "no read had a stall to search behind"
+    plain, _, _ = run_cli(mmain, ["-s", str(tmp_path / "m.tsv"), "-m", model])
+    assert [r[3:12] for r in rows[1:]] != [ln.split("\t")[3:12] for ln in plain.strip().split("\n")[1:]]
+    for argv in (["--i16", str(tmp_path / "r.npy")], ["--blow5", str(tmp_path / "r.blow5")]):
+        got, err2, code = run_cli(mmain, argv + ["-m", model, "--after_stall"])
+        assert code == 0, err2[-400:]
+        grows = [ln.split("\t") for ln in got.strip().split("\n")]
+        assert [r[2:] for r in grows] == [r[2:] for r in rows], argv          # every column but the two name columns
+
+
+def test_blow5_errors_are_messages_not_tracebacks(oracle_backend, tmp_path):
+    """A truncated BLOW5 file, one cut inside a size field, one with zstd records: one line on stderr, exit 1, the rows
+    decoded before the damage still printed -- for every --blow5 branch of both tools."""
+    from squigglekit_amd import fastio, synth
+    from squigglekit_amd.motifseq_cli import main as mmain
+    from squigglekit_amd.segmenter_cli import main as smain
+    sig = synth.squiggle_batch(40, 1500, 3)
+    good = tmp_path / "g.blow5"
+    fastio.write_blow5(str(good), sig, ["r%d" % i for i in range(40)])
+    data = good.read_bytes()
+    cut = tmp_path / "cut.blow5"
+    cut.write_bytes(data[:len(data) - 1000])
+    cut2 = tmp_path / "cut2.blow5"
+    cut2.write_bytes(data[:len(data) - 5 - 3000 - 3])             # inside a record
+    zstd = tmp_path / "zstd.blow5"
+    zstd.write_bytes(data[:9] + b"\x02" + data[10:])
+    model = os.path.join(GOLD, "CATCTATCCAGGGTTAAATT.model")
+    for path in (cut, cut2, zstd):
+        for main, argv, tool in ((smain, ["--blow5", str(path), "--raw_signal"], "segmenter"),
+                                 (smain, ["--blow5", str(path)], "segmenter"),
+                                 (mmain, ["--blow5", str(path), "-m", model], "MotifSeq")):
+            out, err, code = run_cli(main, argv)
+            assert code == 1, (path.name, argv, err[-300:])
+            assert "Traceback" not in err and "%s: --blow5:" % tool in err, (path.name, argv, err[-300:])
+    out, err, code = run_cli(smain, ["--blow5", str(good), "--raw_signal"])
+    assert code == 0 and "--blow5:" not in err
