@@ -15,8 +15,11 @@ Two launch shapes give the same line (squigglekit_amd/multigpu.py):
     python -m torch.distributed.run --nproc-per-node N bench.py --gpus N      one process per GPU; only the
                      launcher's environment is read (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT) -- torch is
                      never imported; rank 0's ncclUniqueId travels through a file store under $TMPDIR.
-`--scaling weak` (default): --reads per GPU (C4 on every GPU); `--scaling strong`: --reads in total (C4 as
-BASELINE.json words it: 1 M reads sharded 1/2/4/8).  With N > 1 the weak run also reports a short strong run.
+`--scaling strong` (default): --reads in TOTAL, block-sharded (C4 as BASELINE.json words it: 1 M reads on 1/2/4/8
+GPUs); `--scaling weak`: --reads per GPU.  Every rank keeps --reads reads resident, so at N > 1 the other curve is
+measured in the same launch and reported beside the headline (`weak_scaling` / `strong_scaling`).  The line carries
+`ranks_seen`, `gather_backend` and `per_rank` (each rank's own ms_per_step and host-to-device GB/s).  Asking for more
+ranks than there are GPUs is refused (exit 2) unless SK_OVERSUBSCRIBE / --ranks-on-device says it is a dry run.
 
 Dry run of the N > 1 paths on a box with fewer GPUs than ranks: `--ranks-on-device D` (or SK_OVERSUBSCRIBE=1 under a
 per-GPU launcher) puts every rank on device D with its own context slot; the gather then runs on the host backend
@@ -54,9 +57,10 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="motifseq", choices=["motifseq", "segmenter"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: --reads per GPU; strong: --reads in total, sharded over the GPUs")
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (weak) or in total (strong)")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="strong (default): --reads in TOTAL, block-sharded over the GPUs -- C4 as BASELINE.json words it "
+                         "(1 M reads, 1/2/4/8 GPUs); weak: --reads per GPU.  At N > 1 the other one is reported as an extra")
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads in total (strong) or per GPU (weak)")
     ap.add_argument("--samples", type=int, default=4000)
     ap.add_argument("--motif", type=int, default=200, help="motif points")
     ap.add_argument("--scale", default="medmad", choices=["medmad", "zscale"])
@@ -168,7 +172,7 @@ class Workload:
         check(L.sk_sync())
         if self.comm is not None and self.comm.backend != "rccl":
             # RCCL could not be loaded / initialised: the same exchange by host concatenation
-            if self.host_rec is None:
+            if self.host_rec is None or self.host_rec.size != max(1, self.pad) * self.rec_bytes:
                 self.host_rec = np.zeros(max(1, self.pad) * self.rec_bytes, dtype=np.uint8)
             if self.R:
                 check(L.sk_dev_download(ptr(self.host_rec), self.d_out, self.R * self.rec_bytes))
@@ -236,6 +240,7 @@ def timed(w, comm, steps, warmup):
                 prof["retries"] += rt
     fence()
     elapsed = time.perf_counter() - t0
+    w.own_elapsed = elapsed                                # (this rank's; the return value is the maximum over ranks)
     if comm is not None:
         elapsed = float(comm.allgather_host(np.array([elapsed], dtype=np.float64)).max())
     return elapsed, prof
@@ -429,19 +434,21 @@ def e2e_all_ranks(a, w, comm):
     lens = w.lens[:Rh]
     if Rh:
         check(L.sk_dev_download(ptr(host), w.d_sig, Rh * w.stride * 2))
-    best = None
+    best, own = None, None
     for it in range(3):
         comm.barrier()
         t0 = time.perf_counter()
         if Rh:
             check(L.sk_motifseq_batch_i16(ptr(host), w.stride, ptr(lens), Rh, ptr(w.motif), w.N, w.mode, 0, 1200,
                                           ptr(hits)))
-        dt = time.perf_counter() - t0
-        dt = float(comm.allgather_host(np.array([dt], dtype=np.float64)).max())
+        mine = time.perf_counter() - t0
+        dt = float(comm.allgather_host(np.array([mine], dtype=np.float64)).max())
         if it and (best is None or dt < best):
             best = dt
+        if it and (own is None or mine < own):
+            own = mine
     del host
-    return Rh, best
+    return Rh, best, (Rh * w.stride * 2 / own / 1e9 if (own and Rh) else 0.0)
 
 
 def cli_block(a, L, main):
@@ -753,22 +760,34 @@ def other_paths_block(a, L, main):
 
 
 
+def _kernels_sha():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from kernels_sha import kernels_sha
+        return kernels_sha(ROOT)
+    except Exception:                                                 # noqa: BLE001 -- tools/ not shipped: no stamp
+        return None
+
+
 def traffic_from_profiles(workload, pattern):
     """HBM bytes per read of one kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, collected
     separately with rocprofv3 --pmc: a bench run cannot read hardware counters itself)."""
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
     try:
         tj = json.load(open(tpath))
+        stamp = tj.get("kernels_sha")
+        stale = " [STALE: measured on kernel sources %s, running %s]" % (stamp or "unstamped", _kernels_sha()) \
+            if stamp != _kernels_sha() else ""
         if pattern is None:                                          # every kernel of the step together
             tot = sum(kk["fetch_bytes_total"] + kk["write_bytes_total"] for kk in tj["kernels"].values())
             per_read = tot / (tj["reads_per_call"] * max(1, tj.get("calls", 1)))
-            return per_read, "profiles/traffic_%s.json: all kernels, %.0f B/read measured" % (workload, per_read)
+            return per_read, "profiles/traffic_%s.json: all kernels, %.0f B/read measured%s" % (workload, per_read, stale)
         key = [k for k in tj["kernels"] if pattern in k]
         if key and tj.get("reads_per_call"):
             kk = tj["kernels"][key[0]]
             per_read = (kk["fetch_bytes_total"] + kk["write_bytes_total"]) / (
                 tj["reads_per_call"] * max(1, tj.get("calls", 1)))
-            return per_read, "profiles/traffic_%s.json: %s, %.0f B/read measured" % (workload, key[0], per_read)
+            return per_read, "profiles/traffic_%s.json: %s, %.0f B/read measured%s" % (workload, key[0], per_read, stale)
     except Exception:
         pass
     return None, None
@@ -830,6 +849,7 @@ def motifseq_roofline(a, w, prof, steps, mean_n):
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+            "traffic_stale": bool(src and "STALE" in src),
             "traffic_ratio": (traffic / alg_bytes) if traffic else None,
             "traffic_ratio_whole_step": (step_read / (2 * M + HIT_BYTES)) if step_read else None,
             "kernel_ms": {"prep": prep_ms, "main": main_ms, "dominant_avg_launch": dom_ms},
@@ -876,6 +896,7 @@ def segmenter_roofline(w, prof, steps, step_ms=None):
     whole = alg_bytes / (step_ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": per_read * R if per_read else None, "traffic_source": src,
+            "traffic_stale": bool(src and "STALE" in src),
             "traffic_ratio": (per_read * R / alg_bytes) if per_read else None,
             "kernel_ms": {"prep": prep_ms, "main": main_ms, "dominant_avg_launch": dom_ms},
             "algorithmic_bytes_per_launch": alg_bytes,
@@ -983,31 +1004,44 @@ def rank_body(a, comm, rank, world, shape):
     """Runs on the rank's own thread / process with its device bound.  Returns the JSON line on rank 0."""
     from squigglekit_amd import _lib, sharding
     L = _lib.load()
-    if a.scaling == "strong":
-        lo, hi = sharding.shard_bounds(a.reads, rank, world)
-        R, pad = hi - lo, max(sharding.shard_sizes(a.reads, world))
-    else:
-        R = pad = a.reads
+    # Every rank keeps a.reads reads resident (the weak-scaling shard); the strong-scaling job -- a.reads in TOTAL,
+    # block-sharded -- runs on the first hi - lo of them, so both curves come out of one launch.
+    lo, hi = sharding.shard_bounds(a.reads, rank, world)
+    strong_R, strong_pad = hi - lo, max(sharding.shard_sizes(a.reads, world))
     use_comm = comm if (world > 1 or a.force_comm) else None
+    R_alloc = a.reads if (a.scaling == "weak" or world > 1) else strong_R
+    w = Workload(a, L, rank, world, R_alloc, comm=use_comm, gather_pad=R_alloc)
+
+    def run(scaling, steps, warmup):
+        if scaling == "strong":
+            w.R, w.pad = strong_R, strong_pad
+        else:
+            w.R, w.pad = a.reads, a.reads
+        el, pf = timed(w, use_comm, steps, warmup)
+        own = float(getattr(w, "own_elapsed", el))
+        per_rank = ([float(v) for v in use_comm.allgather_host(np.array([own], dtype=np.float64))]
+                    if use_comm is not None else [own])
+        return el, pf, [v / steps * 1e3 for v in per_rank]
+
+    elapsed, prof, per_rank_ms = run(a.scaling, a.steps, a.warmup)
     shard_sizes = sharding.shard_sizes(a.reads, world) if a.scaling == "strong" else [a.reads] * world
-    w = Workload(a, L, rank, world, R, comm=use_comm, gather_pad=pad)
-    elapsed, prof = timed(w, use_comm, a.steps, a.warmup)
     ranks_seen = use_comm.ranks_seen() if use_comm is not None else 1
 
-    strong = None
-    if world > 1 and a.scaling == "weak" and a.workload == "motifseq":
-        # the same job as BASELINE.json words C4 -- a.reads in TOTAL, sharded -- on the data already resident
-        lo, hi = sharding.shard_bounds(a.reads, rank, world)
-        keepR, keeppad = w.R, w.pad
-        w.R, w.pad = hi - lo, max(sharding.shard_sizes(a.reads, world))
-        el_s, _ = timed(w, use_comm, a.steps, 1)
-        w.R, w.pad = keepR, keeppad
-        strong = {"scaling": "strong", "total_reads": a.reads, "value": a.reads * a.steps / el_s, "unit": "reads/s",
-                  "ms_per_step": el_s / a.steps * 1e3, "steps": a.steps}
-        w.step()                                                # every rank: d_out holds its full shard again
-    e2e_multi = None
+    other = None
+    if world > 1 and a.workload == "motifseq":
+        # the other curve on the data already resident (weak: C4 on every GPU; strong: C4 as BASELINE.json words it)
+        oscale = "weak" if a.scaling == "strong" else "strong"
+        el_o, _, pr_o = run(oscale, a.steps, 1)
+        tot = a.reads * world if oscale == "weak" else a.reads
+        other = {"scaling": oscale, "total_reads": tot, "value": tot * a.steps / el_o, "unit": "reads/s",
+                 "ms_per_step": el_o / a.steps * 1e3, "steps": a.steps, "per_rank_ms_per_step": pr_o}
+        run(a.scaling, 1, 0)                                    # every rank: d_out holds the headline's shard again
+    if a.scaling == "strong":
+        w.R, w.pad = strong_R, strong_pad
+    e2e_multi, h2d = None, None
     if world > 1 and a.workload == "motifseq" and not a.no_extras:
         e2e_multi = e2e_all_ranks(a, w, use_comm)               # (every rank takes part)
+        h2d = [float(v) for v in use_comm.allgather_host(np.array([e2e_multi[2]], dtype=np.float64))]
     if rank != 0:
         w.free()
         return None
@@ -1052,10 +1086,16 @@ def rank_body(a, comm, rank, world, shape):
                        "oversubscribed": ("every rank on device %d (dry run of the N > 1 path)" % a.ranks_on_device)
                        if a.ranks_on_device is not None else None},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity}
-    if strong:
-        line["strong_scaling"] = strong
+    line["ranks_seen"] = ranks_seen
+    line["gather_backend"] = use_comm.backend if use_comm is not None else None
+    line["per_rank"] = {"ms_per_step": per_rank_ms, "h2d_GBps": h2d,
+                        "note": "each rank's own wall clock of the timed steps (the line's ms_per_step is their maximum); "
+                                "h2d_GBps: its host-to-device rate in the every-rank end-to-end leg -- a slow PCIe root "
+                                "or a rank on the wrong NUMA node shows here"}
+    if other:
+        line["%s_scaling" % other["scaling"]] = other
     if e2e_multi is not None:
-        Rh, dt = e2e_multi
+        Rh, dt = e2e_multi[:2]
         line["end_to_end"] = {"reads_per_gpu": Rh, "motifseq_pinned_reads_per_s": world * Rh / dt if dt else None,
                               "note": "every rank at once: pinned host arrays -> sk_motifseq_batch_i16 (H2D of one "
                                       "sub-batch under the kernels of the previous one) -> host records; one feeder "
@@ -1084,6 +1124,12 @@ def main(argv=None):
         a.ranks_on_device = multigpu.oversubscribed()
     shape, rank, local, world = multigpu.plan(a.gpus)
     a.gpus = world
+    if world > 1 and a.ranks_on_device is None:
+        have = _lib.load().sk_device_count()
+        if have < world:
+            sys.stderr.write("bench.py: %d GPU(s) visible, %d ranks asked for; set SK_OVERSUBSCRIBE=1 (or --ranks-on-device D) "
+                             "for a dry run of the N > 1 path on one device\n" % (have, world))
+            sys.exit(2)
     if shape == "process":
         with multigpu.ProcessGroup(rank, local, world) as comm:
             line = rank_body(a, comm, rank, world, shape)

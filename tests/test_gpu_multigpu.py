@@ -90,6 +90,13 @@ def _check_multi_rank_line(line, world):
     assert all(e["reads"] >= 64 and e["dist_bit_identical"] and e["start_end_exact"] for e in par["per_rank"])
     assert par["per_rank"][0]["regenerated_equals_resident"]
     assert "gathered buffer" in par["source"]
+    # what makes a first real multi-GPU run readable from the one line: who took part, how the gather ran, every
+    # rank's own step time and ingest rate
+    assert line["ranks_seen"] == world and line["gather_backend"] == "host"
+    pr = line["per_rank"]
+    assert len(pr["ms_per_step"]) == world and all(v > 0 for v in pr["ms_per_step"])
+    assert max(pr["ms_per_step"]) <= line["ms_per_step"] * 1.001
+    assert pr["h2d_GBps"] is None or (len(pr["h2d_GBps"]) == world and all(v > 0 for v in pr["h2d_GBps"]))
 
 
 @pytest.mark.parametrize("world,scaling,reads", [(2, "weak", 20000), (3, "strong", 30001)])
@@ -108,9 +115,12 @@ def test_bench_world_gt1_oversubscribed_threads(gpu, world, scaling, reads):
     if scaling == "weak":
         assert line["config"]["total_reads"] == reads * world and line["strong_scaling"]["total_reads"] == reads
     else:
+        # the headline at N > 1 is C4 as BASELINE.json words it (reads in TOTAL); the weak curve is the extra
         assert line["config"]["total_reads"] == reads
+        assert line["weak_scaling"]["total_reads"] == reads * world and line["weak_scaling"]["value"] > 0
+        assert len(line["weak_scaling"]["per_rank_ms_per_step"]) == world
         assert sum(e["reads"] for e in line["parity"]["per_rank"]) >= 3 * 64
-    assert line["end_to_end"]["motifseq_pinned_reads_per_s"] > 0
+    assert line["end_to_end"]["motifseq_pinned_reads_per_s"] > 0 and len(line["per_rank"]["h2d_GBps"]) == world
     assert "sensitivity" not in line and "secondary" not in line          # N = 1 extras stay out
 
 
@@ -129,7 +139,20 @@ def test_bench_world2_oversubscribed_process_per_rank(gpu):
     line = json.loads(lines[0])
     _check_multi_rank_line(line, 2)
     assert line["config"]["launch"].startswith("one process per GPU")
-    assert line["strong_scaling"]["total_reads"] == 20000
+    assert line["scaling"] == "strong" and line["config"]["total_reads"] == 20000        # the default: BASELINE's wording
+    assert line["weak_scaling"]["total_reads"] == 40000
+
+
+def test_bench_refuses_more_ranks_than_gpus(gpu):
+    """`bench.py --gpus N` with fewer than N GPUs and no SK_OVERSUBSCRIBE: one line of reason, exit code 2 -- never a
+    silent run of N ranks on one device that would print a nonsense scaling point."""
+    have = gpu.load().sk_device_count()
+    env = {k: v for k, v in os.environ.items() if k != "SK_OVERSUBSCRIBE"}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 1), "--reads", "4096", "--steps", "1"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert p.returncode == 2 and p.stdout.strip() == "", (p.returncode, p.stdout[-300:])
+    msg = [ln for ln in p.stderr.strip().splitlines() if ln.startswith("bench.py:")]
+    assert len(msg) == 1 and "SK_OVERSUBSCRIBE" in msg[0] and "%d GPU" % have in msg[0]
 
 
 def test_product_api_two_ranks_on_one_device(gpu, ora, monkeypatch):

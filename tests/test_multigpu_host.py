@@ -27,7 +27,7 @@ def test_bench_cli_defaults_finish_fast():
     sys.path.insert(0, ROOT)
     import bench
     a = bench.parse([])
-    assert (a.gpus, a.workload, a.scaling, a.reads, a.samples, a.motif) == (1, "motifseq", "weak", 1_000_000, 4000, 200)
+    assert (a.gpus, a.workload, a.scaling, a.reads, a.samples, a.motif) == (1, "motifseq", "strong", 1_000_000, 4000, 200)      # C4 as BASELINE.json words it
     rows = bench.strided_rows(1_000_000, 8192)
     assert rows[0] == 0 and rows[-1] == 999_999 and 8000 <= len(rows) <= 8192
     assert np.unique(rows // 250_000).size == 4                      # every chunk of the screening path is sampled

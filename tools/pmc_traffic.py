@@ -14,7 +14,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernels_sha import kernels_sha
 
 
 def load(d, counter):
@@ -36,7 +40,7 @@ def main():
     fetch = load(sys.argv[3], "FETCH_SIZE")
     write = load(sys.argv[4], "WRITE_SIZE")
     label = sys.argv[5] if len(sys.argv) > 5 else ""
-    res = {"label": label, "reads_per_call": reads, "calls": calls,
+    res = {"label": label, "reads_per_call": reads, "calls": calls, "kernels_sha": kernels_sha(),
            "note": "bytes = FETCH_SIZE*1024*2 (gfx950 half-count correction) + WRITE_SIZE*1024; "
                    "per call = sum over the launches one hot-path call makes (chunks), averaged over calls",
            "kernels": {}}
