@@ -66,3 +66,83 @@ def test_c2_segmenter_full_size_properties(gpu, ora):
     # checksum of checksums, stable across runs of the same seed (regression anchor)
     again, nagain = api.segment_batch(sig, lens)
     assert np.array_equal(again, segs) and np.array_equal(nagain, nsegs)
+
+
+def test_f64_route_full_size_250k_pa_reads(gpu, ora):
+    """The float64 route at the size bench.py's other_paths block runs it (250 000 reads x 3 999 samples, 8 GB, device
+    resident): (i) on integer-valued doubles it must agree with the int16 kernels for EVERY read -- two kernel
+    families, one answer: segments and MotifSeq records byte for byte; (ii) on the pA image of the same reads a sample
+    strided over the whole batch against the oracle, and the share of reads the streaming kernel could not certify
+    stays tiny."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from conftest import download_rows, strided_rows
+    from squigglekit_amd import synth
+    from squigglekit_amd._lib import HIT_DTYPE, SegParams, check, ptr
+    L = gpu.load()
+    R, M, N, MAXS = 250_000, 4000, 200, 16
+    Mf = M - 1
+    motif = synth.synthetic_motif(N)
+    bufs = []
+
+    def alloc(nbytes):
+        q = L.sk_dev_alloc(nbytes)
+        assert q
+        bufs.append(q)
+        return q
+    try:
+        d_sig, d_len = alloc(R * M * 2), alloc(R * 4)
+        check(L.sk_synth_squiggles_dev(d_sig, M, R, M, synth.SEED_C2, ptr(motif), N))
+        lens = np.full(R, Mf, dtype=np.int32)
+        check(L.sk_dev_upload(d_len, ptr(lens), lens.nbytes))
+        d_f, d_off = alloc(R * Mf * 8), alloc((R + 1) * 8)
+        d_segs, d_ns, d_segs2, d_ns2 = alloc(R * MAXS * 8), alloc(R * 4), alloc(R * MAXS * 8), alloc(R * 4)
+        d_h, d_h2 = alloc(R * 24), alloc(R * 24)
+        sp = SegParams()
+
+        def fetch(d, shape, dtype):
+            a = np.empty(shape, dtype=dtype)
+            check(L.sk_dev_download(ptr(a), d, a.nbytes))
+            return a
+        # (i) integer-valued doubles: offset 0, range / digitisation = 1, two decimals change nothing
+        check(L.sk_synth_pa_dev(d_sig, M, R, Mf, 0.0, 1.0, 1.0, d_f, d_off))
+        check(L.sk_segment_dev_i16(d_sig, M, d_len, R, C.byref(sp), d_segs, d_ns, MAXS))
+        check(L.sk_segment_dev_f64(d_f, d_off, R, R * Mf, Mf, C.byref(sp), d_segs2, d_ns2, MAXS))
+        check(L.sk_sync())
+        assert L.sk_last_f64_retries() >= 0
+        ns, ns2 = fetch(d_ns, R, np.int32), fetch(d_ns2, R, np.int32)
+        assert np.array_equal(ns, ns2) and 0.3 < (ns == 1).mean() < 0.7
+        assert fetch(d_segs, (R, MAXS, 2), np.int32).tobytes() == fetch(d_segs2, (R, MAXS, 2), np.int32).tobytes()
+        check(L.sk_motifseq_dev_i16(d_sig, M, d_len, R, ptr(motif), N, 0, 0, 1200, d_h))
+        check(L.sk_motifseq_dev_f64(d_f, d_off, R, R * Mf, Mf, ptr(motif), N, 0, 0, 1200, d_h2))
+        check(L.sk_sync())
+        assert L.sk_last_f64_retries() >= 0
+        h, h2 = fetch(d_h, R, HIT_DTYPE), fetch(d_h2, R, HIT_DTYPE)
+        assert h.tobytes() == h2.tobytes()
+        assert np.all(h["n"] > 3900) and np.all((0 <= h["start"]) & (h["start"] <= h["end"]) & (h["end"] < h["n"]))
+        # (ii) the pA image (SquigglePull's np.round(..., 2)) against the oracle on a strided sample
+        check(L.sk_synth_pa_dev(d_sig, M, R, Mf, 16.0, 1493.94, 8192.0, d_f, d_off))
+        check(L.sk_segment_dev_f64(d_f, d_off, R, R * Mf, Mf, C.byref(sp), d_segs2, d_ns2, MAXS))
+        check(L.sk_sync())
+        retried = L.sk_last_f64_retries()
+        assert 0 <= retried <= R // 1000, "%d of %d reads could not be certified" % (retried, R)
+        check(L.sk_motifseq_dev_f64(d_f, d_off, R, R * Mf, Mf, ptr(motif), N, 0, 0, 1200, d_h2))
+        check(L.sk_sync())
+        ns2, segs2, h2 = fetch(d_ns2, R, np.int32), fetch(d_segs2, (R, MAXS, 2), np.int32), fetch(d_h2, R, HIT_DTYPE)
+        rows = strided_rows(R, 384)
+        pa = download_rows(L, d_f, Mf * 8, rows, np.float64, Mf)
+        op = ora.SegParams(sp.error, sp.corrector, sp.window, sp.seg_dist, sp.std_scale, sp.stall_len)
+
+        def one(k):
+            f = ora.scale_outliers(pa[k], 0, 900)
+            want = ora.get_segs(f, op) or []
+            f2 = ora.scale_outliers(pa[k], 0, 1200)
+            return want, ora.dtw_subsequence(motif, ora.medmad(f2)[0]) + (f2.size,)
+        with ThreadPoolExecutor(32) as ex:
+            want = list(ex.map(one, range(len(rows))))
+        for k, r in enumerate(rows):
+            assert segs2[r, :ns2[r]].tolist() == want[k][0], r
+            assert (h2["dist"][r], h2["start"][r], h2["end"][r], h2["n"][r]) == want[k][1], r
+    finally:
+        for q in bufs:
+            L.sk_dev_free(q)
