@@ -386,6 +386,7 @@ static int motifseq_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off
     SK_HIP(hipEventRecord(c->ev[1], c->stream));
     sk_sdtw_args a;
     a.feed = SK_FEED_F64_NORM; a.samples = c->comp.p; a.stride = 0; a.off = d_off;
+    a.samples_raw = d_sig;                              // (reads the filter left whole are not copied: SK_IFLAG_INPLACE)
     a.prep = (const sk_prep *)c->prep.p; a.nreads = nreads; a.motif = motif; a.nmotif = nmotif;
     a.out = d_out; a.last_row = nullptr; a.max_len = maxlen; a.force_single = 0;
     if ((rc = sk_launch_sdtw(c, &a))) return rc;

@@ -22,6 +22,12 @@ struct sk_prep {
     double  bot;      // segmenter: median - std*std_scale   (segmenter.py:414)
 };
 
+// Internal flag bits of sk_prep::flags (never reach sk_hit::flags: the DTW kernels keep the low byte only).
+// INPLACE: nothing of this float64 read was dropped by the filter, so its filtered samples were not copied -- the DTW
+// feed reads them from the caller's buffer (sk_sdtw_args::samples_raw) at the same offsets.
+#define SK_IFLAG_INPLACE 0x100
+#define SK_FLAG_PUBLIC   0xff
+
 enum sk_prep_mode { SK_PREP_MEDMAD = 0, SK_PREP_ZSCALE = 1, SK_PREP_SEGMENT = 2, SK_PREP_DRNA = 3 };
 
 // Growable device scratch buffer.
@@ -159,6 +165,8 @@ struct sk_sdtw_args {
     int64_t       max_len;     // upper bound of any read's filtered length (chooses 1 vs 2 passes)
     int           force_single;// 1: always the single FULL pass
     int           accumulate = 0;  // 1: a further launch set of the same API call (keep the retry total)
+    const void   *samples_raw = nullptr;  // float64 feeds: the unfiltered input (same offsets), read instead of `samples`
+                                          // for reads flagged SK_IFLAG_INPLACE
     const sk_prep_fuse *fuse = nullptr;   // non-null: samples / prep are NOT filled yet (see sk_prep_fuse); they are
                                           // the writable c->comp / c->prep buffers
 };

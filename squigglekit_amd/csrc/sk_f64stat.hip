@@ -353,14 +353,8 @@ void k_f64_stats(const F64StatArgs a)
         if (MODE == MODE_MEDMAD) {
             // the filtered samples, in order, for the DTW feed
             double *crow = a.comp + o0;
-            if (n == M) {                               // nothing dropped: a plain copy
-                double *pc = crow + lane;
-#pragma unroll
-                for (int j = 0; j < NJ; j++) {
-                    int rem = M - 64 * j;
-                    asm("" : "+s"(rem));
-                    if (lane < rem) pc[64 * j] = x[j];
-                }
+            if (n == M) {                               // nothing dropped: the DTW feed reads the input itself
+                pr.flags |= SK_IFLAG_INPLACE;
             } else {
                 int base = 0;
 #pragma unroll

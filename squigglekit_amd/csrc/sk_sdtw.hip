@@ -77,13 +77,13 @@ void k_sdtw(const sdtw_kargs a)
     const double  *s64 = nullptr;
     if constexpr (FEED == SK_FEED_I16) {
         const sk_prep pr = a.prep[r];
-        n = pr.n; flags = pr.flags; center = pr.center; scale = pr.scale;
+        n = pr.n; flags = pr.flags & SK_FLAG_PUBLIC; center = pr.center; scale = pr.scale;
         s16 = (const int16_t *)a.samples + (int64_t)r * a.stride;
     } else if constexpr (FEED == SK_FEED_F64_NORM) {
         const sk_prep pr = a.prep[r];
-        n = pr.n; flags = pr.flags; center = pr.center; scale = pr.scale;
+        n = pr.n; flags = pr.flags & SK_FLAG_PUBLIC; center = pr.center; scale = pr.scale;
         rc1 = pr.top; rc2 = pr.bot;                 // zscale re-centring terms (0.0 unless sklearn applied them)
-        s64 = (const double *)a.samples + a.off[r];
+        s64 = (const double *)(((pr.flags & SK_IFLAG_INPLACE) && a.samples_raw) ? a.samples_raw : a.samples) + a.off[r];
     } else {
         n = (int)(a.off[r + 1] - a.off[r]);
         if (n == 0) flags = SK_FLAG_EMPTY;
@@ -391,7 +391,7 @@ static int launch_chained(sk_ctx *c, const sk_sdtw_args *a)
                         (int32_t *)(bufD[1] + (size_t)batch * row_stride) + (size_t)batch * row_stride};
     sdtw_kargs k;
     memset(&k, 0, sizeof k);
-    k.samples = a->samples; k.stride = a->stride; k.off = a->off; k.prep = a->prep;
+    k.samples = a->samples; k.samples_raw = a->samples_raw; k.stride = a->stride; k.off = a->off; k.prep = a->prep;
     k.out = a->out; k.last_row = nullptr; k.row_stride = row_stride;
     c->last_retry = 0;
     c->retry_dev = false;
@@ -497,7 +497,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
 
     sdtw_kargs k;
     memset(&k, 0, sizeof k);
-    k.samples = a->samples; k.stride = a->stride; k.off = a->off; k.prep = a->prep;
+    k.samples = a->samples; k.samples_raw = a->samples_raw; k.stride = a->stride; k.off = a->off; k.prep = a->prep;
     k.nreads = a->nreads; k.read0 = 0; k.ridx = nullptr; k.xlay = (const double *)c->motif.p; k.P = P;
     k.out = a->out; k.last_row = a->last_row;
 

@@ -46,6 +46,7 @@ __device__ __forceinline__ double vmin(double a, double b)
 
 struct sdtw_kargs {
     const void    *samples;     // int16 or double samples (filtered)
+    const void    *samples_raw; // float64 feeds: unfiltered input, read for reads flagged SK_IFLAG_INPLACE (or nullptr)
     int64_t        stride;      // row stride for FEED_I16
     const int64_t *off;         // ragged offsets for the f64 feeds
     const sk_prep *prep;        // n / center / scale per read (not for F64_RAW)

@@ -209,7 +209,7 @@ void k_sdtw_q(const sdtw_kargs a)
     } else if constexpr (FEED == SK_FEED_F64_NORM) {
         const sk_prep pr = a.prep[r];
         n = pr.n; center = pr.center; scale = pr.scale;
-        s64 = (const double *)a.samples + a.off[r];
+        s64 = (const double *)(((pr.flags & SK_IFLAG_INPLACE) && a.samples_raw) ? a.samples_raw : a.samples) + a.off[r];
     } else {
         n = (int)(a.off[r + 1] - a.off[r]);
         s64 = (const double *)a.samples + a.off[r];
@@ -400,7 +400,7 @@ void k_sdtw_p(const sdtw_kargs a)
     } else if constexpr (FEED == SK_FEED_F64_NORM) {
         const sk_prep pr = a.prep[r];
         n = pr.n; center = pr.center; scale = pr.scale;
-        s64 = (const double *)a.samples + a.off[r];
+        s64 = (const double *)(((pr.flags & SK_IFLAG_INPLACE) && a.samples_raw) ? a.samples_raw : a.samples) + a.off[r];
     } else {
         n = (int)(a.off[r + 1] - a.off[r]);
         s64 = (const double *)a.samples + a.off[r];
@@ -555,12 +555,12 @@ void k_sdtw_w(const sdtw_kargs a)
     const double  *s64 = nullptr;
     if constexpr (FEED == SK_FEED_I16) {
         const sk_prep pr = a.prep[r];
-        n = pr.n; flags = pr.flags; center = pr.center; scale = pr.scale;
+        n = pr.n; flags = pr.flags & SK_FLAG_PUBLIC; center = pr.center; scale = pr.scale;
         s16 = (const int16_t *)a.samples + (int64_t)r * a.stride;
     } else if constexpr (FEED == SK_FEED_F64_NORM) {
         const sk_prep pr = a.prep[r];
-        n = pr.n; flags = pr.flags; center = pr.center; scale = pr.scale;
-        s64 = (const double *)a.samples + a.off[r];
+        n = pr.n; flags = pr.flags & SK_FLAG_PUBLIC; center = pr.center; scale = pr.scale;
+        s64 = (const double *)(((pr.flags & SK_IFLAG_INPLACE) && a.samples_raw) ? a.samples_raw : a.samples) + a.off[r];
     } else {
         n = (int)(a.off[r + 1] - a.off[r]);
         if (n == 0) flags = SK_FLAG_EMPTY;
@@ -957,7 +957,7 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
 
     sdtw_kargs k;
     memset(&k, 0, sizeof k);
-    k.samples = a->samples; k.stride = a->stride; k.off = a->off; k.prep = a->prep;
+    k.samples = a->samples; k.samples_raw = a->samples_raw; k.stride = a->stride; k.off = a->off; k.prep = a->prep;
     k.xlay = (const double *)c->motifw.p; k.xlayq = (const unsigned *)c->motifq.p; k.P = P; k.out = a->out;
     k.nck = nck; k.ck = ck; k.span = span; k.retry = d_retry; k.retry_cnt = d_retry_cnt;
     k.ckq = (unsigned *)c->ckpt.p; k.lastq = (unsigned *)c->lastq.p; k.lq_stride = (int64_t)lq_stride;
