@@ -208,6 +208,13 @@ int sk_dtw_subsequence_batch(const double *x, int32_t nx, const double *y, const
 int sk_dtw_subsequence(const double *x, int32_t nx, const double *y, int32_t ny,
                        double *dist, int32_t *start, int32_t *end, double *cost_last_row);
 
+/* The same call in mlpy's own C arithmetic for inputs that hold inf / nan -- `min3` as "a; if (b < m) m = b; if (c < m)
+ * m = c", fabs, np.argmin's first-NaN rule, the back-trace of subsequence_path, all evaluated literally by one GPU lane
+ * over the full cost matrix.  medmad of a read whose MAD is 0 divides by zero (MotifSeq.py:196-199) and the reference
+ * prints whatever mlpy makes of the result; `MotifSeq.py --strict-compat` prints the same row through this entry. */
+int sk_dtw_subsequence_cref(const double *x, int32_t nx, const double *y, int32_t ny,
+                            double *dist, int32_t *start, int32_t *end);
+
 /* Normalised signal of one read exactly as the reference hands it to
  * dtw_subsequence (used by MotifSeq -x/--sig_extract, MotifSeq.py:446-447).
  * out must hold len doubles; *n_out receives the filtered length. */

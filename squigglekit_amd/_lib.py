@@ -128,6 +128,7 @@ ABI = {
                                       C.c_int32, C.c_int32, _vp]),
     "sk_dtw_subsequence_batch": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, _vp]),
     "sk_dtw_subsequence": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _dp, _i32p, _i32p, _vp]),
+    "sk_dtw_subsequence_cref": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _dp, _i32p, _i32p]),
     "sk_normalise_i16": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _i32p]),
     "sk_normalise_f64": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _i32p]),
     "sk_tsv_count_lines": (C.c_int64, [_vp, C.c_size_t]),

@@ -490,6 +490,17 @@ def dtw_subsequence(x, y, last_row=False):
     return dist.value, (LastRowCost(row, x.size) if last_row else None), path
 
 
+def dtw_subsequence_cref(x, y):
+    """mlpy.dtw_subsequence(x, y) -> (dist, start, end) in the reference's own C arithmetic for inputs that hold inf / nan
+    (medmad of a read whose MAD is 0): one GPU lane, full cost matrix (sk_dtw_subsequence_cref)."""
+    L = _lib.ensure_init()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    dist, s, e = C.c_double(), C.c_int32(), C.c_int32()
+    check(L.sk_dtw_subsequence_cref(ptr(x), x.size, ptr(y), y.size, C.byref(dist), C.byref(s), C.byref(e)))
+    return dist.value, s.value, e.value
+
+
 def dtw_subsequence_batch(x, ys):
     """dtw_subsequence(x, y) for a list of already-normalised float64 signals."""
     L = _lib.ensure_init()

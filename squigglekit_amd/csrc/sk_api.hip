@@ -57,6 +57,53 @@ __global__ void k_normalise_f64(const double *__restrict__ comp, const sk_prep *
         out[i] = ((comp[i] - pr.center) - pr.top) / pr.scale - pr.bot;   // top / bot: sklearn's re-centring, 0 unless applied
 }
 
+// mlpy 3.5.0's subsequence() / subsequence_path() arithmetic restated LITERALLY, for inputs that hold inf / nan (medmad
+// of a read whose MAD is 0, MotifSeq.py:196-199): `min3` is "m = a; if (b < m) m = b; if (c < m) m = c" and every
+// comparison with a NaN is false, exactly as the C code behaves; np.argmin returns the first NaN.  The systolic kernels
+// use v_min_f64, which drops NaNs -- they are never given such input (SK_FLAG_DEGENERATE).  One lane walks the whole
+// matrix: this runs for the handful of degenerate reads `MotifSeq.py --strict-compat` prints.
+__device__ __forceinline__ double cref_min3(double a, double b, double c)
+{
+    double m = a;
+    if (b < m) m = b;
+    if (c < m) m = c;
+    return m;
+}
+
+__global__ void k_dtw_cref(const double *__restrict__ x, int n, const double *__restrict__ y, int m,
+                           double *__restrict__ cost, sk_hit *__restrict__ out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    cost[0] = fabs(x[0] - y[0]);
+    for (int i = 1; i < n; i++) cost[(size_t)i * m] = fabs(x[i] - y[0]) + cost[(size_t)(i - 1) * m];
+    for (int j = 1; j < m; j++) cost[j] = fabs(x[0] - y[j]);                       // free start
+    for (int i = 1; i < n; i++) {
+        const double *up = cost + (size_t)(i - 1) * m;
+        double *row = cost + (size_t)i * m;
+        for (int j = 1; j < m; j++) row[j] = fabs(x[i] - y[j]) + cref_min3(up[j], up[j - 1], row[j - 1]);
+    }
+    const double *last = cost + (size_t)(n - 1) * m;
+    int idx = 0;                                                                    // np.argmin: first NaN, else first minimum
+    double best = last[0];
+    if (!(best != best))
+        for (int j = 1; j < m; j++) {
+            if (last[j] != last[j]) { idx = j; break; }
+            if (last[j] < best) { best = last[j]; idx = j; }
+        }
+    int i = n - 1, j = idx;                                                         // subsequence_path: while i > 0
+    while (i > 0) {
+        if (j == 0) { i--; continue; }
+        const double up = cost[(size_t)(i - 1) * m + j], dg = cost[(size_t)(i - 1) * m + j - 1], lf = cost[(size_t)i * m + j - 1];
+        const double mc = cref_min3(up, dg, lf);
+        if (dg == mc)      { i--; j--; }
+        else if (lf == mc) { j--; }
+        else               { i--; }
+    }
+    sk_hit h;
+    h.dist = last[idx]; h.start = j; h.end = idx; h.n = m; h.flags = 0;
+    out[0] = h;
+}
+
 // The host entry points move a large batch in sub-batches: the H2D copy of sub-batch k + 1 (second stream) runs
 // under the kernels of sub-batch k.  Pageable caller memory: hipMemcpyAsync stages it and returns, the kernels
 // launched before keep running meanwhile.  Memory from sk_host_alloc() (pinned): plain DMA at PCIe speed.
@@ -943,6 +990,35 @@ int sk_last_f64_retries(void)
     SK_HIP(hipStreamSynchronize(c->stream));
     SK_HIP(hipMemcpy(&n, c->retry.p, sizeof n, hipMemcpyDeviceToHost));
     return n;
+}
+
+// mlpy.dtw_subsequence(x, y) in the reference's own C arithmetic, NaN / inf included (k_dtw_cref above): what
+// `MotifSeq.py --strict-compat` prints for reads whose MAD is 0.  Full cost matrix in device memory, one lane.
+int sk_dtw_subsequence_cref(const double *x, int32_t nx, const double *y, int32_t ny,
+                            double *dist, int32_t *start, int32_t *end)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (!x || !y || nx <= 0 || ny <= 0) return sk_fail(SK_ERR_INVALID, "empty x or y");
+    const size_t cells = (size_t)nx * (size_t)ny;
+    if (cells > ((size_t)1 << 28)) return sk_fail(SK_ERR_UNSUPPORTED, "%d x %d cost matrix is over 2 GB", nx, ny);
+    int rc;
+    if ((rc = sk_reserve(c, &c->sig, ((size_t)nx + (size_t)ny) * sizeof(double)))) return rc;
+    if ((rc = sk_reserve(c, &c->misc, cells * sizeof(double)))) return rc;
+    if ((rc = sk_reserve(c, &c->out, sizeof(sk_hit)))) return rc;
+    double *d_x = (double *)c->sig.p, *d_y = d_x + nx;
+    SK_HIP(hipMemcpyAsync(d_x, x, (size_t)nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipMemcpyAsync(d_y, y, (size_t)ny * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_dtw_cref, dim3(1), dim3(64), 0, c->stream, (const double *)d_x, nx, (const double *)d_y, ny,
+                       (double *)c->misc.p, (sk_hit *)c->out.p);
+    SK_HIP(hipGetLastError());
+    sk_hit h;
+    SK_HIP(hipMemcpyAsync(&h, c->out.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    if (dist) *dist = h.dist;
+    if (start) *start = h.start;
+    if (end) *end = h.end;
+    return SK_OK;
 }
 
 } // extern "C"

@@ -159,11 +159,19 @@ class _Batcher:
             if h["flags"] & 1:
                 sys.stderr.write("MotifSeq: no sample of {} survived the outlier limits; skipped\n".format(read_id))
                 break
-            if h["flags"] & 2:                                      # SK_FLAG_DEGENERATE
+            if h["flags"] & 2 and not a.strict_compat:              # SK_FLAG_DEGENERATE
                 sys.stderr.write("MotifSeq: the MAD of {} is 0 (medmad divides by it, MotifSeq.py:196-199); "
-                                 "skipped\n".format(read_id))
+                                 "skipped (--strict-compat prints the reference's nan row)\n".format(read_id))
                 break
-            dist, start, end = float(h["dist"]), int(h["start"]), int(h["end"])
+            if h["flags"] & 2:
+                # the reference divides by zero and hands inf / nan to mlpy: the same division, then mlpy's C arithmetic
+                # evaluated literally on the GPU (sk_dtw_subsequence_cref) -- a nan distance at the first sample that
+                # equals the median
+                if norm is None:
+                    norm = api.normalise(sig, a.scale, a.scale_low, a.scale_hi)
+                dist, start, end = api.dtw_subsequence_cref(np.asarray(self.models[name], dtype=np.float64), norm)
+            else:
+                dist, start, end = float(h["dist"]), int(h["start"]), int(h["end"])
             mod_mean = (a.slope * self.lens[c]) + a.intercept
             mod_stdev = mod_mean * a.std_const
             z = (dist - mod_mean) / mod_stdev
@@ -261,7 +269,7 @@ class _Batcher:
             return
         for i in range(len(nsamp)):
             self.emit(name_of(i), id_of(i), [hits[c][i] for c in range(len(self.order))],
-                      rows[i, :nsamp[i]] if self.args.sig_extract else None, None)
+                      rows[i, :nsamp[i]] if (self.args.sig_extract or self.args.strict_compat) else None, None)
 
     def block(self, blk):
         """A parsed TSV chunk (tsvio.TsvBlock): its integer lines go to the GPU as ONE int16 batch straight from the
@@ -304,7 +312,7 @@ class _Batcher:
             k = res.get(i)
             if k is not None:
                 if a.sig_extract or any(cols[c][0][k] & 3 for c in range(len(self.order))):
-                    sig = blk.rows[i, :blk.nsamp[i]] if a.sig_extract else None      # the general route: -x, flagged reads
+                    sig = blk.rows[i, :blk.nsamp[i]] if (a.sig_extract or a.strict_compat) else None   # the general route: -x, flagged reads
                     self.emit(blk.name(i), blk.read_id(i), [hits[c][k] for c in range(len(self.order))], sig, None)
                     continue
                 fast5, read_id = blk.name(i), blk.read_id(i)

@@ -111,7 +111,10 @@ def oracle_backend(monkeypatch, ora):
         for i, r in enumerate(reads):
             y = norm(r, scale, lo, hi)
             out[i]["n"] = y.size
-            if y.size:
+            if y.size and not np.all(np.isfinite(y)):
+                out[i]["flags"] = 2                                     # MAD = 0: flagged, as the library does
+                out[i]["dist"], out[i]["start"], out[i]["end"] = np.nan, -1, -1
+            elif y.size:
                 out[i]["dist"], out[i]["start"], out[i]["end"] = ora.dtw_subsequence(motif, y)
             else:
                 out[i]["flags"] = 1
@@ -141,6 +144,7 @@ def oracle_backend(monkeypatch, ora):
                         lambda reads, motifs, scale="medmad", lo=0, hi=1200: [mot_any(reads, m, scale, lo, hi)
                                                                                for m in motifs])
     monkeypatch.setattr(api, "normalise", norm)
+    monkeypatch.setattr(api, "dtw_subsequence_cref", lambda x, y: ora.dtw_subsequence(x, y))
     monkeypatch.setattr(_lib, "init", lambda device=None: 0)
 
 
@@ -393,3 +397,45 @@ def test_blow5_errors_are_messages_not_tracebacks(oracle_backend, tmp_path):
             assert "Traceback" not in err and "%s: --blow5:" % tool in err, (path.name, argv, err[-300:])
     out, err, code = run_cli(smain, ["--blow5", str(good), "--raw_signal"])
     assert code == 0 and "--blow5:" not in err
+
+
+def _degenerate_case(tmp_path):
+    gold = load_golden("motifseq_degenerate.json")
+    path = tmp_path / "deg.tsv"
+    with open(path, "w") as fh:
+        for k in gold["order"]:
+            fh.write("\t".join([k + ".fast5", "id_" + k] + ["c%d" % i for i in range(6)] +
+                               [str(v) for v in gold["reads"][k]]) + "\n")
+    return gold, str(path), os.path.join(GOLD, "CATCTATCCAGGGTTAAATT.fa")
+
+
+def _check_degenerate(tmp_path):
+    """MAD = 0 reads (MotifSeq.py:196-199 divides by zero): --strict-compat prints the rows the reference prints (minted
+    by tools/gen_golden_degenerate.py running the reference: nan distance at the first sample that equals the median);
+    the default reports those reads on stderr and prints the others unchanged."""
+    from squigglekit_amd.motifseq_cli import main as mmain
+    gold, tsv, fa = _degenerate_case(tmp_path)
+    for run in gold["runs"]:
+        out, err, code = run_cli(mmain, ["-s", tsv, "-i", fa, "--strict-compat"] + run["flags"])
+        assert code == 0 and out == run["stdout"], (run["flags"], out[-400:], err[-300:])
+        assert "nan" in out
+    out, err, code = run_cli(mmain, ["-s", tsv, "-i", fa])
+    want = [ln for ln in gold["runs"][0]["stdout"].splitlines() if "\tnan\t" not in ln]
+    assert code == 0 and out.splitlines() == want and err.count("MAD of") == 3
+
+
+def test_motifseq_strict_compat_degenerate_rows_cpu(oracle_backend, scrappy_stub, tmp_path):
+    _check_degenerate(tmp_path)
+
+
+@pytest.mark.gpu
+def test_motifseq_strict_compat_degenerate_rows_gpu(gpu, scrappy_stub, tmp_path):
+    """... and through the real backend: the division on the GPU (sk_normalise_*), mlpy's C arithmetic evaluated
+    literally by k_dtw_cref (sk_dtw_subsequence_cref)."""
+    _check_degenerate(tmp_path)
+    # the literal kernel agrees with the systolic ones wherever both apply (finite input)
+    from squigglekit_amd import api, synth
+    x = synth.synthetic_motif(37, seed=3)
+    y = api.normalise(synth.squiggle_batch(1, 700, 5)[0])
+    d, cost, path = api.dtw_subsequence(x, y)
+    assert api.dtw_subsequence_cref(x, y) == (d, int(path[1][0]), int(path[1][-1]))
