@@ -639,6 +639,7 @@ def other_paths_block(a, L, main):
         sp = SegParams()
         secs, ev = best_of(lambda: check(L.sk_segment_dev_f64(d_pa, d_off, Rf, total, Mf, C.byref(sp), d_segs, d_nsegs,
                                                               MAX_SEGS)))
+        retried = L.sk_last_f64_retries()
         rows = strided_rows(Rf, 512)
         pa = download_rows(L, d_pa, Mf * 8, rows, np.float64, Mf)
         segs = np.empty((Rf, MAX_SEGS, 2), dtype=np.int32)
@@ -657,12 +658,51 @@ def other_paths_block(a, L, main):
         out["segmenter_f64_pA"] = {
             "workload": "%d reads x %d float64 pA samples (2 decimals), default flags" % (Rf, Mf),
             "value": Rf / secs, "unit": "reads/s", "ms_per_step": secs * 1e3,
-            "kernel_ms": {"statistics": ev[0], "walk": ev[1]},
+            "kernel_ms": {"statistics": ev[0], "walk": ev[1]}, "reads_redone_in_numpy_order": int(retried),
             "roofline": {"bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
                          "statistics_kernel_frac": (alg / (ev[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ev[0] > 0 else None},
             "parity": {"reads_checked": int(len(rows)), "segments_bit_exact": bool(ok),
                        "segments_in_sample": int(nsegs[rows].sum())}}
+
+        # ---------------- the same on long reads (C5-shaped: 20 000 samples): the window-by-window float64 kernel -------
+        RL, ML = 50_000, 20_000
+        d_raw_l = alloc(RL * ML * 2)
+        check(L.sk_synth_squiggles_dev(d_raw_l, ML, RL, ML, synth.SEED_C5, None, 0))
+        MLf = ML - 1
+        d_pa_l, d_off_l = alloc(RL * MLf * 8), alloc((RL + 1) * 8)
+        check(L.sk_synth_pa_dev(d_raw_l, ML, RL, MLf, PA_OFFSET, PA_RANGE, PA_DIGITISATION, d_pa_l, d_off_l))
+        MAXS_L = 64
+        d_segs_l, d_nsegs_l = alloc(RL * MAXS_L * 2 * 4), alloc(RL * 4)
+        secs, ev = best_of(lambda: check(L.sk_segment_dev_f64(d_pa_l, d_off_l, RL, RL * MLf, MLf, C.byref(sp), d_segs_l,
+                                                              d_nsegs_l, MAXS_L)))
+        retried_l = int(L.sk_last_f64_retries())
+        rows_l = strided_rows(RL, 128)
+        pa_l = download_rows(L, d_pa_l, MLf * 8, rows_l, np.float64, MLf)
+        segs_l = np.empty((RL, MAXS_L, 2), dtype=np.int32)
+        nsegs_l = np.empty(RL, dtype=np.int32)
+        check(L.sk_dev_download(ptr(segs_l), d_segs_l, segs_l.nbytes))
+        check(L.sk_dev_download(ptr(nsegs_l), d_nsegs_l, nsegs_l.nbytes))
+
+        def seg_ok_l(k):
+            want = ora.get_segs(ora.scale_outliers(pa_l[k], sp.lim_low, sp.lim_hi), op) or []
+            r = rows_l[k]
+            return nsegs_l[r] == len(want) and segs_l[r, :nsegs_l[r]].tolist() == want
+        with ThreadPoolExecutor(T) as ex:
+            ok_l = all(ex.map(seg_ok_l, range(len(rows_l))))
+        alg = RL * (8 * MLf + 4 + 16)
+        out["segmenter_f64_pA_20k"] = {
+            "workload": "%d reads x %d float64 pA samples (2 decimals), default flags" % (RL, MLf),
+            "value": RL / secs, "unit": "reads/s", "ms_per_step": secs * 1e3,
+            "kernel_ms": {"statistics": ev[0], "walk": ev[1]}, "reads_redone_in_numpy_order": retried_l,
+            "roofline": {"bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
+                         "note": "window-by-window kernel (k_f64_long): the read is looked at four times"},
+            "parity": {"reads_checked": int(len(rows_l)), "segments_bit_exact": bool(ok_l),
+                       "segments_in_sample": int(nsegs_l[rows_l].sum())}}
+        for q in (d_raw_l, d_pa_l, d_off_l, d_segs_l, d_nsegs_l):
+            L.sk_dev_free(q)
+            bufs.remove(q)
 
         d_hits = alloc(max(Rf, main.R) * HIT_BYTES * 4)
 

@@ -380,11 +380,386 @@ void k_f64_stats(const F64StatArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Reads longer than 4 096 samples (real reads are tens of thousands of samples long): the same algorithm, one wavefront
+// per read, but the read no longer fits the registers -- it is looked at several times, window by window (2 048 samples),
+// each look re-reading it (L2 / Infinity Cache / HBM):
+//   look A   filter, n, extremes, shifted sums
+//   look B   histogram over [min, max]            look C   members of the selected bin (+ their extremes)
+//            -- repeated on the members' own range while the bin holds more than 512 values that are not all equal;
+//               up to 512 members are resolved in LDS (re-histogrammed there until at most 64 are left, then ranked)
+//   segmenter: look D   classification, the {in band, kept} entries of each window stored as it goes
+//   MotifSeq:  looks B', C' for the MAD; the filtered samples are copied (one more look) only when the filter dropped some
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int LNJ = 32;                 // 64-sample slots per window
+constexpr int LWIN = 64 * LNJ;
+constexpr int CAPL = 512;               // members resolved in LDS
+
+template <int MODE>
+__global__ __launch_bounds__(64 * WPB, 3)
+void k_f64_long(const F64StatArgs a)
+{
+    __shared__ __align__(16) unsigned hist_all[WPB][NB + 64];
+    __shared__ __align__(16) double list_all[WPB][CAPL];
+    __shared__ unsigned cnt_all[WPB][2];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned *hist = hist_all[w];
+    double *list = list_all[w];
+    unsigned *cnt = cnt_all[w];
+    const double INF = __builtin_huge_val();
+
+    auto clear_hist = [&]() {
+#pragma unroll
+        for (int q = 0; q < PER / 4; q++) *(uint4 *)(hist + lane * PER + 4 * q) = make_uint4(0u, 0u, 0u, 0u);
+        hist[NB + lane] = 0u;
+    };
+    clear_hist();
+
+    // exact ranks j1 (and j1 + 1 when two_ranks) among list[0 .. c), c <= CAPL, not all equal: re-histogram in LDS until
+    // at most 64 are left, then rank them one per lane
+    auto list_select = [&](int c, int j1, bool two_ranks, double &v1, double &v2) __attribute__((always_inline)) -> bool {
+        for (int it = 0; it < 10; it++) {
+            if (c <= 64) {
+                const double m = (lane < c) ? list[lane] : INF;
+                int rk = 0;
+                for (int k = 0; k < c; k++) {
+                    const double mk = list[k];
+                    rk += (mk < m || (mk == m && k < lane)) ? 1 : 0;
+                }
+                const unsigned long long h1 = __ballot(lane < c && rk == j1);
+                if (h1 == 0ull) return false;
+                v1 = readlane64(m, (int)__builtin_ctzll(h1));
+                v2 = v1;
+                if (two_ranks) {
+                    const unsigned long long h2 = __ballot(lane < c && rk == j1 + 1);
+                    if (h2 == 0ull) return false;
+                    v2 = readlane64(m, (int)__builtin_ctzll(h2));
+                }
+                return true;
+            }
+            double e[CAPL / 64];                                  // my entries: list[lane + 64 k]
+            double lmn = INF, lmx = -INF;
+#pragma unroll
+            for (int k = 0; k < CAPL / 64; k++) {
+                e[k] = (lane + 64 * k < c) ? list[lane + 64 * k] : INF;
+                if (lane + 64 * k < c) { lmn = vmin64(lmn, e[k]); lmx = vmax64(lmx, e[k]); }
+            }
+            lmn = readlane64(wave_min64(lmn), 0);
+            lmx = readlane64(wave_max64(lmx), 0);
+            if (lmn == lmx) { v1 = v2 = lmn; return true; }
+            const double sc = ((double)NB - 0.5) / (lmx - lmn);
+            if (!(sc > 0.0 && sc < 1e300)) return false;
+#pragma unroll
+            for (int k = 0; k < CAPL / 64; k++)
+                if (lane + 64 * k < c) atomicAdd(&hist[(unsigned)((e[k] - lmn) * sc)], 1u);
+            RankSel r1, r2;
+            rank_select2(hist, lane, j1, two_ranks ? j1 + 1 : j1, r1, r2);
+            clear_hist();
+            if (lane == 0) cnt[0] = 0u;
+            if (r1.b < 0 || r2.b < 0) return false;
+            const bool two = r2.b != r1.b;
+            double m2 = INF;
+#pragma unroll
+            for (int k = 0; k < CAPL / 64; k++) {
+                if (lane + 64 * k < c) {
+                    const unsigned b = (unsigned)((e[k] - lmn) * sc);
+                    if (b == (unsigned)r1.b) list[atomicAdd(&cnt[0], 1u)] = e[k];      // (every read of the old list is done)
+                    if (two && b == (unsigned)r2.b) m2 = vmin64(m2, e[k]);
+                }
+            }
+            if (two) {                                            // rank j1 + 1 is the first value of the next occupied bin
+                m2 = readlane64(wave_min64(m2), 0);
+                double dummy;
+                const bool ok1 = r1.c <= c;
+                c = r1.c; j1 -= r1.pre;
+                if (!ok1) return false;
+                // resolve rank j1 alone, then attach m2
+                two_ranks = false;
+                double t1 = 0.0;
+                // (tail call by iteration: fall through with the narrowed list)
+                bool done = false;
+                for (int it2 = it + 1; it2 < 10 && !done; it2++) {
+                    if (c <= 64) {
+                        const double m = (lane < c) ? list[lane] : INF;
+                        int rk = 0;
+                        for (int k = 0; k < c; k++) {
+                            const double mk = list[k];
+                            rk += (mk < m || (mk == m && k < lane)) ? 1 : 0;
+                        }
+                        const unsigned long long h1 = __ballot(lane < c && rk == j1);
+                        if (h1 == 0ull) return false;
+                        t1 = readlane64(m, (int)__builtin_ctzll(h1));
+                        done = true;
+                    } else {
+                        // still more than 64 equal-bin members: they are the largest of the bin... take the exact path again
+                        double e2[CAPL / 64];
+                        double qmn = INF, qmx = -INF;
+#pragma unroll
+                        for (int k = 0; k < CAPL / 64; k++) {
+                            e2[k] = (lane + 64 * k < c) ? list[lane + 64 * k] : INF;
+                            if (lane + 64 * k < c) { qmn = vmin64(qmn, e2[k]); qmx = vmax64(qmx, e2[k]); }
+                        }
+                        qmn = readlane64(wave_min64(qmn), 0);
+                        qmx = readlane64(wave_max64(qmx), 0);
+                        if (qmn == qmx) { t1 = qmn; done = true; break; }
+                        const double sc2 = ((double)NB - 0.5) / (qmx - qmn);
+                        if (!(sc2 > 0.0 && sc2 < 1e300)) return false;
+#pragma unroll
+                        for (int k = 0; k < CAPL / 64; k++)
+                            if (lane + 64 * k < c) atomicAdd(&hist[(unsigned)((e2[k] - qmn) * sc2)], 1u);
+                        RankSel q1, q2;
+                        rank_select2(hist, lane, j1, j1, q1, q2);
+                        clear_hist();
+                        if (lane == 0) cnt[0] = 0u;
+                        if (q1.b < 0) return false;
+#pragma unroll
+                        for (int k = 0; k < CAPL / 64; k++)
+                            if (lane + 64 * k < c && (unsigned)((e2[k] - qmn) * sc2) == (unsigned)q1.b)
+                                list[atomicAdd(&cnt[0], 1u)] = e2[k];
+                        c = q1.c; j1 -= q1.pre;
+                    }
+                }
+                (void)dummy;
+                if (!done) return false;
+                v1 = t1; v2 = m2;
+                return true;
+            }
+            c = r1.c; j1 -= r1.pre;
+        }
+        return false;
+    };
+
+    const int nwaves = gridDim.x * WPB;
+    for (int r = blockIdx.x * WPB + w; r < a.nreads; r += nwaves) {
+        const int64_t o0 = a.off[r];
+        const int M = __builtin_amdgcn_readfirstlane((int)min(max(a.off[r + 1] - o0, (int64_t)0), (int64_t)0x3fffffff));
+        const double *row = a.sig + o0;
+        const int nwin = (M + LWIN - 1) / LWIN;
+
+        double x[LNJ];
+        unsigned kplo = 0u, kphi = 0u;                  // lane j: the kept word of slot j of the CURRENT window
+        int Mw = 0, nkw = 0;                            // samples / kept samples of the current window
+        // one window into registers, filtered: dropped samples and slots past the end become +inf
+        auto load_window = [&](int wi) __attribute__((always_inline)) {
+            Mw = __builtin_amdgcn_readfirstlane(min(M - wi * LWIN, LWIN));
+            const double *prow = row + (int64_t)wi * LWIN + lane;
+#pragma unroll
+            for (int j = 0; j < LNJ; j++) {
+                const int rem = __builtin_amdgcn_readfirstlane(Mw - 64 * j);   // (scalar and opaque: see k_f64_stats)
+                x[j] = (lane < rem) ? prow[64 * j] : INF;
+            }
+            nkw = 0;
+#pragma unroll
+            for (int j = 0; j < LNJ; j++) {
+                if (64 * j >= Mw) {                     // (wave-uniform)
+                    kplo = (unsigned)sk_writelane_i32(0, j, (int)kplo);
+                    kphi = (unsigned)sk_writelane_i32(0, j, (int)kphi);
+                    continue;
+                }
+                const bool k = x[j] > a.lo && x[j] < a.hi;
+                const unsigned long long km = __ballot(k);
+                kplo = (unsigned)sk_writelane_i32((int)(unsigned)km, j, (int)kplo);
+                kphi = (unsigned)sk_writelane_i32((int)(unsigned)(km >> 32), j, (int)kphi);
+                nkw += __popcll(km);
+                if (km != ~0ull) x[j] = k ? x[j] : INF;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        // ---- look A ---------------------------------------------------------------------------------------------
+        int n = 0;
+        double mn = INF, mx = -INF, S1 = 0.0, S2 = 0.0;
+        double K = (M > 0) ? row[0] : 0.0;              // shift of the sums (any finite value near the data)
+        if (!(K > a.lo && K < a.hi)) K = 0.5 * (a.lo + a.hi);
+        if (!(fabs(K) < 1e300)) K = 0.0;
+        for (int wi = 0; wi < nwin; wi++) {
+            load_window(wi);
+            n += nkw;
+#pragma unroll
+            for (int j = 0; j < LNJ; j++) {
+                if (64 * j >= Mw) continue;
+                if (x[j] != INF) {
+                    mn = vmin64(mn, x[j]);
+                    mx = vmax64(mx, x[j]);
+                    if (MODE == MODE_SEG) {
+                        const double d = x[j] - K;
+                        S1 += d;
+                        S2 = fma(d, d, S2);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        mn = readlane64(wave_min64(mn), 0);
+        mx = readlane64(wave_max64(mx), 0);
+        if (MODE == MODE_SEG) {
+            S1 = readlane64(wave_sum64(S1), 0);
+            S2 = readlane64(wave_sum64(S2), 0);
+        }
+
+        sk_prep pr;
+        pr.n = n; pr.flags = 0; pr.center = 0.0; pr.scale = 1.0; pr.top = 0.0; pr.bot = 0.0;
+        bool ok = true;
+
+        // exact order statistics k1 <= k2 <= k1 + 1 of val(x) over the kept samples, val in [vlo, vhi], vlo < vhi
+        auto select2 = [&](auto val, double vlo, double vhi, int k1, int k2, double &v1, double &v2) __attribute__((always_inline)) -> bool {
+            bool restricted = false;                    // later rounds: only values inside [vlo, vhi] take part
+            bool have2 = false;                         // v2 already known (k2 fell into the next occupied bin)
+            for (int round = 0; round < 6; round++) {
+                const double sc = ((double)NB - 0.5) / (vhi - vlo);
+                if (!(sc > 0.0 && sc < 1e300)) return false;
+                for (int wi = 0; wi < nwin; wi++) {     // ---- look B
+                    load_window(wi);
+#pragma unroll
+                    for (int j = 0; j < LNJ; j++) {
+                        if (64 * j >= Mw) continue;
+                        const double v = val(x[j]);
+                        bool in = x[j] != INF;
+                        if (restricted) in = in && v >= vlo && v <= vhi;
+                        const unsigned b = in ? (unsigned)((v - vlo) * sc) : (unsigned)NB;
+                        atomicAdd(&hist[b], 1u);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                RankSel r1, r2;
+                rank_select2(hist, lane, k1, have2 ? k1 : k2, r1, r2);
+                clear_hist();
+                if (lane == 0) cnt[0] = 0u;
+                if (r1.b < 0 || r2.b < 0) return false;
+                const bool two = !have2 && r2.b != r1.b;
+                double mnm = INF, mxm = -INF, mn2 = INF;
+                for (int wi = 0; wi < nwin; wi++) {     // ---- look C
+                    load_window(wi);
+#pragma unroll
+                    for (int j = 0; j < LNJ; j++) {
+                        if (64 * j >= Mw) continue;
+                        const double v = val(x[j]);
+                        bool in = x[j] != INF;
+                        if (restricted) in = in && v >= vlo && v <= vhi;
+                        const unsigned b = in ? (unsigned)((v - vlo) * sc) : (unsigned)NB;
+                        if (b == (unsigned)r1.b) {
+                            const unsigned slot = atomicAdd(&cnt[0], 1u);
+                            if (slot < (unsigned)CAPL) list[slot] = v;
+                            mnm = vmin64(mnm, v);
+                            mxm = vmax64(mxm, v);
+                        }
+                        if (two && b == (unsigned)r2.b) mn2 = vmin64(mn2, v);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                mnm = readlane64(wave_min64(mnm), 0);
+                mxm = readlane64(wave_max64(mxm), 0);
+                if (two) { v2 = readlane64(wave_min64(mn2), 0); have2 = true; }
+                const int j1 = k1 - r1.pre;
+                const bool both_here = !have2 && k2 != k1;      // k2 = k1 + 1 lies in the same bin
+                if (mnm == mxm) { v1 = mnm; if (!have2) v2 = mnm; return true; }
+                if (r1.c <= CAPL) {
+                    double t1 = 0.0, t2 = 0.0;
+                    if (!list_select(r1.c, j1, both_here, t1, t2)) return false;
+                    v1 = t1;
+                    if (!have2) v2 = t2;
+                    return true;
+                }
+                // too many distinct members: again, on the members' own range
+                vlo = mnm; vhi = mxm; restricted = true;
+                k1 = j1; k2 = both_here ? j1 + 1 : j1;
+            }
+            return false;
+        };
+
+        double median = 0.0, s_lo = 0.0, s_hi = 0.0;
+        if (n == 0) {
+            pr.flags = SK_FLAG_EMPTY;
+            const double qnan = __builtin_nan("");
+            pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
+            s_lo = -1.0; s_hi = -1.0;                   // nothing is in band
+        } else {
+            const int k1 = (n - 1) / 2, k2 = n / 2;
+            double v1 = mn, v2 = mn;
+            if (mn != mx) ok = select2([&](double v) { return v; }, mn, mx, k1, k2, v1, v2);
+            median = (k1 == k2) ? v1 : (v1 + v2) / 2.0;
+            if (MODE == MODE_MEDMAD) {
+                double w1 = 0.0, w2 = 0.0;
+                const double umax = vmax64(fabs(mn - median), fabs(mx - median));
+                if (ok && umax > 0.0)
+                    ok = select2([&](double v) { return fabs(v - median); }, 0.0, umax, k1, k2, w1, w2);
+                const double mad = (k1 == k2) ? w1 : (w1 + w2) / 2.0;
+                pr.center = median;
+                pr.scale = mad * 1.4826;
+                if (mad == 0.0) pr.flags |= SK_FLAG_DEGENERATE;
+            } else {
+                const double dn = (double)n;
+                const double md = S1 / dn, Q = S2 / dn;
+                const double var = Q - md * md;
+                const double Ev = 8.0 * (dn + 8.0) * U53 * Q;
+                const double sd = sqrt(var);
+                const double A = vmax64(fabs(mn), fabs(mx));
+                const double dstd = Ev / sd + dn * U53 * A + sd * (dn + 8.0) * U53;
+                const double spread = sd * a.std_scale;
+                const double dlt = a.delta_scale * 4.0 *
+                                   (fabs(a.std_scale) * dstd + U53 * (4.0 * fabs(spread) + fabs(median) + 2.0 * A));
+                if (!(var > 4.0 * Ev)) ok = false;
+                s_lo = spread - dlt; s_hi = spread + dlt;
+                pr.center = median; pr.scale = sd; pr.top = median + spread; pr.bot = median - spread;
+            }
+        }
+
+        if (MODE == MODE_MEDMAD) {
+            if (n == M) {
+                pr.flags |= SK_IFLAG_INPLACE;           // nothing dropped: the DTW feed reads the input itself
+            } else {
+                double *crow = a.comp + o0;             // the filtered samples, in order
+                int base = 0;
+                for (int wi = 0; wi < nwin; wi++) {
+                    load_window(wi);
+#pragma unroll
+                    for (int j = 0; j < LNJ; j++) {
+                        if (64 * j >= Mw) continue;
+                        const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)kplo, j);
+                        const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)kphi, j);
+                        const unsigned long long km = ((unsigned long long)khi << 32) | klo;
+                        const int pos = base + (int)__builtin_amdgcn_mbcnt_hi(khi, __builtin_amdgcn_mbcnt_lo(klo, 0u));
+                        if ((km >> lane) & 1ull) crow[pos] = x[j];
+                        base += __popcll(km);
+                    }
+                }
+            }
+        } else {
+            // ---- look D: in band / out of band / undecided; the window's entries go out as they are made -------------
+            unsigned long long unc = 0ull;
+            for (int wi = 0; wi < nwin; wi++) {
+                load_window(wi);
+                unsigned inlo = 0u, inhi = 0u;
+#pragma unroll
+                for (int j = 0; j < LNJ; j++) {
+                    if (64 * j >= Mw) continue;
+                    const double u = fabs(x[j] - median);
+                    const unsigned long long im = __ballot(u < s_lo);
+                    unc |= ~(im | __ballot(u > s_hi));
+                    inlo = (unsigned)sk_writelane_i32((int)(unsigned)im, j, (int)inlo);
+                    inhi = (unsigned)sk_writelane_i32((int)(unsigned)(im >> 32), j, (int)inhi);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const int nent = (Mw + 63) >> 6;
+                if (lane < nent) a.mask2[(int64_t)r * a.row16 + wi * LNJ + lane] = make_uint4(inlo, inhi, kplo, kphi);
+            }
+            if (n > 0 && unc != 0ull) ok = false;
+        }
+        if (lane == 0) {
+            a.prep[r] = pr;
+            if (MODE == MODE_SEG) a.len_out[r] = M;
+            if (!ok) a.retry[1 + atomicAdd(&a.retry[0], 1)] = r;
+        }
+    }
+}
+
 typedef void (*f64stat_fn)(const F64StatArgs);
 
 f64stat_fn pick(int mode, int64_t maxlen)
 {
     const bool seg = mode == MODE_SEG;
+    if (maxlen > 4096) return seg ? k_f64_long<MODE_SEG> : k_f64_long<MODE_MEDMAD>;
     if (maxlen <= 1024) return seg ? k_f64_stats<16, MODE_SEG, 6> : k_f64_stats<16, MODE_MEDMAD, 6>;
     if (maxlen <= 2048) return seg ? k_f64_stats<32, MODE_SEG, 4> : k_f64_stats<32, MODE_MEDMAD, 4>;
     return seg ? k_f64_stats<64, MODE_SEG, 3> : k_f64_stats<64, MODE_MEDMAD, 3>;
@@ -396,7 +771,7 @@ f64stat_fn pick(int mode, int64_t maxlen)
 bool sk_f64_fast_applies(int64_t maxlen, double std_scale)
 {
     if (sk_tune("SK_F64_OLD")) return false;                  // A/B switch: the numpy-order kernel for everything
-    if (maxlen > 4096) return false;
+    if (maxlen > (1 << 20)) return false;                    // (window-by-window kernel from 4 097 samples to 2^20)
     if (!(std_scale == std_scale) || fabs(std_scale) > 1e6) return false;
     return true;
 }

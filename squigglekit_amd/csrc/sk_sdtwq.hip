@@ -251,14 +251,19 @@ void k_sdtw_q(const sdtw_kargs a)
         else                               return s64[min(idx, nlast)];
     };
     // screening only: fma(x, 2^22 / s, -c 2^22 / s) instead of the reference's (x - c) / s -- the two differ by
-    // < 1e-6 of a fixed-point unit, covered by the slack in E (pass W divides, exactly).  Rounding to the nearest
-    // integer by adding 1.5 * 2^52: the sum's low word is the two's complement integer.
+    // < 1e-4 of a fixed-point unit for int16 samples (|c / s| < 32 768 / 0.74: the rounding of the second constant is
+    // 2e-5 units), covered by the slack in E (pass W divides, exactly).  float64 samples get (x - c) * (2^22 / s): the
+    // constant -c 2^22 / s is only good to 1e-16 of ITS size, which for a near-constant read (c / s ~ 1e14; found by the
+    // round-4 fuzz once its float64 batches were large enough to be screened) is 1e5 units -- the difference is taken
+    // first, exactly for samples near c.  Rounding to the nearest integer by adding 1.5 * 2^52: the sum's low word is
+    // the two's complement integer.
     const double qa = inv_scale * QSCALE, qb = -center * qa;
     auto toq = [&](auto raw_, int idx) -> unsigned {
         const double raw = (double)raw_;
         double t;
-        if constexpr (FEED != SK_FEED_F64_RAW) t = __builtin_fma(raw, qa, qb);
-        else                                   t = raw * QSCALE;
+        if constexpr (FEED == SK_FEED_I16)           t = __builtin_fma(raw, qa, qb);
+        else if constexpr (FEED == SK_FEED_F64_NORM) t = (raw - center) * qa;
+        else                                         t = raw * QSCALE;
         const bool ok = fabs(t) < QLIM * QSCALE;     // false for NaN / inf too
         const unsigned q = (unsigned)__double2loint(t + 6755399441055744.0) ^ 0x80000000u;
         const bool in = idx < n;

@@ -242,3 +242,93 @@ def test_f64_streaming_medmad_vs_oracle(gpu, ora, example_model):
             assert got["n"][r] == w[0] and got["flags"][r] & 2, r
         else:
             assert (got["dist"][r], got["start"][r], got["end"][r], got["n"][r]) == w, r
+
+
+def _long_reads(rng):
+    """Reads beyond 4 096 samples (the window-by-window float64 kernel): pA-like, ungridded (hundreds of distinct values
+    in the median's bin: resolved in LDS), three distinct values (more than 512 equal-bin members), an outlier-stretched
+    range, NaN inside, lengths around the 2 048-sample windows."""
+    reads = []
+    for n in (4097, 6143, 6144, 6145, 20000, 36977, 70001):
+        reads.append(np.round(rng.normal(96.0, 15.0, n), 2))
+        reads.append(rng.normal(96.0, 15.0, n))
+        reads.append(rng.choice([80.25, 95.5, 95.51], n))
+        x = np.round(rng.normal(90.0, 6.0, n), 2)
+        x[rng.integers(0, n, 3)] = [899.99, np.nan, 0.011]
+        reads.append(x)
+    reads.append(90.0 + rng.integers(0, 100000, 150001) * 2.0 ** -30)           # dense: the select recurses on the members' range
+    reads.append(np.full(9000, 77.77))
+    return reads
+
+
+def test_f64_long_reads_segmenter_vs_oracle(gpu, ora, monkeypatch):
+    from squigglekit_amd import api
+    from squigglekit_amd._lib import SegParams
+    reads = _long_reads(np.random.default_rng(311))
+    for kw in (dict(), dict(lim_low=60, lim_hi=130, window=40), dict(std_scale=0.1, window=20)):
+        p = SegParams(**kw)
+        op = ora.SegParams(p.error, p.corrector, p.window, p.seg_dist, p.std_scale, p.stall_len)
+        want = [ora.get_segs(f, op) if f.size else False
+                for f in (ora.scale_outliers(sig, p.lim_low, p.lim_hi) for sig in reads)]
+        for delta in (None, "1e13"):
+            if delta:
+                monkeypatch.setenv("SK_SEG_DELTA_SCALE", delta)
+            got = api.segment_reads_f64(reads, p)
+            retried = gpu.load().sk_last_f64_retries()
+            monkeypatch.delenv("SK_SEG_DELTA_SCALE", raising=False)
+            assert retried >= 0, "the batch did not take the streaming kernels"
+            if not delta:
+                assert retried <= 4, retried                 # (the all-equal read; nothing else should need the redo)
+            bad = [r for r in range(len(reads)) if got[r] != want[r]]
+            assert not bad, (kw, delta, bad[:8], retried)
+
+
+def test_f64_long_reads_medmad_vs_oracle(gpu, ora, example_model):
+    from concurrent.futures import ThreadPoolExecutor
+    from squigglekit_amd import api
+    reads = _long_reads(np.random.default_rng(312))[:24]
+    got = api.motifseq_reads_f64(reads, example_model, scale="medmad", scale_low=0, scale_hi=900)
+    assert 0 <= gpu.load().sk_last_f64_retries() <= 2
+
+    def one(sig):
+        f = ora.scale_outliers(sig, 0, 900)
+        y = ora.medmad(f)[0]
+        return (ora.dtw_subsequence(example_model, y) + (f.size,)) if np.all(np.isfinite(y)) else (f.size,)
+    with ThreadPoolExecutor(16) as ex:
+        want = list(ex.map(one, reads))
+    for r, w in enumerate(want):
+        if len(w) == 1:
+            assert got["n"][r] == w[0] and got["flags"][r] & 2, r
+        else:
+            assert (got["dist"][r], got["start"][r], got["end"][r], got["n"][r]) == w, r
+
+
+@pytest.mark.parametrize("scale", ["medmad", "zscale"])
+def test_f64_screening_of_near_constant_reads(gpu, ora, example_model, scale):
+    """Reads whose spread is 1e-14 of their level, enough of them for the screening scheme: the fixed-point image of a
+    sample must come from (x - centre) * (2^22 / scale) -- the constant -centre * 2^22 / scale of the int16 feed's fma
+    is only good to 1e-16 of its own size, 1e5 fixed-point units here (found by the round-4 fuzz)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from squigglekit_amd import api
+    rng = np.random.default_rng(2)
+    reads = [500.0 + rng.integers(0, 3, int(rng.integers(1500, 2600))) * 2.0 ** -40 for _ in range(150)]
+    reads += [90.0 + rng.integers(0, 2000, int(rng.integers(1500, 2600))) * 2.0 ** -44 for _ in range(150)]
+    got = api.motifseq_reads_f64(reads, example_model, scale=scale)
+    launches = C.c_int32()
+    gpu.load().sk_last_dtw_profile(None, C.byref(launches), None, None, None)
+    assert launches.value >= 1, "the batch did not take the screening scheme"
+
+    def one(sig):
+        f = ora.scale_outliers(sig, 0, 1200)
+        y = ora.medmad(f)[0] if scale == "medmad" else ora.zscale(f)[0]
+        return (ora.dtw_subsequence(example_model, y) + (f.size,)) if np.all(np.isfinite(y)) else None
+    with ThreadPoolExecutor(16) as ex:
+        want = list(ex.map(one, reads))
+    checked = 0
+    for r, w in enumerate(want):
+        if w is None:
+            assert got["flags"][r] & 2
+        else:
+            checked += 1
+            assert (got["dist"][r], got["start"][r], got["end"][r], got["n"][r]) == w, (scale, r)
+    assert checked >= 150

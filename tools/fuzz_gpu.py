@@ -5,10 +5,13 @@ lengths, strides, motif lengths, outlier limits, both scalings, segmenter parame
     python tools/fuzz_gpu.py [seconds=120] [seed=1]
 
 Prints one line per mismatch and exits non-zero if there was any.  (Test infrastructure.)"""
+import os
 import sys
 import time
 
 import numpy as np
+
+os.environ["SK_TUNING"] = "1"      # this tool flips tuning switches
 
 sys.path.insert(0, ".")
 from squigglekit_amd import api, synth               # noqa: E402
@@ -43,7 +46,6 @@ def main():
         # the lanes-per-read layout of the screening scheme (8 is what large batches get by themselves: these batches
         # are small, so it is asked for), the fused / separate filter + statistics, the early / late exact retry
         import os
-os.environ["SK_TUNING"] = "1"      # this tool flips tuning switches
         ql = [None, "8", "16", "64"][int(rng.integers(4))]
         for key, val in (("SK_DTW_QL", ql), ("SK_DTW_NOFUSE", "1" if rng.random() < 0.3 else None),
                          ("SK_DTW_NO_EARLY", "1" if rng.random() < 0.3 else None),
@@ -75,26 +77,48 @@ os.environ["SK_TUNING"] = "1"      # this tool flips tuning switches
                 not np.array_equal(segs[r, :nsegs[r]], osegs[r, :nsegs[r]]) for r in range(R)):
             bad += 1
             print("SEGMENTER mismatch R=%d M=%d %s" % (R, M, kw))
-        # ---- float64 reads (pA-like), per-read oracle composition, a few reads per round ----
-        kinds = int(rng.integers(4))
+        # ---- float64 reads (pA-like), per-read oracle composition ----
+        # (round 4: reads of up to 4 096 samples take the streaming statistics kernel, sk_f64stat.hip -- histogram median,
+        # certified comparisons, numpy-order redo list; longer ones, and everything under SK_F64_OLD, the numpy-order
+        # kernel.  Drawn per round: the data kind, segmenter parameters and limits, the certification margin blown up so
+        # that every read takes the redo, the old kernel, and once in a while a read too long for the streaming path.)
+        kinds = int(rng.integers(6))
         freads = []
-        for _ in range(int(rng.integers(1, 12))):
-            n = int(rng.choice([1, 2, 5, 64, 257, 1500, 4000]))
+        for _ in range(int(rng.choice([1, 3, 12, 70, 300]))):
+            n = int(rng.choice([1, 2, 5, 63, 64, 65, 257, 1500, 4000, 4095, 4096]))
             if kinds == 0:
                 x = np.round(rng.normal(90.0, 14.0, n), 1)                      # 0.1 pA steps: many ties
             elif kinds == 1:
                 x = rng.normal(90.0, 14.0, n)
             elif kinds == 2:
                 x = 500.0 + rng.integers(0, 3, n) * 2.0 ** -40                  # near constant
-            else:
+            elif kinds == 3:
                 x = np.exp(rng.normal(4.0, 1.0, n))
+            elif kinds == 4:                                                    # SquigglePull's pA image of a squiggle
+                x = np.round((synth.squiggle_batch(1, n, int(rng.integers(1 << 30)))[0].astype(np.int64) + 16.0)
+                             * (1493.94 / 8192.0), 2)
+            else:                                                               # gridded, a far outlier, NaN / inf inside
+                x = np.round(rng.normal(96.0, 9.0, n), 2)
+                x[rng.integers(0, n)] = rng.choice([899.99, 0.01, np.nan, np.inf, -np.inf, 1199.0])
             freads.append(x)
+        if rng.random() < 0.1:
+            freads.append(np.round(rng.normal(96.0, 15.0, int(rng.integers(4097, 9000))), 2))   # -> the old kernel for the batch
+        for key, val in (("SK_F64_OLD", "1" if rng.random() < 0.15 else None),
+                         ("SK_SEG_DELTA_SCALE", "1e13" if rng.random() < 0.2 else None)):
+            if val is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = val
         fm = synth.synthetic_motif(int(rng.choice([3, 50, 163])), seed=int(rng.integers(1000)))
         fscale = ["medmad", "zscale"][int(rng.integers(2))]
-        fgot = api.motifseq_reads_f64(freads, fm, scale=fscale)
+        flo, fhi = [(0, 1200), (0, 900), (60, 130), (-1000, 1000)][int(rng.integers(4))]
+        fgot = api.motifseq_reads_f64(freads, fm, scale=fscale, scale_low=flo, scale_hi=fhi)
         for i, x in enumerate(freads):
-            f = ora.scale_outliers(x, 0, 1200)
+            f = ora.scale_outliers(x, flo, fhi)
             if f.size == 0:
+                if not (fgot["flags"][i] & 1):
+                    bad += 1
+                    print("F64 empty read not flagged, kind %d" % kinds)
                 continue
             y = ora.medmad(f)[0] if fscale == "medmad" else ora.zscale(f)[0]
             if not np.all(np.isfinite(y)):
@@ -102,14 +126,20 @@ os.environ["SK_TUNING"] = "1"      # this tool flips tuning switches
             d, s0, e0 = ora.dtw_subsequence(fm, y)
             if (fgot["dist"][i], fgot["start"][i], fgot["end"][i], fgot["n"][i]) != (d, s0, e0, f.size):
                 bad += 1
-                print("F64 mismatch kind %d %s n=%d: got %s want %s" % (kinds, fscale, len(x), fgot[i], (d, s0, e0)))
-        fsegs = api.segment_reads_f64(freads)
+                print("F64 mismatch kind %d %s n=%d lo=%d hi=%d: got %s want %s" % (kinds, fscale, len(x), flo, fhi, fgot[i], (d, s0, e0)))
+        fkw = [dict(), dict(error=10, corrector=3), dict(window=20, seg_dist=5), dict(std_scale=0.2, stall_len=0.9),
+               dict(lim_low=60, lim_hi=130), dict(std_scale=-0.3)][int(rng.integers(6))]
+        fp = SegParams(**fkw)
+        fokw = {a: b for a, b in fkw.items() if a not in ("lim_low", "lim_hi")}
+        fsegs = api.segment_reads_f64(freads, fp)
         for x, gsegs in zip(freads, fsegs):
-            f = ora.scale_outliers(x, 0, 900)
-            wsegs = ora.get_segs(f) if f.size else False
+            f = ora.scale_outliers(x, fp.lim_low, fp.lim_hi)
+            wsegs = ora.get_segs(f, ora.SegParams(**fokw)) if f.size else False
             if gsegs != wsegs:
                 bad += 1
-                print("F64 SEGMENTER mismatch kind %d n=%d" % (kinds, len(x)))
+                print("F64 SEGMENTER mismatch kind %d n=%d %s" % (kinds, len(x), fkw))
+        os.environ.pop("SK_F64_OLD", None)
+        os.environ.pop("SK_SEG_DELTA_SCALE", None)
         # ---- dRNA_segmenter: both branches on a few long ragged reads ----
         if rounds % 4 == 0:
             from squigglekit_amd._lib import DrnaParams, RollParams
