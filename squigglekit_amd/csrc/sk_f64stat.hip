@@ -384,8 +384,9 @@ void k_f64_stats(const F64StatArgs a)
 // Reads longer than 4 096 samples (real reads are tens of thousands of samples long): the same algorithm, one wavefront
 // per read, but the read no longer fits the registers -- it is looked at several times, window by window (2 048 samples),
 // each look re-reading it (L2 / Infinity Cache / HBM):
-//   look A   filter, n, extremes, shifted sums
-//   look B   histogram over [min, max]            look C   members of the selected bin (+ their extremes)
+//   look A   filter, n, extremes, shifted sums -- and the median's first histogram, over a provisional range taken from
+//            the first window (values outside clamp into the edge bins: any monotone binning serves the rank select)
+//   look B   (later rounds / the MAD) histogram over the range           look C   members of the selected bin (+ their extremes)
 //            -- repeated on the members' own range while the bin holds more than 512 values that are not all equal;
 //               up to 512 members are resolved in LDS (re-histogrammed there until at most 64 are left, then ranked)
 //   segmenter: look D   classification, the {in band, kept} entries of each window stored as it goes
@@ -573,9 +574,26 @@ void k_f64_long(const F64StatArgs a)
         double K = (M > 0) ? row[0] : 0.0;              // shift of the sums (any finite value near the data)
         if (!(K > a.lo && K < a.hi)) K = 0.5 * (a.lo + a.hi);
         if (!(fabs(K) < 1e300)) K = 0.0;
+        // The median's first histogram rides in this look, over a PROVISIONAL range -- the first window's extremes, widened
+        // by a quarter -- with everything outside clamped into the edge bins: any monotone binning serves the rank select,
+        // a poor range only costs more members in the selected bin (resolved by the later rounds).  Saves one look.
+        bool pre = false;
+        double plo = 0.0, psc = 0.0;
         for (int wi = 0; wi < nwin; wi++) {
             load_window(wi);
             n += nkw;
+            if (wi == 0) {
+                double m0 = INF, m1 = -INF;
+#pragma unroll
+                for (int j = 0; j < LNJ; j++)
+                    if (64 * j < Mw && x[j] != INF) { m0 = vmin64(m0, x[j]); m1 = vmax64(m1, x[j]); }
+                m0 = readlane64(wave_min64(m0), 0);
+                m1 = readlane64(wave_max64(m1), 0);
+                const double wd = 0.25 * (m1 - m0);
+                plo = m0 - wd;
+                psc = ((double)NB - 0.5) / ((m1 + wd) - plo);
+                pre = (m1 > m0) && (psc > 0.0) && (psc < 1e300) && (fabs(plo) < 1e300);
+            }
 #pragma unroll
             for (int j = 0; j < LNJ; j++) {
                 if (64 * j >= Mw) continue;
@@ -587,6 +605,10 @@ void k_f64_long(const F64StatArgs a)
                         S1 += d;
                         S2 = fma(d, d, S2);
                     }
+                }
+                if (pre) {                              // (wave-uniform)
+                    const double t = vmin64(vmax64((x[j] - plo) * psc, 0.0), (double)(NB - 1));
+                    atomicAdd(&hist[(x[j] != INF) ? (unsigned)t : (unsigned)NB], 1u);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -603,22 +625,30 @@ void k_f64_long(const F64StatArgs a)
         bool ok = true;
 
         // exact order statistics k1 <= k2 <= k1 + 1 of val(x) over the kept samples, val in [vlo, vhi], vlo < vhi
-        auto select2 = [&](auto val, double vlo, double vhi, int k1, int k2, double &v1, double &v2) __attribute__((always_inline)) -> bool {
+        // have_hist: the histogram of round 0 is already in LDS (look A built it: bins clamped, range plo / psc)
+        auto select2 = [&](auto val, double vlo, double vhi, int k1, int k2, double &v1, double &v2, bool have_hist)
+                       __attribute__((always_inline)) -> bool {
             bool restricted = false;                    // later rounds: only values inside [vlo, vhi] take part
             bool have2 = false;                         // v2 already known (k2 fell into the next occupied bin)
             for (int round = 0; round < 6; round++) {
-                const double sc = ((double)NB - 0.5) / (vhi - vlo);
+                const bool clamped = have_hist && round == 0;
+                double sc = ((double)NB - 0.5) / (vhi - vlo);
+                if (clamped) { vlo = plo; sc = psc; }
                 if (!(sc > 0.0 && sc < 1e300)) return false;
+                auto bin_of = [&](double xv, double v) -> unsigned {
+                    bool in = xv != INF;
+                    if (restricted) in = in && v >= vlo && v <= vhi;
+                    double t = (v - vlo) * sc;
+                    if (clamped) t = vmin64(vmax64(t, 0.0), (double)(NB - 1));
+                    return in ? (unsigned)t : (unsigned)NB;
+                };
+                if (!clamped)
                 for (int wi = 0; wi < nwin; wi++) {     // ---- look B
                     load_window(wi);
 #pragma unroll
                     for (int j = 0; j < LNJ; j++) {
                         if (64 * j >= Mw) continue;
-                        const double v = val(x[j]);
-                        bool in = x[j] != INF;
-                        if (restricted) in = in && v >= vlo && v <= vhi;
-                        const unsigned b = in ? (unsigned)((v - vlo) * sc) : (unsigned)NB;
-                        atomicAdd(&hist[b], 1u);
+                        atomicAdd(&hist[bin_of(x[j], val(x[j]))], 1u);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -635,9 +665,7 @@ void k_f64_long(const F64StatArgs a)
                     for (int j = 0; j < LNJ; j++) {
                         if (64 * j >= Mw) continue;
                         const double v = val(x[j]);
-                        bool in = x[j] != INF;
-                        if (restricted) in = in && v >= vlo && v <= vhi;
-                        const unsigned b = in ? (unsigned)((v - vlo) * sc) : (unsigned)NB;
+                        const unsigned b = bin_of(x[j], v);
                         if (b == (unsigned)r1.b) {
                             const unsigned slot = atomicAdd(&cnt[0], 1u);
                             if (slot < (unsigned)CAPL) list[slot] = v;
@@ -677,13 +705,14 @@ void k_f64_long(const F64StatArgs a)
         } else {
             const int k1 = (n - 1) / 2, k2 = n / 2;
             double v1 = mn, v2 = mn;
-            if (mn != mx) ok = select2([&](double v) { return v; }, mn, mx, k1, k2, v1, v2);
+            if (mn != mx) ok = select2([&](double v) { return v; }, mn, mx, k1, k2, v1, v2, pre);
+            else if (pre) clear_hist();                  // (unused provisional histogram)
             median = (k1 == k2) ? v1 : (v1 + v2) / 2.0;
             if (MODE == MODE_MEDMAD) {
                 double w1 = 0.0, w2 = 0.0;
                 const double umax = vmax64(fabs(mn - median), fabs(mx - median));
                 if (ok && umax > 0.0)
-                    ok = select2([&](double v) { return fabs(v - median); }, 0.0, umax, k1, k2, w1, w2);
+                    ok = select2([&](double v) { return fabs(v - median); }, 0.0, umax, k1, k2, w1, w2, false);
                 const double mad = (k1 == k2) ? w1 : (w1 + w2) / 2.0;
                 pr.center = median;
                 pr.scale = mad * 1.4826;

@@ -7,7 +7,7 @@
 # microbenchmark the DTW roof rests on, the command-line tools end to end, and the multi-rank dry run.
 export SK_TUNING=1        # the library reads its tuning switches only with this set
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -46,6 +46,20 @@ for WL in motifseq segmenter; do
     rm -rf "$OUT/kt_$WL" "$OUT/pmc_FETCH_SIZE_$WL" "$OUT/pmc_WRITE_SIZE_$WL"
     unset SK_SEG_CHUNKS
 done
+# the paths the headline does not take (bench.py other_paths: float64 pA segmenter, 4 000- and 20 000-sample reads, float64
+# medmad, int16 zscale, four motifs): the bench block, a kernel-trace summary and the FETCH / WRITE passes of the same command
+python "$R/bench.py" --only-other-paths --steps 3 --cpu-seconds 0 > "$OUT/bench_other_paths.json" 2> "$OUT/bench_other_paths.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_other" -- python "$R/bench.py" --only-other-paths --steps 1 --warmup 0 \
+    --cpu-seconds 0 > "$OUT/kt_other.log" 2>&1
+DB=$(find "$OUT/kt_other" -name '*_results.db' | head -1)
+python "$R/tools/rocprof_summary.py" "$DB" "bench.py --only-other-paths --steps 1 --warmup 0 ($TAG)" > "$OUT/other_paths_kernel_stats.txt"
+for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_other" -- \
+        python "$R/bench.py" --only-other-paths --steps 1 --warmup 0 --cpu-seconds 0 > "$OUT/pmc_${C}_other.log" 2>&1
+done
+python "$R/tools/pmc_traffic.py" 250000 1 "$OUT/pmc_FETCH_SIZE_other" "$OUT/pmc_WRITE_SIZE_other" \
+    "bench.py --only-other-paths --steps 1 --warmup 0 ($TAG; per-launch bytes: the float64 kernels run on 250 000 reads x 3 999 samples and 50 000 x 19 999, 4 launches each)" > "$OUT/traffic_other_paths.json"
+rm -rf "$OUT/kt_other" "$OUT/pmc_FETCH_SIZE_other" "$OUT/pmc_WRITE_SIZE_other"
 python "$R/tools/cli_throughput.py" 200000 1000000 > "$OUT/cli_throughput.txt" 2>&1
 (cd "$R" && python tools/parity_at_scale.py 400000 128 && python tools/parity_at_scale.py segmenter 1000000 128) > "$OUT/parity_at_scale.txt" 2>&1
 ls -la "$OUT"
