@@ -219,7 +219,50 @@ def rounds_for_mutations():
 
 
 # ------------------------------------------------------------------------------------------------------- formatter / oracle
+class _Col(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("data", C.c_void_p), ("off", C.c_void_p)]
+
+
+def fmt_case(L, rng, nrows):
+    """sk_fmt_rows over every column kind (exactly-sized heap copies), the float column against Python's own repr()."""
+    f = np.array([rng.choice([0.0, -0.0, 1e-320, 5e-324, 1e22, 1e21, 1e16, 123456789012345680.0, 0.1, 1 / 3, 2.5e-5,
+                              1e-4, 9.999e-5, float("nan"), float("inf"), float("-inf"), rng.uniform(-1e6, 1e6),
+                              rng.lognormvariate(0, 30)]) for _ in range(nrows)], dtype=np.float64)
+    i32 = np.array([rng.choice([0, -1, 2147483647, -2147483648, rng.randrange(-10**6, 10**6)]) for _ in range(nrows)],
+                   dtype=np.int32)
+    strs = [bytes(rng.randrange(33, 127) for _ in range(rng.randrange(0, 12))) for _ in range(nrows)]
+    blob = np.frombuffer(b"".join(strs) or b"x", dtype=np.uint8).copy()
+    off = np.concatenate([[0], np.cumsum([len(x) for x in strs])]).astype(np.int64)
+    spans = np.stack([off[:-1], off[1:]], axis=1).astype(np.int64).copy()
+    lens = [rng.randrange(0, 5) for _ in range(nrows)]
+    lvals = np.array([rng.randrange(-5000, 5000) for _ in range(sum(lens))] or [0], dtype=np.int32)
+    loff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    const = np.frombuffer(b"model_name", dtype=np.uint8).copy()
+    coff = np.array([0, const.size], dtype=np.int64)
+    cols = (_Col * 6)(_Col(0, blob.ctypes.data, off.ctypes.data), _Col(1, i32.ctypes.data, None),
+                      _Col(2, f.ctypes.data, None), _Col(3, const.ctypes.data, coff.ctypes.data),
+                      _Col(4, lvals.ctypes.data, loff.ctypes.data), _Col(5, blob.ctypes.data, spans.ctypes.data))
+    skip = np.array([rng.random() < 0.2 for _ in range(nrows)], dtype=np.uint8)
+    for sk in (None, skip):
+        n = C.c_int64(0)
+        ptr_ = L.sk_fmt_rows(nrows, 6, C.cast(cols, C.c_void_p), None if sk is None else sk.ctypes.data,
+                             rng.choice((1, 3, 16)), C.byref(n))
+        assert ptr_, "sk_fmt_rows failed"
+        text = C.string_at(ptr_, n.value).decode("latin-1")
+        L.sk_fmt_free(ptr_)
+        want = []
+        for r in range(nrows):
+            if sk is not None and sk[r]:
+                continue
+            s_ = strs[r].decode("latin-1")
+            want.append("\t".join([s_, str(int(i32[r])), repr(float(f[r])), "model_name",
+                                   ",".join(str(int(v)) for v in lvals[loff[r]:loff[r + 1]]), s_]))
+        assert text == "".join(w + "\n" for w in want), "formatter output differs from Python's"
+
+
 def fmt_and_ndtr(L, rng):
+    for nrows in (0, 1, 7, 300):
+        fmt_case(L, rng, nrows)
     z = np.array([0.0, -0.0, 1.0, -1.0, 37.0, -37.0, 1e308, -1e308, np.inf, -np.inf, np.nan, 5e-324] +
                  [rng.uniform(-10, 10) for _ in range(500)])
     out = np.empty_like(z)

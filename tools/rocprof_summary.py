@@ -33,7 +33,7 @@ def main():
         sys.path.insert(0, here)
         import re
         import kernel_resources as kr
-        names = {re.sub(r"\(.*$", "", n).replace("(anonymous namespace)::", "").replace("void ", "") for n in seen}
+        names = {re.sub(r"\(.*$", "", n.replace("(anonymous namespace)::", "").replace("void ", "")) for n in seen}
         print()
         print("# code-object notes of %s (llvm-readelf --notes): registers per lane, spills, LDS, scratch" % os.path.basename(so))
         print("%-70s %5s %5s %7s %7s %7s %8s" % ("kernel", "vgpr", "sgpr", "v_spill", "s_spill", "lds", "scratch"))
