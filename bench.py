@@ -501,6 +501,7 @@ def cli_block(a, L, main):
         os.remove(f)
         Rt = min(Rp, 200_000)
         texts = ["\t".join(str(v) for v in reads[r].tolist()) for r in range(min(Rt, 256))]
+        reads256 = np.array(reads[:min(Rt, 256)])
         del host, reads
         for label, ncols, cmd in (("segmenter_tsv", 4, [seg, "-s"]), ("motifseq_tsv", 8, [mot, "-m", model, "-s"])):
             f = os.path.join(d, label)
@@ -509,6 +510,18 @@ def cli_block(a, L, main):
                     fh.write("\t".join(["read%d.fast5" % r, "id%d" % r] + ["x"] * (ncols - 2)) + "\t"
                              + texts[r % len(texts)] + "\n")
             timed_runs(((label, Rt, cmd + [f]),))
+            os.remove(f)
+        # ... and as SquigglePull writes them by default: pA values with two decimals (float64 route, 100 000 lines = 2.5 GB)
+        Rq = min(Rt, 100_000)
+        pa = np.round((reads256.astype(np.int64) + PA_OFFSET) * (PA_RANGE / PA_DIGITISATION), 2)
+        texts = ["\t".join(repr(float(v)) for v in pa[r]) for r in range(pa.shape[0])]
+        for label, ncols, cmd in (("segmenter_tsv_pA", 4, [seg, "-s"]), ("motifseq_tsv_pA", 8, [mot, "-m", model, "-s"])):
+            f = os.path.join(d, label)
+            with open(f, "w") as fh:
+                for r in range(Rq):
+                    fh.write("\t".join(["read%d.fast5" % r, "id%d" % r] + ["x"] * (ncols - 2)) + "\t"
+                             + texts[r % len(texts)] + "\n")
+            timed_runs(((label, Rq, cmd + [f]),))
             os.remove(f)
     except Exception as e:                                            # noqa: BLE001 -- report, keep the line
         out["error"] = repr(e)

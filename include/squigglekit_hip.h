@@ -123,6 +123,10 @@ int sk_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len,
  * sig[off[r] .. off[r+1]). */
 int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
                          const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs);
+/* the same with the caller's sig[:Num] cut (segmenter.py:207) applied per read: read r is the first len[r] samples of
+ * sig[off[r] .. off[r+1]) (len may be NULL: whole reads) -- a parsed TSV chunk goes in as it is, no repacking. */
+int sk_segment_batch_f64_len(const double *sig, const int64_t *off, const int32_t *len, int32_t nreads,
+                             const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs);
 /* device-resident form of sk_segment_batch_i16 (all pointers device). */
 int sk_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
                        const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs);

@@ -207,6 +207,43 @@ def segment_reads_f64(reads, params=None, max_segs=64):
         return [segs[i, :nsegs[i]].tolist() if nsegs[i] else False for i in range(R)]
 
 
+def segment_ragged_f64(values, off, lens=None, params=None, max_segs=64):
+    """scale_outliers + get_segs for a ragged float64 batch as a tokenizer leaves it: read r is the first lens[r]
+    (default: all) of values[off[r]:off[r+1]].  Returns (segs int32 [R, max_segs, 2], nsegs int32 [R])."""
+    L = _lib.ensure_init()
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    R = off.size - 1
+    params = params or SegParams()
+    ln = None if lens is None else np.ascontiguousarray(lens, dtype=np.int32)
+    while True:
+        segs = np.zeros((max(R, 1), max_segs, 2), dtype=np.int32)
+        nsegs = np.zeros(max(R, 1), dtype=np.int32)
+        rc = L.sk_segment_batch_f64_len(ptr(values), ptr(off), None if ln is None else ptr(ln), R, C.byref(params),
+                                        ptr(segs), ptr(nsegs), max_segs)
+        if rc == _lib.SK_ERR_OVERFLOW:
+            max_segs = int(nsegs.max()) + 8
+            continue
+        check(rc)
+        return segs[:R], nsegs[:R]
+
+
+def motifseq_multi_ragged_f64(values, off, motifs, scale="medmad", scale_low=0, scale_hi=1200):
+    """Every motif against a ragged float64 batch (read r = values[off[r]:off[r+1]]): one record array per motif."""
+    L = _lib.ensure_init()
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    R = off.size - 1
+    out = []
+    for m in motifs:
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        hits = np.zeros(max(R, 1), dtype=HIT_DTYPE)
+        check(L.sk_motifseq_batch_f64(ptr(values), ptr(off), R, ptr(m), m.size, _lib.SK_SCALE[scale], int(scale_low),
+                                      int(scale_hi), ptr(hits)))
+        out.append(hits[:R])
+    return out
+
+
 def drna_segment_reads(reads, params=None, max_segs=32):
     """dRNA_segmenter.py's slow5-branch per-read work (scale_outliers, window statistics, scan)
     for a list of raw integer reads: per read the list of [start, end] collected before the scan

@@ -418,7 +418,7 @@ static int motifseq_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off
         // whose median / MAD bin it could not resolve
         if ((rc = sk_reserve(c, &c->retry, ((size_t)nreads + 16) * sizeof(int32_t)))) return rc;
         int32_t *retry = (int32_t *)c->retry.p;
-        rc = sk_launch_f64_stats(c, d_sig, d_off, nreads, maxlen, (double)scale_low, (double)scale_hi, SK_PREP_MEDMAD,
+        rc = sk_launch_f64_stats(c, d_sig, d_off, nullptr, nreads, maxlen, (double)scale_low, (double)scale_hi, SK_PREP_MEDMAD,
                                  0.0, (sk_prep *)c->prep.p, nullptr, 0, nullptr, retry, (double *)c->comp.p);
         if (rc) return rc;
         rc = sk_launch_prep_f64_listed(c, d_sig, d_off, retry + 1, retry, nreads < 2 * c->num_cu ? nreads : 2 * c->num_cu,
@@ -713,7 +713,8 @@ int sk_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len,
 
 // device-resident core of the float64 segmenter path (d_off zero based; d_segs zeroed here)
 static int segment_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t total,
-                           int64_t maxlen, const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs)
+                           int64_t maxlen, const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs,
+                           const int32_t *d_rlen = nullptr)
 {
     int rc;
     const int64_t words = (maxlen + 63) / 64 > 0 ? (maxlen + 63) / 64 : 1;
@@ -734,12 +735,12 @@ static int segment_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off,
         int32_t *retry = (int32_t *)c->retry.p;
         SK_HIP(hipMemsetAsync(d_segs, 0, gb, c->stream));
         SK_HIP(hipEventRecord(c->ev[0], c->stream));
-        rc = sk_launch_f64_stats(c, d_sig, d_off, nreads, maxlen, (double)p->lim_low, (double)p->lim_hi, SK_PREP_SEGMENT,
+        rc = sk_launch_f64_stats(c, d_sig, d_off, d_rlen, nreads, maxlen, (double)p->lim_low, (double)p->lim_hi, SK_PREP_SEGMENT,
                                  p->std_scale, (sk_prep *)c->prep.p, c->mask.p, row16, (int32_t *)c->len.p, retry, nullptr);
         if (rc) return rc;
         rc = sk_launch_prep_f64_listed(c, d_sig, d_off, retry + 1, retry, grid, (double)p->lim_low, (double)p->lim_hi,
                                        SK_PREP_SEGMENT, p->std_scale, (double *)c->comp.p, srow, (sk_prep *)c->prep.p,
-                                       c->mask.p, row16);
+                                       c->mask.p, row16, d_rlen);
         if (rc) return rc;
         SK_HIP(hipEventRecord(c->ev[1], c->stream));
         rc = sk_launch_seg_walk_masks(c, c->mask.p, row16, (const int32_t *)c->len.p, nreads, p, d_segs, d_nsegs, max_segs);
@@ -754,7 +755,7 @@ static int segment_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off,
     SK_HIP(hipEventRecord(c->ev[0], c->stream));
     rc = sk_launch_prep_f64(c, d_sig, d_off, nreads, (double)p->lim_low,
                             (double)p->lim_hi, SK_PREP_SEGMENT, p->std_scale, (double *)c->comp.p,
-                            (sk_prep *)c->prep.p, (uint64_t *)c->mask.p, nreads);
+                            (sk_prep *)c->prep.p, (uint64_t *)c->mask.p, nreads, d_rlen);
     if (rc) return rc;
     SK_HIP(hipEventRecord(c->ev[1], c->stream));
     rc = sk_launch_segment_walk(c, (const uint64_t *)c->mask.p, nreads, nullptr, (const sk_prep *)c->prep.p,
@@ -764,8 +765,8 @@ static int segment_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off,
     return SK_OK;
 }
 
-int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads, const sk_seg_params *p,
-                         int32_t *segs, int32_t *nsegs, int32_t max_segs)
+int sk_segment_batch_f64_len(const double *sig, const int64_t *off, const int32_t *len, int32_t nreads,
+                             const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
@@ -777,11 +778,20 @@ int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads, 
     if (!segs || !nsegs) return sk_fail(SK_ERR_INVALID, "NULL segs/nsegs");
     int64_t total, maxlen;
     if ((rc = stage_ragged_f64(c, sig, off, nreads, &total, &maxlen))) return rc;
+    const int32_t *d_rlen = nullptr;
+    if (len) {                                      // the caller's sig[:Num] cut: read r is its first len[r] samples
+        for (int32_t r = 0; r < nreads; r++)
+            if (len[r] < 0 || (int64_t)len[r] > off[r + 1] - off[r])
+                return sk_fail(SK_ERR_INVALID, "len[%d] = %d is outside [0, %lld]", r, len[r], (long long)(off[r + 1] - off[r]));
+        if ((rc = sk_reserve(c, &c->len, (size_t)nreads * sizeof(int32_t)))) return rc;
+        SK_HIP(hipMemcpyAsync(c->len.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        d_rlen = (const int32_t *)c->len.p;
+    }
     const size_t gb = (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t);
     if ((rc = sk_reserve(c, &c->out, gb))) return rc;
     if ((rc = sk_reserve(c, &c->out2, (size_t)nreads * sizeof(int32_t)))) return rc;
     rc = segment_dev_f64(c, (const double *)c->sig.p, (const int64_t *)c->off.p, nreads, total, maxlen, p,
-                         (int32_t *)c->out.p, (int32_t *)c->out2.p, max_segs);
+                         (int32_t *)c->out.p, (int32_t *)c->out2.p, max_segs, d_rlen);
     if (rc) return rc;
     SK_HIP(hipMemcpyAsync(segs, c->out.p, gb, hipMemcpyDeviceToHost, c->stream));
     SK_HIP(hipMemcpyAsync(nsegs, c->out2.p, (size_t)nreads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -790,6 +800,12 @@ int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads, 
         if (nsegs[r] > max_segs)
             return sk_fail(SK_ERR_OVERFLOW, "read %d has %d segments, max_segs is %d", r, nsegs[r], max_segs);
     return SK_OK;
+}
+
+int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads, const sk_seg_params *p,
+                         int32_t *segs, int32_t *nsegs, int32_t max_segs)
+{
+    return sk_segment_batch_f64_len(sig, off, nullptr, nreads, p, segs, nsegs, max_segs);
 }
 
 int sk_segment_dev_f64(const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t total, int64_t max_len,

@@ -134,7 +134,8 @@ int sk_launch_prepw_medmad(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
 // f64 ragged: read r is sig[off[r]..off[r+1]); comp uses the same offsets.
 int sk_launch_prep_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads,
                        double lo, double hi, int mode, double std_scale,
-                       double *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_rows);
+                       double *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_rows,
+                       const int32_t *d_rlen = nullptr);   // optional: read r is its first d_rlen[r] samples
 
 // ---- DTW (sk_sdtw.hip) ----
 // Input kinds for the sample feed.
@@ -213,12 +214,12 @@ int sk_launch_raw_to_pa(sk_ctx *c, const int16_t *d_sig, int64_t stride, int32_t
 // ---- float64 reads, streaming statistics (sk_f64stat.hip) + the numpy-order redo of its uncertified reads ----
 bool sk_f64_fast_applies(int64_t maxlen, double std_scale);
 int  sk_f64_row16(int64_t maxlen);
-int  sk_launch_f64_stats(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t maxlen,
+int  sk_launch_f64_stats(sk_ctx *c, const double *d_sig, const int64_t *d_off, const int32_t *d_rlen, int32_t nreads, int64_t maxlen,
                          double lo, double hi, int mode, double std_scale, sk_prep *d_prep, void *d_mask2, int row16,
                          int32_t *d_len, int32_t *d_retry, double *d_comp);
 int  sk_launch_prep_f64_listed(sk_ctx *c, const double *d_sig, const int64_t *d_off, const int32_t *d_list,
                                const int32_t *d_count, int grid, double lo, double hi, int mode, double std_scale,
                                double *d_comp_or_scratch, int64_t scratch_stride, sk_prep *d_prep, void *d_mask2,
-                               int row16);
+                               int row16, const int32_t *d_rlen = nullptr);
 int  sk_launch_seg_walk_masks(sk_ctx *c, const void *d_mask2, int row16, const int32_t *d_len, int32_t nreads,
                               const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs);

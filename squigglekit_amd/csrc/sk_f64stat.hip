@@ -48,6 +48,7 @@ constexpr double U53 = 1.1102230246251565e-16;   // 2^-53
 struct F64StatArgs {
     const double  *sig;
     const int64_t *off;                 // zero based, nreads + 1
+    const int32_t *len;                 // optional: read r is its first len[r] samples (the caller's sig[:Num] cut)
     int            nreads;
     double         lo, hi;              // outlier limits (strict)
     double         std_scale;           // segmenter
@@ -178,7 +179,9 @@ void k_f64_stats(const F64StatArgs a)
     const int nwaves = gridDim.x * WPB;
     for (int r = blockIdx.x * WPB + w; r < a.nreads; r += nwaves) {
         const int64_t o0 = a.off[r];
-        const int M = __builtin_amdgcn_readfirstlane((int)min(max(a.off[r + 1] - o0, (int64_t)0), (int64_t)(64 * NJ)));
+        int64_t Mfull = max(a.off[r + 1] - o0, (int64_t)0);
+        if (a.len) Mfull = min(Mfull, (int64_t)max(a.len[r], 0));
+        const int M = __builtin_amdgcn_readfirstlane((int)min(Mfull, (int64_t)(64 * NJ)));
         const double *row = a.sig + o0;
 
         // ---- the read into registers: lane l holds samples 64 j + l; slots past the end read as +inf ----------
@@ -534,7 +537,9 @@ void k_f64_long(const F64StatArgs a)
     const int nwaves = gridDim.x * WPB;
     for (int r = blockIdx.x * WPB + w; r < a.nreads; r += nwaves) {
         const int64_t o0 = a.off[r];
-        const int M = __builtin_amdgcn_readfirstlane((int)min(max(a.off[r + 1] - o0, (int64_t)0), (int64_t)0x3fffffff));
+        int64_t Mfull = max(a.off[r + 1] - o0, (int64_t)0);
+        if (a.len) Mfull = min(Mfull, (int64_t)max(a.len[r], 0));
+        const int M = __builtin_amdgcn_readfirstlane((int)min(Mfull, (int64_t)0x3fffffff));
         const double *row = a.sig + o0;
         const int nwin = (M + LWIN - 1) / LWIN;
 
@@ -813,13 +818,13 @@ int sk_f64_row16(int64_t maxlen)
 
 // mode: SK_PREP_SEGMENT (masks + len_out) or SK_PREP_MEDMAD (comp).  d_retry: nreads + 16 ints, zeroed here; the
 // caller runs the numpy-order kernel over that list next.
-int sk_launch_f64_stats(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t maxlen,
+int sk_launch_f64_stats(sk_ctx *c, const double *d_sig, const int64_t *d_off, const int32_t *d_rlen, int32_t nreads, int64_t maxlen,
                         double lo, double hi, int mode, double std_scale, sk_prep *d_prep, void *d_mask2, int row16,
                         int32_t *d_len, int32_t *d_retry, double *d_comp)
 {
     if (nreads <= 0) return SK_OK;
     F64StatArgs a;
-    a.sig = d_sig; a.off = d_off; a.nreads = nreads; a.lo = lo; a.hi = hi; a.std_scale = std_scale;
+    a.sig = d_sig; a.off = d_off; a.len = d_rlen; a.nreads = nreads; a.lo = lo; a.hi = hi; a.std_scale = std_scale;
     a.delta_scale = 1.0;
     if (const char *e = sk_tune("SK_SEG_DELTA_SCALE")) { const double v = atof(e); if (v > 0) a.delta_scale = v; }
     a.prep = d_prep; a.mask2 = (uint4 *)d_mask2; a.row16 = row16; a.len_out = d_len; a.retry = d_retry; a.comp = d_comp;

@@ -752,6 +752,7 @@ struct ListedF64 {
     unsigned char *mask2;
     int            row16;
     int64_t        scratch_stride;      // doubles per scratch row (segmenter mode)
+    const int32_t *len;                 // optional: read r is its first len[r] samples
 };
 
 struct PrepF64Shared {
@@ -774,7 +775,8 @@ __device__ void prep_f64_read(PrepF64Shared *sh, int r, const double *__restrict
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t o0 = off[r];
-    const int M = (int)(off[r + 1] - o0);
+    int M = (int)(off[r + 1] - o0);
+    if (la.len) M = min(M, max(la.len[r], 0));
     const double *row = sig + o0;
     double *crow = (LISTED && mode == SK_PREP_SEGMENT) ? comp + (int64_t)blockIdx.x * la.scratch_stride : comp + o0;
     if (tid < 4) sc->sel[tid] = 0;
@@ -1077,11 +1079,11 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
 
 int sk_launch_prep_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads,
                        double lo, double hi, int mode, double std_scale,
-                       double *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_rows)
+                       double *d_comp, sk_prep *d_prep, uint64_t *d_mask, int64_t mask_rows, const int32_t *d_rlen)
 {
     if (nreads <= 0) return SK_OK;
     ListedF64 la;
-    la.list = nullptr; la.count = nullptr; la.mask2 = nullptr; la.row16 = 0; la.scratch_stride = 0;
+    la.list = nullptr; la.count = nullptr; la.mask2 = nullptr; la.row16 = 0; la.scratch_stride = 0; la.len = d_rlen;
     hipLaunchKernelGGL(k_prep_f64<false>, dim3(nreads), dim3(TPB), 0, c->stream, d_sig, d_off, nreads, lo, hi, mode,
                        std_scale, d_comp, d_prep, d_mask, mask_rows, la);
     SK_HIP(hipGetLastError());
@@ -1093,12 +1095,13 @@ int sk_launch_prep_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int
 // scratch_stride doubles), medmad mode their prep records and comp rows.
 int sk_launch_prep_f64_listed(sk_ctx *c, const double *d_sig, const int64_t *d_off, const int32_t *d_list,
                               const int32_t *d_count, int grid, double lo, double hi, int mode, double std_scale,
-                              double *d_comp_or_scratch, int64_t scratch_stride, sk_prep *d_prep, void *d_mask2, int row16)
+                              double *d_comp_or_scratch, int64_t scratch_stride, sk_prep *d_prep, void *d_mask2, int row16,
+                              const int32_t *d_rlen)
 {
     if (grid <= 0) return SK_OK;
     ListedF64 la;
     la.list = d_list; la.count = d_count; la.mask2 = (unsigned char *)d_mask2; la.row16 = row16;
-    la.scratch_stride = scratch_stride;
+    la.scratch_stride = scratch_stride; la.len = d_rlen;
     hipLaunchKernelGGL(k_prep_f64<true>, dim3(grid), dim3(TPB), 0, c->stream, d_sig, d_off, 0, lo, hi, mode,
                        std_scale, d_comp_or_scratch, d_prep, (uint64_t *)nullptr, (int64_t)0, la);
     SK_HIP(hipGetLastError());

@@ -249,11 +249,28 @@ class _Batcher:
             finally:
                 _mark("GPU call ends")
         job = self._worker.submit(call)
-        prev, self._pending = self._pending, (job, rows, nsamp, fast5_col, id_col, name_of, id_of)
+        prev, self._pending = self._pending, (job, len(nsamp), fast5_col, id_col, name_of, id_of,
+                                              lambda i, r=rows, ns=nsamp: r[i, :ns[i]])
         if prev is not None:
             self._finish(prev)
         if a.sig_extract:                                   # (-x normalises on the GPU from this thread: no overlap)
             self.drain()
+
+    def rows_f64(self, fb):
+        """A chunk of plain decimal (pA) lines as the float64 tokenizer leaves it (tsvio.FloatBlock: flat values +
+        offsets): one GPU batch per motif, one native table, pipelined like rows()."""
+        a = self.args
+        motifs = [np.asarray(self.models[n_], dtype=np.float64) for n_ in self.order]
+        if self._worker is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._worker = ThreadPoolExecutor(1)
+        _mark("block of %d float64 reads to the GPU worker" % fb.n)
+        job = self._worker.submit(api.motifseq_multi_ragged_f64, fb.values, fb.off, motifs, a.scale, a.scale_low, a.scale_hi)
+        prev, self._pending = self._pending, (job, fb.n, ("span", fb.buf, fb.spans("name")), ("span", fb.buf, fb.spans("id")),
+                                              lambda i, b=fb: b.text("name", i), lambda i, b=fb: b.text("id", i),
+                                              lambda i, b=fb: b.values[b.off[i]:b.off[i + 1]])
+        if prev is not None:
+            self._finish(prev)
 
     def drain(self):
         prev, self._pending = self._pending, None
@@ -261,15 +278,15 @@ class _Batcher:
             self._finish(prev)
 
     def _finish(self, p):
-        job, rows, nsamp, fast5_col, id_col, name_of, id_of = p
+        job, n, fast5_col, id_col, name_of, id_of, sig_of = p
         hits = job.result()
-        _mark("block of %d reads back from the GPU" % len(nsamp))
-        if self.table(len(nsamp), fast5_col, id_col, hits):
+        _mark("block of %d reads back from the GPU" % n)
+        if self.table(n, fast5_col, id_col, hits):
             _mark("table written")
             return
-        for i in range(len(nsamp)):
+        for i in range(n):
             self.emit(name_of(i), id_of(i), [hits[c][i] for c in range(len(self.order))],
-                      rows[i, :nsamp[i]] if (self.args.sig_extract or self.args.strict_compat) else None, None)
+                      sig_of(i) if (self.args.sig_extract or self.args.strict_compat) else None, None)
 
     def block(self, blk):
         """A parsed TSV chunk (tsvio.TsvBlock): its integer lines go to the GPU as ONE int16 batch straight from the
@@ -387,12 +404,21 @@ def main(argv=None):
     if args.signal:
         # native tokenizer (csrc/sk_tsv.cpp): integer lines arrive as int16 rows, one GPU batch per chunk of the
         # file; decimal (pA) chunks go through the float64 tokenizer, odd lines through the reference's own parse
-        for blk in tsvio.iter_tsv_blocks_i16(args.signal, 8):
-            if blk.mostly_integer():
-                out.block(blk)
+        for blk in tsvio.iter_tsv_blocks(args.signal, 8):
+            if isinstance(blk, tsvio.FloatBlock):        # (first line decimal: straight from the float64 tokenizer)
+                fb = blk
+            else:
+                if blk.mostly_integer():
+                    out.block(blk)
+                    continue
+                fb = blk.float_block(8)
+                if fb is None:
+                    continue
+            if fb.clean() and not (args.sig_extract or args.after_stall):
+                out.rows_f64(fb)                         # the whole chunk as one batch, no Python per read
                 continue
             out.flush()
-            for fast5, read_id, vals, fl, raw in blk.float_lines(8):
+            for fast5, read_id, vals, fl, raw in tsvio.float_block_lines(fb):
                 if fl & 8 or (fl & 16 and raw is not None and raw.count(b"\t") < 1):
                     # odd tokens (or not even a readID column): the reference's own parse, exceptions included
                     fast5, read_id, sig = tsvio.parse_motifseq_line(raw.decode())

@@ -126,6 +126,22 @@ class _Batcher:
         if prev is not None:
             self._finish(prev)
 
+    def rows_f64(self, fb):
+        """A chunk of plain decimal (pA) lines as the float64 tokenizer leaves it (tsvio.FloatBlock: flat values +
+        offsets): one GPU batch -- the sig[:Num] cut rides along as per-read lengths, nothing is repacked --, one
+        native table, pipelined like rows()."""
+        Num = self.args.Num
+        ntok = np.diff(fb.off).astype(np.int64)
+        lens = (np.maximum(ntok + Num, 0) if Num < 0 else np.minimum(ntok, Num)).astype(np.int32)    # sig[:Num]
+        if self._worker is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._worker = ThreadPoolExecutor(1)
+        _mark("block of %d float64 reads to the GPU worker" % fb.n)
+        job = self._worker.submit(api.segment_ragged_f64, fb.values, fb.off, lens, self.params)
+        prev, self._pending = self._pending, (job, fb.n, ("span", fb.buf, fb.spans("name")), lambda i, b=fb: b.text("name", i))
+        if prev is not None:
+            self._finish(prev)
+
     def drain(self):
         prev, self._pending = self._pending, None
         if prev is not None:
@@ -216,12 +232,23 @@ def main(argv=None):
         # native tokenizer (csrc/sk_tsv.cpp): integer lines arrive as int16 rows, one GPU batch per chunk of the
         # file; a line it cannot take verbatim (odd tokens, decimals, too few columns) is parsed exactly the
         # reference's way
-        for blk in tsvio.iter_tsv_blocks_i16(args.signal, 4):
-            if blk.mostly_integer():
-                out.block(blk, args.signal)
+        # (a chunk whose first line starts with a decimal token -- pA files, SquigglePull's default output -- comes
+        # straight from the float64 tokenizer: tsvio.FloatBlock)
+        for blk in tsvio.iter_tsv_blocks(args.signal, 4):
+            if isinstance(blk, tsvio.FloatBlock):
+                fb = blk
+            else:
+                if blk.mostly_integer():
+                    out.block(blk, args.signal)
+                    continue
+                fb = blk.float_block(4)                              # decimal lines after all: float64 tokenizer
+                if fb is None:
+                    continue
+            if fb.clean() and not args.test:
+                out.rows_f64(fb)                                      # the whole chunk as one batch, no Python per read
                 continue
             out.flush()
-            for name, _rid, vals, fl, raw in blk.float_lines(4):      # pA (decimal) lines: float64 tokenizer
+            for name, _rid, vals, fl, raw in tsvio.float_block_lines(fb):
                 if (fl & 24) or not (fl & 5):       # SLOW | SHORT, or neither FIRSTDOT nor ALLINT
                     name, sig = tsvio.parse_segmenter_line(raw.decode())
                 else:

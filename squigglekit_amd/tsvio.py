@@ -38,17 +38,46 @@ def parse_motifseq_line(line):
     return cols[0], cols[1], np.array([float(v) for v in cols[8:]])
 
 
-def _parse_block_float(chunk, start_col, nthreads):
-    """One whole-line chunk through the float64 tokenizer (sk_tsv_parse): (name, read_id, values, flags, raw)."""
+class FloatBlock:
+    """One whole-line chunk through the float64 tokenizer (sk_tsv_parse): every line's data tokens in ONE flat float64
+    array -- line i's at values[off[i]:off[i+1]] -- its name / read-id columns as byte ranges of `buf` (the chunk is
+    buf[base:end]: bytes or a read-only memory map, nothing copied), its flags (SK_TSV_*).  What the float64 batch entry
+    points take as it stands."""
+
+    def __init__(self, chunk, n, values, off, flags, name_off, name_len, id_off, id_len):
+        self.buf, self.base, self.end = chunk
+        self.n, self.values, self.off, self.flags = n, values, off, flags
+        self.name_off, self.name_len, self.id_off, self.id_len = name_off, name_len, id_off, id_len   # relative to base
+
+    def clean(self):
+        """Every line is a plain decimal (or integer) read with a non-zero value somewhere: the reference's own parse
+        would give exactly `values` (flags: not SLOW / SHORT, FIRSTDOT or ALLINT, ANY)."""
+        f = self.flags
+        return bool(self.n) and not np.any(f & 24) and bool(np.all(f & 5)) and bool(np.all(f & 2))
+
+    def spans(self, which):
+        """[n, 2] first / one-past-last byte of the column in `buf` (absolute positions)."""
+        o, ln = (self.name_off, self.name_len) if which == "name" else (self.id_off, self.id_len)
+        a = self.base + o
+        return np.stack([a, a + ln.astype(np.int64)], axis=1)
+
+    def text(self, which, i):
+        o, ln = (self.name_off, self.name_len) if which == "name" else (self.id_off, self.id_len)
+        a = self.base + int(o[i])
+        return bytes(self.buf[a:a + int(ln[i])]).decode()
+
+
+def parse_block_float(chunk, start_col, nthreads):
+    """(FloatBlock or None) of a whole-line chunk (buf, start, end); the tokenizer reads the chunk in place."""
     from . import _lib
     L = _lib.load()
     src, start, end = chunk
-    buf = src[start:end] if not isinstance(src, bytes) or start or end != len(src) else src   # (bytes: the slow lines are sliced)
-    n = L.sk_tsv_count_lines(buf, len(buf))
+    cp, clen = _cptr(src, start), end - start
+    n = L.sk_tsv_count_lines(cp, clen)
     if n <= 0:
-        return
+        return None
     ntok = np.zeros(n, dtype=np.int64)
-    _lib.check(L.sk_tsv_count_tokens(buf, len(buf), start_col, n, _lib.ptr(ntok), nthreads))
+    _lib.check(L.sk_tsv_count_tokens(cp, clen, start_col, n, _lib.ptr(ntok), nthreads))
     off = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(ntok, out=off[1:])
     values = np.empty(max(1, int(off[-1])), dtype=np.float64)
@@ -57,18 +86,29 @@ def _parse_block_float(chunk, start_col, nthreads):
     id_off = np.zeros(n, dtype=np.int64)
     id_len = np.zeros(n, dtype=np.int32)
     flags = np.zeros(n, dtype=np.int32)
-    _lib.check(L.sk_tsv_parse(buf, len(buf), start_col, n, _lib.ptr(off), _lib.ptr(values),
+    _lib.check(L.sk_tsv_parse(cp, clen, start_col, n, _lib.ptr(off), _lib.ptr(values),
                               _lib.ptr(name_off), _lib.ptr(name_len), _lib.ptr(id_off),
                               _lib.ptr(id_len), _lib.ptr(flags), nthreads))
-    pos = 0
+    return FloatBlock(chunk, n, values, off, flags, name_off, name_len, id_off, id_len)
+
+
+def _parse_block_float(chunk, start_col, nthreads):
+    """The same chunk line by line: (name, read_id, values, flags, raw)."""
+    fb = parse_block_float(chunk, start_col, nthreads)
+    if fb is None:
+        return
+    yield from float_block_lines(fb)
+
+
+def float_block_lines(fb):
+    buf, n, values, off, flags = fb.buf, fb.n, fb.values, fb.off, fb.flags
+    pos = fb.base
     for i in range(n):
-        nl = buf.find(b"\n", pos)
-        end = nl if nl >= 0 else len(buf)
+        nl = buf.find(b"\n", pos, fb.end)
+        end = nl if nl >= 0 else fb.end
         fl = int(flags[i])
-        raw = buf[pos:end] if (fl & 24) or not (fl & 5) else None
-        yield (buf[name_off[i]:name_off[i] + name_len[i]].decode(),
-               buf[id_off[i]:id_off[i] + id_len[i]].decode(),
-               values[off[i]:off[i + 1]], fl, raw)
+        raw = bytes(buf[pos:end]) if (fl & 24) or not (fl & 5) else None
+        yield (fb.text("name", i), fb.text("id", i), values[off[i]:off[i + 1]], fl, raw)
         pos = end + 1
 
 
@@ -178,6 +218,39 @@ class TsvBlock:
         import os
         return _parse_block_float((self.buf, self.base, self.end), start_col, nthreads or min(32, os.cpu_count() or 1))
 
+    def float_block(self, start_col, nthreads=None):
+        """The chunk through the float64 tokenizer as ONE FloatBlock (flat values + offsets), or None."""
+        import os
+        return parse_block_float((self.buf, self.base, self.end), start_col, nthreads or min(32, os.cpu_count() or 1))
+
+
+def _parse_chunk_i16(chunk, start_col, nthreads):
+    """One whole-line chunk through the int16 tokenizer: TsvBlock, or None for an empty chunk."""
+    from . import _lib
+    L = _lib.load()
+    src, start, end = chunk
+    cp, clen = _cptr(src, start), end - start
+    n = L.sk_tsv_count_lines(cp, clen)
+    if n <= 0:
+        return None
+    ntok = np.zeros(n, dtype=np.int64)
+    _lib.check(L.sk_tsv_count_tokens(cp, clen, start_col, n, _lib.ptr(ntok), nthreads))
+    stride = max(8, (int(ntok.max()) + 7) // 8 * 8)
+    if n * stride * 2 > (3 << 30):               # one enormous line among short ones: not worth a dense block
+        stride = max(8, (int(np.percentile(ntok, 99)) + 7) // 8 * 8)   # (longer lines are flagged SLOW)
+    rows = np.empty((n, stride), dtype=np.int16)
+    nsamp = np.zeros(n, dtype=np.int32)
+    flags = np.zeros(n, dtype=np.int32)
+    name_off = np.zeros(n, dtype=np.int64)
+    name_len = np.zeros(n, dtype=np.int32)
+    id_off = np.zeros(n, dtype=np.int64)
+    id_len = np.zeros(n, dtype=np.int32)
+    line_off = np.zeros(n + 1, dtype=np.int64)
+    _lib.check(L.sk_tsv_parse_i16(cp, clen, start_col, n, stride, _lib.ptr(rows), _lib.ptr(nsamp),
+                                  _lib.ptr(name_off), _lib.ptr(name_len), _lib.ptr(id_off), _lib.ptr(id_len),
+                                  _lib.ptr(flags), _lib.ptr(line_off), nthreads))
+    return TsvBlock(chunk, rows, nsamp, flags, name_off, name_len, id_off, id_len, line_off)
+
 
 def iter_tsv_blocks_i16(path, start_col, chunk_bytes=48 << 20, nthreads=None, prefetch=True):
     """Stream a SquigglePull TSV as TsvBlock chunks (csrc/sk_tsv.cpp: sk_tsv_parse_i16): integer lines land in
@@ -191,28 +264,39 @@ def iter_tsv_blocks_i16(path, start_col, chunk_bytes=48 << 20, nthreads=None, pr
     L = _lib.load()
     nthreads = nthreads or min(32, os.cpu_count() or 1)
     for chunk in _line_blocks(path, chunk_bytes):
+        blk = _parse_chunk_i16(chunk, start_col, nthreads)
+        if blk is not None:
+            yield blk
+
+
+def _first_token_has_dot(src, start, end, start_col):
+    """Does the first line's first data token hold a "." -- the reference's own test for "this is a float read"
+    (segmenter.py:198; MotifSeq.py:270 parses everything as float anyway)?"""
+    nl = src.find(b"\n", start, end)
+    line = bytes(src[start:(nl if nl >= 0 else end)][:4096 + 64 * start_col])
+    cols = line.split(b"\t", start_col + 1)
+    return len(cols) > start_col and b"." in cols[start_col]
+
+
+def iter_tsv_blocks(path, start_col, chunk_bytes=48 << 20, nthreads=None, prefetch=True):
+    """Stream a SquigglePull TSV chunk by chunk: a chunk whose first line starts its data with a decimal token goes
+    straight through the float64 tokenizer (FloatBlock: pA files, SquigglePull's default output), any other one through
+    the int16 one (TsvBlock).  Either way the chunk is tokenised in place, one chunk ahead on a background thread."""
+    if prefetch:
+        yield from _prefetched(iter_tsv_blocks(path, start_col, chunk_bytes, nthreads, prefetch=False))
+        return
+    import os
+    nthreads = nthreads or min(32, os.cpu_count() or 1)
+    for chunk in _line_blocks(path, chunk_bytes):
         src, start, end = chunk
-        cp, clen = _cptr(src, start), end - start
-        n = L.sk_tsv_count_lines(cp, clen)
-        if n <= 0:
+        if _first_token_has_dot(src, start, end, start_col):
+            fb = parse_block_float(chunk, start_col, nthreads)
+            if fb is not None:
+                yield fb
             continue
-        ntok = np.zeros(n, dtype=np.int64)
-        _lib.check(L.sk_tsv_count_tokens(cp, clen, start_col, n, _lib.ptr(ntok), nthreads))
-        stride = max(8, (int(ntok.max()) + 7) // 8 * 8)
-        if n * stride * 2 > (3 << 30):               # one enormous line among short ones: not worth a dense block
-            stride = max(8, (int(np.percentile(ntok, 99)) + 7) // 8 * 8)   # (longer lines are flagged SLOW)
-        rows = np.empty((n, stride), dtype=np.int16)
-        nsamp = np.zeros(n, dtype=np.int32)
-        flags = np.zeros(n, dtype=np.int32)
-        name_off = np.zeros(n, dtype=np.int64)
-        name_len = np.zeros(n, dtype=np.int32)
-        id_off = np.zeros(n, dtype=np.int64)
-        id_len = np.zeros(n, dtype=np.int32)
-        line_off = np.zeros(n + 1, dtype=np.int64)
-        _lib.check(L.sk_tsv_parse_i16(cp, clen, start_col, n, stride, _lib.ptr(rows), _lib.ptr(nsamp),
-                                      _lib.ptr(name_off), _lib.ptr(name_len), _lib.ptr(id_off), _lib.ptr(id_len),
-                                      _lib.ptr(flags), _lib.ptr(line_off), nthreads))
-        yield TsvBlock(chunk, rows, nsamp, flags, name_off, name_len, id_off, id_len, line_off)
+        blk = _parse_chunk_i16(chunk, start_col, nthreads)
+        if blk is not None:
+            yield blk
 
 
 def _prefetched(gen, depth=2):

@@ -136,6 +136,25 @@ def oracle_backend(monkeypatch, ora):
         reads = [np.asarray(sig[r, :lens[r]]) for r in range(sig.shape[0])]
         return [mot_any(reads, m, scale, lo, hi) for m in motifs]
 
+    def seg_ragged(values, off, lens=None, params=None, max_segs=64):
+        R = len(off) - 1
+        reads = [np.asarray(values[off[r]:off[r] + (int(lens[r]) if lens is not None else off[r + 1] - off[r])]) for r in range(R)]
+        res = seg_any(reads, params)
+        k = max([len(x) for x in res if x] + [1])
+        segs = np.zeros((R, k, 2), dtype=np.int32)
+        nsegs = np.zeros(R, dtype=np.int32)
+        for r, x in enumerate(res):
+            if x:
+                nsegs[r] = len(x)
+                segs[r, :len(x)] = x
+        return segs, nsegs
+
+    def mot_ragged(values, off, motifs, scale="medmad", lo=0, hi=1200):
+        reads = [np.asarray(values[off[r]:off[r + 1]]) for r in range(len(off) - 1)]
+        return [mot_any(reads, m, scale, lo, hi) for m in motifs]
+
+    monkeypatch.setattr(api, "segment_ragged_f64", seg_ragged)
+    monkeypatch.setattr(api, "motifseq_multi_ragged_f64", mot_ragged)
     monkeypatch.setattr(api, "segment_batch", seg_batch)
     monkeypatch.setattr(api, "motifseq_multi_batch", mot_batch, raising=False)
     monkeypatch.setattr(api, "segment_any", seg_any)
@@ -439,3 +458,46 @@ def test_motifseq_strict_compat_degenerate_rows_gpu(gpu, scrappy_stub, tmp_path)
     y = api.normalise(synth.squiggle_batch(1, 700, 5)[0])
     d, cost, path = api.dtw_subsequence(x, y)
     assert api.dtw_subsequence_cref(x, y) == (d, int(path[1][0]), int(path[1][-1]))
+
+
+@pytest.mark.gpu
+def test_pa_tsv_block_route(gpu, ora, tmp_path):
+    """pA TSVs (SquigglePull's default output: decimals) go to the GPU a whole chunk at a time, straight from the float64
+    tokenizer (tsvio.FloatBlock, sk_segment_batch_f64_len / sk_motifseq_batch_f64): the table must be what the per-line
+    route prints -- checked against the oracle read by read, with and without the -n cut, and with a chunk that holds an
+    odd token (falls back to the per-line route) or an integer line among the decimal ones."""
+    from squigglekit_amd import synth
+    from squigglekit_amd.motifseq_cli import main as mmain
+    from squigglekit_amd.segmenter_cli import main as smain
+    R, M = 200, 3000
+    sig = synth.squiggle_batch(R, M, 606)
+    pa = np.round((sig.astype(np.int64) + 16.0) * (1493.94 / 8192.0), 2)
+    pa[5] = np.rint(pa[5])                                       # a line of integer-valued tokens ("95.0" -> still decimal)
+    lines_s = ["\t".join(["r%d.fast5" % r, "a", "b", "c"] + [repr(float(v)) for v in pa[r]]) for r in range(R)]
+    lines_m = ["\t".join(["f.fast5", "id%d" % r] + ["x"] * 6 + [repr(float(v)) for v in pa[r]]) for r in range(R)]
+    (tmp_path / "s.tsv").write_text("\n".join(lines_s) + "\n")
+    (tmp_path / "m.tsv").write_text("\n".join(lines_m) + "\n")
+    odd = list(lines_s)
+    odd[17] = odd[17].replace("\t", "\t ", 5)                    # tokens with a leading blank: SK_TSV_SLOW -> per-line route
+    (tmp_path / "odd.tsv").write_text("\n".join(odd) + "\n")
+
+    def want_seg(num):
+        out = []
+        for r in range(R):
+            x = pa[r][:num] if num else pa[r][:-1]               # segmenter.py:104-105,207
+            segs = ora.get_segs(ora.scale_outliers(x, 0, 900))
+            if segs:
+                out.append("r%d.fast5\t%s" % (r, ",".join(str(v) for p in segs for v in p)))
+        return out
+    for argv, num in ((["-s", str(tmp_path / "s.tsv")], 0), (["-s", str(tmp_path / "s.tsv"), "-n", "2500"], 2500),
+                      (["-s", str(tmp_path / "odd.tsv")], 0)):
+        got, err, code = run_cli(smain, argv)
+        assert code == 0 and got.strip().split("\n") == want_seg(num), (argv, err[-300:])
+    model = os.path.join(GOLD, "CATCTATCCAGGGTTAAATT.model")
+    motif = np.array(load_golden("motifseq_cli.json.gz")["model_expanded"]["values"])
+    got, err, code = run_cli(mmain, ["-s", str(tmp_path / "m.tsv"), "-m", model])
+    rows = [ln.split("\t") for ln in got.strip().split("\n")[1:]]
+    assert code == 0 and len(rows) == R, err[-300:]
+    for r in (0, 5, 17, 99, R - 1):
+        d, s0, e0 = ora.dtw_subsequence(motif, ora.medmad(ora.scale_outliers(pa[r], 0, 1200))[0])
+        assert rows[r][1] == "id%d" % r and (int(rows[r][3]), int(rows[r][4]), float(rows[r][6])) == (s0, e0, d), r

@@ -332,3 +332,31 @@ def test_f64_screening_of_near_constant_reads(gpu, ora, example_model, scale):
             checked += 1
             assert (got["dist"][r], got["start"][r], got["end"][r], got["n"][r]) == w, (scale, r)
     assert checked >= 150
+
+
+def test_segment_ragged_f64_with_per_read_cuts(gpu, ora):
+    """sk_segment_batch_f64_len: read r is the first len[r] samples of its slot (the tools' sig[:Num] cut on a parsed TSV
+    chunk, nothing repacked) -- through the 4 096-sample kernel, the window-by-window one and the numpy-order one."""
+    from squigglekit_amd import api
+    rng = np.random.default_rng(9)
+    for maxn in (3000, 9000):
+        reads = _pa_reads(40, maxn, 3)
+        reads = [r[:int(rng.integers(2, maxn + 1))] for r in reads]
+        flat = np.concatenate(reads)
+        off = np.concatenate([[0], np.cumsum([r.size for r in reads])]).astype(np.int64)
+        for cut in ("all", "minus1", "random"):
+            if cut == "all":
+                lens = None
+            elif cut == "minus1":
+                lens = np.array([max(r.size - 1, 0) for r in reads], dtype=np.int32)
+            else:
+                lens = np.array([int(rng.integers(0, r.size + 1)) for r in reads], dtype=np.int32)
+            segs, nsegs = api.segment_ragged_f64(flat, off, lens)
+            for r, sig in enumerate(reads):
+                x = sig if lens is None else sig[:lens[r]]
+                f = ora.scale_outliers(x, 0, 900)
+                want = (ora.get_segs(f) if f.size else False) or []
+                assert segs[r, :nsegs[r]].tolist() == want, (maxn, cut, r)
+    bad = np.array([5, 99999], dtype=np.int32)
+    with pytest.raises(Exception):
+        api.segment_ragged_f64(np.zeros(10), np.array([0, 4, 10], dtype=np.int64), bad)

@@ -62,6 +62,20 @@ def main():
         run("MotifSeq.py -s -m (TSV)", [py, mot, "-s", os.path.join(d, "mot.tsv"), "-m", model], R, size, out)
         for f in ("seg.tsv", "mot.tsv"):
             os.remove(os.path.join(d, f))
+        # the same reads as SquigglePull writes them by default: pA values with two decimals (SquigglePull.py:183-189)
+        pa = np.round((sig[:256].astype(np.int64) + 16.0) * (1493.94 / 8192.0), 2)
+        texts = ["\t".join(repr(float(v)) for v in row) for row in pa]
+        Rp = max(1, R // 2)
+        for name, ncols in (("seg", 4), ("mot", 8)):
+            with open(os.path.join(d, name + "_pa.tsv"), "w") as fh:
+                for r in range(Rp):
+                    fh.write("\t".join(["read%d.fast5" % r, "id%d" % r] + ["x"] * (ncols - 2)) + "\t"
+                             + texts[r % len(texts)] + "\n")
+        size = os.path.getsize(os.path.join(d, "seg_pa.tsv")) / 1e6
+        run("segmenter.py -s (pA TSV)", [py, seg, "-s", os.path.join(d, "seg_pa.tsv")], Rp, size, out)
+        run("MotifSeq.py -s -m (pA TSV)", [py, mot, "-s", os.path.join(d, "mot_pa.tsv"), "-m", model], Rp, size, out)
+        for f in ("seg_pa.tsv", "mot_pa.tsv"):
+            os.remove(os.path.join(d, f))
     if RP > 0:
         base = synth.squiggle_batch(min(RP, 65536), M, 4243)
         big = np.lib.format.open_memmap(os.path.join(d, "reads.npy"), mode="w+", dtype=np.int16, shape=(RP, M))
