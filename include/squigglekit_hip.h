@@ -127,6 +127,12 @@ int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
  * sig[off[r] .. off[r+1]) (len may be NULL: whole reads) -- a parsed TSV chunk goes in as it is, no repacking. */
 int sk_segment_batch_f64_len(const double *sig, const int64_t *off, const int32_t *len, int32_t nreads,
                              const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs);
+/* raw reads through the pA route -- what segmenter.py does with fast5 / slow5 input unless --raw_signal is given
+ * (segmenter.py:345-349, 366-370, 385): np.round((raw + offset) * (float("%.2f" % range) / digitisation), 2), made on
+ * the device from the int16 rows, then scale_outliers + get_segs on the float64 values.  calib[3 r ..] = digitisation,
+ * offset, range of read r (what a fast5 / BLOW5 record carries).  The caller applies [:Num] via len[]. */
+int sk_segment_batch_i16_pa(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads, const double *calib,
+                            const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs);
 /* device-resident form of sk_segment_batch_i16 (all pointers device). */
 int sk_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
                        const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs);

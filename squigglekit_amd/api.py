@@ -207,6 +207,28 @@ def segment_reads_f64(reads, params=None, max_segs=64):
         return [segs[i, :nsegs[i]].tolist() if nsegs[i] else False for i in range(R)]
 
 
+def segment_batch_pa(sig, lens, calib, params=None, max_segs=64):
+    """Raw int16 rows through the pA route (segmenter.py:345-349: fast5 / slow5 input without --raw_signal): the
+    conversion np.round((raw + offset) * (float("%.2f" % range) / digitisation), 2) runs on the GPU, then the float64
+    segmenter path.  calib: float64 [R, 3] = digitisation, offset, range per read.  Returns (segs, nsegs)."""
+    L = _lib.ensure_init()
+    sig = np.ascontiguousarray(sig, dtype=np.int16)
+    R = sig.shape[0]
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    calib = np.ascontiguousarray(calib, dtype=np.float64).reshape(R, 3)
+    params = params or SegParams()
+    while True:
+        segs = np.zeros((max(R, 1), max_segs, 2), dtype=np.int32)
+        nsegs = np.zeros(max(R, 1), dtype=np.int32)
+        rc = L.sk_segment_batch_i16_pa(ptr(sig), sig.shape[1], ptr(lens), R, ptr(calib), C.byref(params), ptr(segs),
+                                       ptr(nsegs), max_segs)
+        if rc == _lib.SK_ERR_OVERFLOW:
+            max_segs = int(nsegs.max()) + 8
+            continue
+        check(rc)
+        return segs[:R], nsegs[:R]
+
+
 def segment_ragged_f64(values, off, lens=None, params=None, max_segs=64):
     """scale_outliers + get_segs for a ragged float64 batch as a tokenizer leaves it: read r is the first lens[r]
     (default: all) of values[off[r]:off[r+1]].  Returns (segs int32 [R, max_segs, 2], nsegs int32 [R])."""

@@ -4,6 +4,8 @@
 #include "sk_common.h"
 #include <math.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -806,6 +808,63 @@ int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads, 
                          int32_t *segs, int32_t *nsegs, int32_t max_segs)
 {
     return sk_segment_batch_f64_len(sig, off, nullptr, nreads, p, segs, nsegs, max_segs);
+}
+
+// Raw reads through the pA route: what segmenter.py does with fast5 / slow5 input unless --raw_signal is given
+// (segmenter.py:345-349, 366-370: np.round(convert_to_pA_numpy(sig, digitisation, range, offset), 2) with range first
+// cut to two decimals, float("{0:.2f}".format(range)), :385) -- made on the device from the int16 rows, then the float64
+// segmenter path.  calib[3 r ..] = digitisation, offset, range of read r (what a fast5 / BLOW5 record carries).
+int sk_segment_batch_i16_pa(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads, const double *calib,
+                            const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    int rc = check_i16(sig, stride, len, nreads);
+    if (rc) return rc;
+    if ((rc = check_len_host(len, nreads, stride))) return rc;
+    if ((rc = check_seg_params(p))) return rc;
+    if (max_segs <= 0) return sk_fail(SK_ERR_INVALID, "max_segs must be positive");
+    if (nreads == 0) return SK_OK;
+    if (!calib || !segs || !nsegs) return sk_fail(SK_ERR_INVALID, "NULL calib/segs/nsegs");
+    std::vector<int64_t> off((size_t)nreads + 1);
+    std::vector<double> cal((size_t)nreads * 2);
+    int64_t maxlen = 0;
+    off[0] = 0;
+    for (int32_t r = 0; r < nreads; r++) {
+        off[r + 1] = off[r] + len[r];
+        if (len[r] > maxlen) maxlen = len[r];
+        const double dig = calib[3 * r], ofs = calib[3 * r + 1], rng = calib[3 * r + 2];
+        char txt[512];
+        snprintf(txt, sizeof txt, "%.2f", rng);              // float("{0:.2f}".format(range))
+        cal[2 * r] = ofs;
+        cal[2 * r + 1] = strtod(txt, nullptr) / dig;         // raw_unit = range / digitisation
+    }
+    const int64_t total = off[nreads];
+    const size_t sb = (size_t)nreads * (size_t)stride * sizeof(int16_t);
+    const size_t gb = (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t);
+    if ((rc = sk_reserve(c, &c->misc, sb))) return rc;
+    if ((rc = sk_reserve(c, &c->sig, (size_t)(total > 0 ? total : 1) * sizeof(double)))) return rc;
+    if ((rc = sk_reserve(c, &c->off, off.size() * sizeof(int64_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->pacal, cal.size() * sizeof(double)))) return rc;
+    if ((rc = sk_reserve(c, &c->out, gb))) return rc;
+    if ((rc = sk_reserve(c, &c->out2, (size_t)nreads * sizeof(int32_t)))) return rc;
+    SK_HIP(hipMemcpyAsync(c->misc.p, sig, sb, hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipMemcpyAsync(c->off.p, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipMemcpyAsync(c->pacal.p, cal.data(), cal.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));                 // off / cal go out of scope
+    rc = sk_launch_rows_to_pa(c, (const int16_t *)c->misc.p, stride, nreads, (const int64_t *)c->off.p,
+                              (const double *)c->pacal.p, (double *)c->sig.p);
+    if (rc) return rc;
+    rc = segment_dev_f64(c, (const double *)c->sig.p, (const int64_t *)c->off.p, nreads, total, maxlen, p,
+                         (int32_t *)c->out.p, (int32_t *)c->out2.p, max_segs);
+    if (rc) return rc;
+    SK_HIP(hipMemcpyAsync(segs, c->out.p, gb, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipMemcpyAsync(nsegs, c->out2.p, (size_t)nreads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    for (int32_t r = 0; r < nreads; r++)
+        if (nsegs[r] > max_segs)
+            return sk_fail(SK_ERR_OVERFLOW, "read %d has %d segments, max_segs is %d", r, nsegs[r], max_segs);
+    return SK_OK;
 }
 
 int sk_segment_dev_f64(const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t total, int64_t max_len,

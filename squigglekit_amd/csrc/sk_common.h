@@ -58,6 +58,7 @@ struct sk_ctx {
     sk_buf out;       // sk_hit / segs staging
     sk_buf out2;      // nsegs staging
     sk_buf misc;
+    sk_buf pacal;     // per read {offset, range / digitisation}: the pA conversion of raw rows (sk_segment_batch_i16_pa)
     sk_buf ckpt;      // DTW checkpoints (systolic state dumps: doubles or fixed-point units)
     sk_buf motifq;    // fixed-point motif layout
     sk_buf motif64;   // the motif laid out for 64 lanes (retry pass of a short motif)
@@ -210,6 +211,9 @@ int sk_launch_synth_windows(sk_ctx *c, int16_t *d_sig, int64_t stride, int32_t n
                             uint64_t seed, int64_t row0, const int16_t *d_tmpl, int32_t ntmpl, float sigma);
 int sk_launch_raw_to_pa(sk_ctx *c, const int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
                         double offset, double raw_unit, double *d_out, int64_t *d_off);
+// ragged form with per-read constants: read r's len = off[r+1] - off[r] samples, cal[2r] = offset, cal[2r+1] = raw unit
+int sk_launch_rows_to_pa(sk_ctx *c, const int16_t *d_sig, int64_t stride, int32_t nreads, const int64_t *d_off,
+                         const double *d_cal, double *d_out);
 
 // ---- float64 reads, streaming statistics (sk_f64stat.hip) + the numpy-order redo of its uncertified reads ----
 bool sk_f64_fast_applies(int64_t maxlen, double std_scale);

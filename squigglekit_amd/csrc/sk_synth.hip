@@ -146,7 +146,35 @@ void k_raw_to_pa(const int16_t *__restrict__ sig, int64_t stride, int nreads, in
         off[r] = r * nsamples;
 }
 
+// the same conversion for a batch of raw rows with their own channel constants (what segmenter.py:345-349 / :366-370 do
+// read by read for fast5 / slow5 input): read r -> out[off[r] .. off[r+1])
+__global__ __launch_bounds__(256)
+void k_rows_to_pa(const int16_t *__restrict__ sig, int64_t stride, int nreads, const int64_t *__restrict__ off,
+                  const double *__restrict__ cal, double *__restrict__ out)
+{
+    for (int r = blockIdx.x; r < nreads; r += gridDim.x) {
+        const int64_t o0 = off[r];
+        const int n = (int)(off[r + 1] - o0);
+        const double offset = cal[2 * r], unit = cal[2 * r + 1];
+        const int16_t *row = sig + (int64_t)r * stride;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const double v = ((double)row[i] + offset) * unit;
+            out[o0 + i] = rint(v * 100.0) / 100.0;
+        }
+    }
+}
+
 } // namespace
+
+int sk_launch_rows_to_pa(sk_ctx *c, const int16_t *d_sig, int64_t stride, int32_t nreads, const int64_t *d_off,
+                         const double *d_cal, double *d_out)
+{
+    if (nreads <= 0) return SK_OK;
+    const int grid = nreads < c->num_cu * 16 ? nreads : c->num_cu * 16;
+    hipLaunchKernelGGL(k_rows_to_pa, dim3(grid), dim3(256), 0, c->stream, d_sig, stride, nreads, d_off, d_cal, d_out);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
+}
 
 int sk_launch_raw_to_pa(sk_ctx *c, const int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
                         double offset, double raw_unit, double *d_out, int64_t *d_off)

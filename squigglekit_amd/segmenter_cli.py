@@ -126,6 +126,22 @@ class _Batcher:
         if prev is not None:
             self._finish(prev)
 
+    def rows_pa(self, rows, nsamp, calib, name_col, name_of):
+        """A block of raw reads with their channel constants (BLOW5 records without --raw_signal): the pA conversion the
+        reference applies to fast5 / slow5 input (segmenter.py:345-349) runs on the GPU, then the float64 path; one batch,
+        one native table, pipelined like rows()."""
+        if not len(nsamp):
+            return
+        Num = self.args.Num
+        lens = (np.maximum(nsamp + Num, 0) if Num < 0 else np.minimum(nsamp, Num)).astype(np.int32)   # sig[:Num]
+        if self._worker is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._worker = ThreadPoolExecutor(1)
+        job = self._worker.submit(api.segment_batch_pa, rows, lens, calib, self.params)
+        prev, self._pending = self._pending, (job, len(nsamp), name_col, name_of)
+        if prev is not None:
+            self._finish(prev)
+
     def rows_f64(self, fb):
         """A chunk of plain decimal (pA) lines as the float64 tokenizer leaves it (tsvio.FloatBlock: flat values +
         offsets): one GPU batch -- the sig[:Num] cut rides along as per-read lengths, nothing is repacked --, one
@@ -284,6 +300,28 @@ def main(argv=None):
                 out.rows(part, ns, ("i32", np.arange(lo, lo + part.shape[0], dtype=np.int32)), lambda i, lo=lo: str(lo + i))
         except ValueError as e:
             sys.stderr.write("segmenter: --i16: {}\n".format(e))
+            sys.exit(1)
+    elif args.blow5 and not args.test:
+        # pA (the reference's default for fast5 / slow5 input): records decoded natively into int16 rows + channel
+        # constants, converted on the GPU
+        seen = 0
+        try:
+            for blk in fastio.iter_blow5_blocks_i16(args.blow5, keep=_KEEP):
+                ok = np.flatnonzero((blk.flags & 2) == 0)
+                for i in np.flatnonzero(blk.flags & 2):
+                    sys.stderr.write("segmenter: unreadable BLOW5 record {} in {}; skipped\n".format(seen + int(i), args.blow5))
+                seen += blk.n
+                if ok.size != blk.n:
+                    blk = fastio.Blow5Block(blk.rows[ok], blk.nsamp[ok], blk.ids[ok], blk.calib[ok], blk.flags[ok])
+                w = blk.ids.dtype.itemsize
+                st = np.arange(blk.n, dtype=np.int64) * w
+                out.rows_pa(blk.rows, blk.nsamp, blk.calib,
+                            ("span", blk.ids, np.stack([st, st + np.char.str_len(blk.ids)], axis=1)),
+                            lambda i, b=blk: b.ids[i].decode())
+        except ValueError as e:
+            out.drain()
+            out.flush()
+            sys.stderr.write("segmenter: --blow5: {}\n".format(e))
             sys.exit(1)
     elif args.blow5:
         from .blow5 import read_blow5, to_pA

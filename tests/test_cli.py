@@ -153,6 +153,13 @@ def oracle_backend(monkeypatch, ora):
         reads = [np.asarray(values[off[r]:off[r + 1]]) for r in range(len(off) - 1)]
         return [mot_any(reads, m, scale, lo, hi) for m in motifs]
 
+    def seg_pa(sig, lens, calib, params=None, max_segs=64):
+        from squigglekit_amd.blow5 import to_pA
+        reads = [to_pA(np.asarray(sig[r, :lens[r]]), calib[r][0], calib[r][1], calib[r][2]) for r in range(len(lens))]
+        off = np.concatenate([[0], np.cumsum([x.size for x in reads])]).astype(np.int64)
+        return seg_ragged(np.concatenate(reads) if reads else np.zeros(0), off, None, params, max_segs)
+
+    monkeypatch.setattr(api, "segment_batch_pa", seg_pa)
     monkeypatch.setattr(api, "segment_ragged_f64", seg_ragged)
     monkeypatch.setattr(api, "motifseq_multi_ragged_f64", mot_ragged)
     monkeypatch.setattr(api, "segment_batch", seg_batch)
@@ -501,3 +508,38 @@ def test_pa_tsv_block_route(gpu, ora, tmp_path):
     for r in (0, 5, 17, 99, R - 1):
         d, s0, e0 = ora.dtw_subsequence(motif, ora.medmad(ora.scale_outliers(pa[r], 0, 1200))[0])
         assert rows[r][1] == "id%d" % r and (int(rows[r][3]), int(rows[r][4]), float(rows[r][6])) == (s0, e0, d), r
+
+
+@pytest.mark.gpu
+def test_blow5_default_pa_route_on_gpu(gpu, ora, tmp_path):
+    """`segmenter.py --blow5 x` without --raw_signal works in pA like the reference does for fast5 / slow5 input
+    (segmenter.py:345-349): records decoded natively, np.round((raw + offset) * (float("%.2f" % range) / digitisation), 2)
+    made on the GPU (sk_segment_batch_i16_pa), float64 segmenter -- the table must be what the record-by-record Python
+    route (kept for -u) prints, and the reference arithmetic restated by blow5.to_pA + the oracle."""
+    from squigglekit_amd import blow5, fastio, synth
+    from squigglekit_amd.segmenter_cli import main as smain
+    R, M = 300, 3000
+    sig = synth.squiggle_batch(R, M, 4711)
+    ids = ["read-%04d" % i for i in range(R)]
+    path = str(tmp_path / "r.blow5")
+    fastio.write_blow5(path, sig, ids)
+    got, err, code = run_cli(smain, ["--blow5", path])
+    assert code == 0, err[-300:]
+    want = []
+    for rec in blow5.read_blow5(path):
+        pa = blow5.to_pA(rec["signal"].astype(int), rec["digitisation"], rec["offset"], rec["range"])[:-1]
+        segs = ora.get_segs(ora.scale_outliers(pa, 0, 900))
+        if segs:
+            want.append("%s\t%s" % (rec["read_id"], ",".join(str(v) for p in segs for v in p)))
+    assert got.strip().split("\n") == want and len(want) > R // 2
+    slow, _, code = run_cli(smain, ["--blow5", path, "-u"])              # per-read checks: the record-by-record route
+    assert code == 0 and slow == got
+    # odd channel constants: a range whose two-decimal cut matters, a float offset
+    from squigglekit_amd import api
+    calib = np.array([[8192.0, 10.0, 1467.6149], [2048.0, -3.5, 748.58496], [8192.0, 0.0, 1200.005]])
+    lens = np.array([M, M - 7, 1], dtype=np.int32)
+    segs, nsegs = api.segment_batch_pa(sig[:3], lens, calib)
+    for r in range(3):
+        pa = blow5.to_pA(sig[r, :lens[r]].astype(int), *[calib[r][k] for k in (0, 1, 2)])
+        w = ora.get_segs(ora.scale_outliers(pa, 0, 900)) or []
+        assert segs[r, :nsegs[r]].tolist() == w, r
