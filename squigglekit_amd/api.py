@@ -266,6 +266,24 @@ def motifseq_multi_ragged_f64(values, off, motifs, scale="medmad", scale_low=0, 
     return out
 
 
+def drna_segment_batch(sig, lens, params=None, max_segs=32):
+    """dRNA_segmenter.py's slow5 branch for every row of an int16 [R, stride] batch: (segs int32 [R, max_segs, 2], nsegs)."""
+    L = _lib.ensure_init()
+    sig = np.ascontiguousarray(sig, dtype=np.int16)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    params = params or _lib.DrnaParams()
+    R = sig.shape[0]
+    while True:
+        segs = np.zeros((max(R, 1), max_segs, 2), dtype=np.int32)
+        nsegs = np.zeros(max(R, 1), dtype=np.int32)
+        rc = L.sk_drna_segment_batch_i16(ptr(sig), sig.shape[1], ptr(lens), R, C.byref(params), ptr(segs), ptr(nsegs), max_segs)
+        if rc == _lib.SK_ERR_OVERFLOW:
+            max_segs = int(nsegs.max()) + 8
+            continue
+        check(rc)
+        return segs[:R], nsegs[:R]
+
+
 def drna_segment_reads(reads, params=None, max_segs=32):
     """dRNA_segmenter.py's slow5-branch per-read work (scale_outliers, window statistics, scan)
     for a list of raw integer reads: per read the list of [start, end] collected before the scan

@@ -12,6 +12,8 @@ would; `--strict-compat` reproduces the reference's failure instead."""
 import argparse
 import sys
 
+import numpy as np
+
 from . import api
 
 
@@ -97,6 +99,23 @@ def main(argv=None):
         ids.clear()
         sigs.clear()
 
+    with open(args.slow5, "rb") as fh:
+        binary = fh.read(6) == b"BLOW5\x01"
+    if binary:
+        # BLOW5: records decoded natively into int16 rows, a block (16 384 reads) per GPU call
+        from . import fastio
+        from ._lib import DrnaParams
+        try:
+            for blk in fastio.iter_blow5_blocks_i16(args.slow5):
+                for i in np.flatnonzero(blk.flags & 2):
+                    sys.stderr.write("dRNA_segmenter: unreadable BLOW5 record in {}; skipped\n".format(args.slow5))
+                segs, nsegs = api.drna_segment_batch(blk.rows, blk.nsamp, DrnaParams())
+                for i in np.flatnonzero((nsegs > 0) & ((blk.flags & 2) == 0)):
+                    print("{}\t{}\t{}".format(blk.ids[i].decode(), segs[i, 0, 0], segs[i, 0, 1]))
+        except ValueError as e:
+            sys.stderr.write("dRNA_segmenter: -f: {}\n".format(e))
+            sys.exit(1)
+        return
     for rec in read_slow5(args.slow5):
         ids.append(rec["read_id"])
         sigs.append(rec["signal"])
