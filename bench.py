@@ -999,9 +999,9 @@ def segmenter_isolated(w, steps=3):
 
 
 def seg_kernel_prof(w, prof, steps):
-    """The timed steps' HIP-event sums, unless the two kernels overlapped in them (large batches go in 4 chunks by
-    default, SK_SEG_CHUNKS overrides): then a short run with the kernels one after the other."""
-    chunks = os.environ.get("SK_SEG_CHUNKS") or ("4" if w.R >= 262144 else "1")
+    """The timed steps' HIP-event sums, unless the two kernels overlapped in them (SK_SEG_CHUNKS > 1; the default is one
+    chunk since the jumping walk, round 4): then a short run with the kernels one after the other."""
+    chunks = os.environ.get("SK_SEG_CHUNKS") or "1"
     if chunks == "1" or w.R < 65536:
         return prof, steps
     return segmenter_isolated(w)
@@ -1012,7 +1012,7 @@ def segmenter_roofline(w, prof, steps, step_ms=None):
     prep_ms, main_ms = prof["prep_ms"] / steps, prof["main_ms"] / steps
     alg_bytes = R * (2 * M + 4 + 8 * 2)
     dominant, dom_ms = ("k_seg_stats (filter + statistics + in-band / kept masks)", prep_ms) if prep_ms >= main_ms \
-        else ("k_seg_walk3 (run-hopping get_segs walk)", main_ms)
+        else ("k_seg_walk4 (run-hopping, jumping get_segs walk)", main_ms)
     per_read, src = traffic_from_profiles("segmenter", "k_seg_stats" if prep_ms >= main_ms else "k_seg_walk")
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
     both = alg_bytes / ((prep_ms + main_ms) * 1e-3) / 1e9
@@ -1027,8 +1027,8 @@ def segmenter_roofline(w, prof, steps, step_ms=None):
             "both_kernels": {"achieved": both, "frac": both / HBM_PEAK_GBS,
                              "note": "the two kernels run one after the other (SK_SEG_CHUNKS=1), HIP-event times added"},
             "whole_step": {"achieved": whole, "frac": whole / HBM_PEAK_GBS, "ms": step_ms,
-                           "note": "as shipped: large batches go in 4 chunks, the walk of one beside the statistics of "
-                                   "the next on a second stream; algorithmic bytes / wall time of the timed step"}}
+                           "note": "as shipped (statistics kernel, then the walk); algorithmic bytes / wall time of the "
+                                   "timed step"}}
 
 
 def extras_single_gpu(a, L, main):

@@ -58,6 +58,7 @@ struct sk_ctx {
     sk_buf out;       // sk_hit / segs staging
     sk_buf out2;      // nsegs staging
     sk_buf misc;
+    sk_buf seghints;  // per read: the stretches of quiet mask entries and their anchors, k_seg_stats -> k_seg_walk4
     sk_buf pacal;     // per read {offset, range / digitisation}: the pA conversion of raw rows (sk_segment_batch_i16_pa)
     sk_buf ckpt;      // DTW checkpoints (systolic state dumps: doubles or fixed-point units)
     sk_buf motifq;    // fixed-point motif layout

@@ -84,6 +84,9 @@ static const sk_tunable SK_TUNABLES[] = {
     {"SK_SEG_CHUNKS",         "2 8",         "segmenter: chunks of a large batch (walk of one beside the statistics of the next)"},
     {"SK_WALK_STEP",          "1",           "segmenter walk: per-sample straight-line step instead of run hopping"},
     {"SK_WALK_GENERAL",       "1",           "segmenter walk: general step (corrector test live)"},
+    {"SK_WALK_SYNC",          "1",           "segmenter walk: run hopping with the 64 lanes of a wavefront on the same word (k_seg_walk3)"},
+    {"SK_WALK_OWNPASS",       "1",           "segmenter walk: finds the quiet stretches and anchors in a pass of its own instead of taking the statistics kernel's hints"},
+    {"SK_WALK_NOJUMP",        "1",           "segmenter walk: every run is hopped through, no jumps between the stretches of quiet entries"},
     {"SK_INGEST_MB",          "1 4",         "sub-batch size of the host entry points in MB"},
     {"SK_F64_OLD",            "1",           "float64 reads: numpy-order statistics kernel for every read"},
 };
@@ -186,7 +189,7 @@ int sk_shutdown(void)
         (void)hipStreamSynchronize(c->stream);
         sk_buf *bufs[] = {&c->sig, &c->len, &c->off, &c->comp, &c->prep, &c->mask,
                           &c->motif, &c->out, &c->out2, &c->misc, &c->ckpt, &c->retry, &c->motifq, &c->lastq, &c->qflag,
-                          &c->motif64, &c->commbuf, &c->dtwcnt, &c->wsoft, &c->wstate, &c->wrec, &c->motifw, &c->lsum, &c->wrecq, &c->order, &c->pacal};
+                          &c->motif64, &c->commbuf, &c->dtwcnt, &c->wsoft, &c->wstate, &c->wrec, &c->motifw, &c->lsum, &c->wrecq, &c->order, &c->pacal, &c->seghints};
         for (sk_buf *b : bufs) free_buf(b);
         for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev[i]);
         for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);

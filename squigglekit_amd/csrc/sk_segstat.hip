@@ -95,6 +95,28 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     return v;
 }
 __device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_incl_scan(v), 63); }
+// inclusive running maximum across the wavefront (unsigned; lanes without a source contribute 0)
+__device__ __forceinline__ unsigned wave_incl_max(unsigned v)
+{
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
+    return v;
+}
+// lane i <- lane i - 1 across the whole wavefront (lane 0 <- 0)
+__device__ __forceinline__ unsigned wave_shr1(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
+}
+
+// Hints for k_seg_walk4, SEG_HINTS dwords per read: [0] = number of stretches of quiet entries (SEG_HINT_NONE: walk
+// this read without jumps), [1 + i] = stretch i: anchor (12 bits) | last entry << 12 (6 bits) | samples dropped before
+// the anchor's entry << 18 (13 bits).
+constexpr int SEG_HINTS = 8;
+constexpr unsigned SEG_HINT_NONE = 255u;
 
 // lane i <- lane i + N inside a row of 16 (lanes without a source get 0)
 template <int N>
@@ -115,6 +137,8 @@ struct SegStatArgs {
     uint4         *mask2;            // [nreads][row16] of {in band lo, hi, kept lo, hi}: 64 raw samples per entry
     int            row16;            // entries per read (8 per 512-sample tile)
     int32_t       *retry;            // [0] = count, [1 ..] = reads that could not be certified
+    unsigned      *hints;            // [nreads][SEG_HINTS] for k_seg_walk4 (reads of up to 4 096 samples), or nullptr
+    int            e1;               // the walk's error + 1 (hints)
 };
 
 // NT: 512-sample tiles held in registers (one "window" of 512 NT samples)
@@ -316,9 +340,44 @@ void k_seg_stats(const SegStatArgs a)
                 p_dr[t * 64 + lane] = (unsigned char)drop8;
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (lane < 8 * ntiles) {
-                const uint2 vi = *(const uint2 *)(p_in + 8 * lane), vd = *(const uint2 *)(p_dr + 8 * lane);
+            const uint2 vi = *(const uint2 *)(p_in + 8 * lane), vd = *(const uint2 *)(p_dr + 8 * lane);
+            if (lane < 8 * ntiles)
                 a.mask2[(int64_t)r * a.row16 + wi * (8 * NT) + lane] = make_uint4(vi.x, vi.y, ~vd.x, ~vd.y);   // {in band, kept}
+            if (!LONG && a.hints) {
+                // What k_seg_walk4 would otherwise read the whole mask row for (see there): lane e holds entry e, so
+                // the stretches of quiet entries, their anchors and the drop counts are a few wave-wide operations.
+                const int nent = (M + 63) >> 6;
+                const bool has = lane < nent;
+                const unsigned klo = has ? ~vd.x : 0u, khi = has ? ~vd.y : 0u;
+                const unsigned olo = vi.x & klo, ohi = vi.y & khi;           // kept and in band
+                const unsigned zlo = ~vi.x & klo, zhi = ~vi.y & khi;         // kept and out of band
+                const bool quiet = has && __builtin_popcount(zlo) + __builtin_popcount(zhi) < a.e1;
+                const int dcnt = has ? 64 - __builtin_popcount(klo) - __builtin_popcount(khi) : 0;
+                const int dcum = wave_incl_scan(dcnt) - dcnt;                // samples dropped before my entry
+                // bit i of (alo, ahi): the e1 samples before sample i of my entry are all kept and out of band
+                const unsigned zprev = wave_shr1(zhi);
+                unsigned alo = ~0u, ahi = ~0u;
+                for (int j = 1; j <= a.e1; j++) {
+                    alo &= __builtin_amdgcn_alignbit(zlo, zprev, 32 - j);
+                    ahi &= __builtin_amdgcn_alignbit(zhi, zlo, 32 - j);
+                }
+                alo &= olo; ahi &= ohi;
+                unsigned key = 0u;                                           // newest anchor of my entry << 16 | dcum
+                if (alo | ahi)
+                    key = ((unsigned)(64 * lane + (ahi ? 63 - __builtin_clz(ahi) : 31 - __builtin_clz(alo))) << 16) | (unsigned)dcum;
+                const unsigned akey = wave_shr1(wave_shr1(wave_incl_max(key)));   // newest anchor in entries <= mine - 2 (none: sample 0)
+                const unsigned long long Qm = __ballot(quiet);
+                const bool rise = quiet && wave_shr1(quiet ? 1u : 0u) == 0u;
+                const unsigned long long Rm = __ballot(rise);
+                const int cnt = __builtin_popcountll(Rm);
+                if (rise) {
+                    const unsigned long long nq = ~Qm >> lane;               // (bit 0 clear: I am quiet)
+                    const int kb = nq ? lane + (int)__builtin_ctzll(nq) - 1 : 63;
+                    const int idx = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(Rm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Rm, 0u));
+                    if (idx < SEG_HINTS - 1)
+                        a.hints[(int64_t)r * SEG_HINTS + 1 + idx] = (akey >> 16) | ((unsigned)kb << 12) | ((akey & 0xffffu) << 18);
+                }
+                if (lane == 0) a.hints[(int64_t)r * SEG_HINTS] = (certified && cnt <= SEG_HINTS - 1) ? (unsigned)cnt : SEG_HINT_NONE;
             }
         }
     }
@@ -497,6 +556,27 @@ void k_seg_walk2(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
 // and the scan resumes behind z.  So a lane hops from run to run with bit scans (find-first-set, popcount,
 // clear-lowest-set) on 32-bit pieces of its read's in-band mask instead of stepping through every sample:
 // ~200 runs instead of 4 000 samples per read, 3-4x fewer vector instructions (the kernel is issue-bound).
+// An entry's in-band bits with the dropped samples' bits deleted (the filter drops a handful of samples per read, so
+// the loop runs a few times per READ); returns the samples kept.
+__device__ __forceinline__ int squeeze_entry(unsigned long long &inb, unsigned long long kp)
+{
+    int cnt = 64;
+    if (kp != ~0ull) {
+        if (kp == 0ull) { cnt = 0; kp = ~0ull; }
+        const int hz = __builtin_clzll(kp);                    // dropped samples at the top of the entry go at once
+        if (hz > 0) { cnt -= hz; kp |= ~0ull << (64 - hz); }
+        while (kp != ~0ull) {                                  // delete the lowest dropped sample's bit, close the gap
+            const int pos = __builtin_ctzll(~kp);
+            const unsigned long long below = (1ull << pos) - 1ull;
+            inb = (inb & below) | ((inb >> 1) & ~below);
+            kp = (kp & below) | ((kp >> 1) & ~below) | (1ull << 63);
+            cnt--;
+        }
+        if (cnt < 64) inb &= (1ull << cnt) - 1ull;
+    }
+    return cnt;
+}
+
 struct RunState {
     int in_run, zl, start, last1;     // zl: out-of-band samples the open run still needs to close
     int nseg, last_end;
@@ -546,25 +626,14 @@ __device__ __forceinline__ void run_word32(RunState &st, unsigned W, int base, i
     }
 }
 
-__global__ __launch_bounds__(64)
-void k_seg_walk3(const uint4 *__restrict__ mask2, int row16, const int32_t *__restrict__ len, int64_t stride,
-                 int nreads, WalkParams p, int32_t *__restrict__ segs, int32_t *__restrict__ nsegs, int max_segs)
+// one lane's read, the wavefront's lanes on the same entry (nmax: the longest read's entries); returns the segment count
+__device__ __forceinline__ int walk_sync_read(const uint4 *__restrict__ mrow, int nent, int nmax, const WalkParams &p,
+                                              int32_t *my, int max_segs)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = r < nreads;
-    const int M = live ? min(max(len[r], 0), (int)min(stride, (int64_t)row16 * 64)) : 0;
-    const uint4 *mrow = mask2 + (int64_t)(live ? r : 0) * row16;
-    int32_t *my = segs + (int64_t)(live ? r : 0) * 2 * max_segs;
-
     RunState st;
     st.in_run = 0; st.zl = 0; st.start = 0; st.last1 = 0; st.nseg = 0; st.last_end = 0;
     st.thr = (unsigned)min(p.window, p.first_len);
     const int E1 = max(p.error, 0) + 1;
-
-    const int nent = (M + 63) >> 6;               // my entries
-    int nmax = nent;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d));
 
     unsigned long long qlo = 0ull, qhi = 0ull;    // bit queue: `fill` bits, oldest at bit 0 of qlo
     int fill = 0, done = 0;                       // done: filtered samples already walked
@@ -579,21 +648,7 @@ void k_seg_walk3(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
             if (e0 + k >= nmax) break;            // (wave-uniform)
             if (e0 + k < nent) {
                 unsigned long long inb = ((unsigned long long)buf[k].y << 32) | buf[k].x;
-                unsigned long long kp = ((unsigned long long)buf[k].w << 32) | buf[k].z;
-                int cnt = 64;
-                if (kp != ~0ull) {                // the filter dropped samples here: squeeze their bits out
-                    if (kp == 0ull) { cnt = 0; kp = ~0ull; }
-                    const int hz = __builtin_clzll(kp);        // dropped samples at the top of the entry go at once
-                    if (hz > 0) { cnt -= hz; kp |= ~0ull << (64 - hz); }
-                    while (kp != ~0ull) {         // delete the lowest dropped sample's bit, close the gap
-                        const int pos = __builtin_ctzll(~kp);
-                        const unsigned long long below = (1ull << pos) - 1ull;
-                        inb = (inb & below) | ((inb >> 1) & ~below);
-                        kp = (kp & below) | ((kp >> 1) & ~below) | (1ull << 63);
-                        cnt--;
-                    }
-                    if (cnt < 64) inb &= (1ull << cnt) - 1ull;
-                }
+                int cnt = squeeze_entry(inb, ((unsigned long long)buf[k].w << 32) | buf[k].z);
                 if (fill == 0) { qlo = inb; qhi = 0ull; }
                 else { qlo |= inb << fill; qhi = inb >> (64 - fill); }
                 fill += cnt;
@@ -613,14 +668,241 @@ void k_seg_walk3(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
         run_word32(st, (unsigned)w, done, E1, p, my, max_segs);
         run_word32(st, (unsigned)(w >> 32), done + 32, E1, p, my, max_segs);
     }
+    return st.nseg;
+}
+
+__global__ __launch_bounds__(64)
+void k_seg_walk3(const uint4 *__restrict__ mask2, int row16, const int32_t *__restrict__ len, int64_t stride,
+                 int nreads, WalkParams p, int32_t *__restrict__ segs, int32_t *__restrict__ nsegs, int max_segs)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r < nreads;
+    const int M = live ? min(max(len[r], 0), (int)min(stride, (int64_t)row16 * 64)) : 0;
+    const uint4 *mrow = mask2 + (int64_t)(live ? r : 0) * row16;
+    int32_t *my = segs + (int64_t)(live ? r : 0) * 2 * max_segs;
+    const int nent = (M + 63) >> 6;               // my entries
+    int nmax = nent;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+    const int ns = walk_sync_read(mrow, nent, nmax, p, my, max_segs);
+    if (live) nsegs[r] = ns;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// the walk by runs with every lane at ITS OWN position, jumping between the places that can matter
+// (same preconditions as k_seg_walk3, plus window >= 127 and error <= 31)
+// ------------------------------------------------------------------------------------------------------
+// k_seg_walk3 keeps its 64 lanes on the same 32-sample word (a lane leaves run_word32's loop after (runs closing in
+// the word) + 1 trips, the wavefront after the slowest lane's) and squeezes the dropped samples' bits out of every
+// entry to get there.  This kernel stays in RAW sample coordinates -- a dropped sample is neither in band nor out of
+// band, it is skipped and counted -- and lets every lane hop from run to run on a 64-sample window taken at its own
+// position out of the two mask entries it holds in registers: one trip per run, plus one per 64 samples of a long run.
+//
+// Jumps.  Once a read has its first segment only runs of c >= window samples count (:448).  Such a run [s, z) spans
+// >= 127 raw samples, so it covers the aligned entry k1 = ceil(s / 64) completely -- an entry with <= E out-of-band
+// samples, "quiet".  A first pass over the read's entries (uniform across the wavefront, ~40 instructions per entry) notes
+// every stretch [ka, kb] of quiet entries together with an ANCHOR: the newest position <= 64 (ka - 1) at which the state
+// of the chain is known without walking it -- an in-band sample whose E + 1 raw predecessors are all kept and out of
+// band opens a run whatever came before (a run open there has closed inside them, the scan was idle behind it), or
+// sample 0 -- and the number of samples dropped before the anchor's entry.  Every run of interest that opens in a stretch
+// (s in (64 (ka - 1), 64 kb]) opens at or behind the stretch's anchor, and no anchor lies inside a run with E
+// out-of-band samples.  So an idle lane whose read has a segment drops the stretches that end before its position and
+// continues at max(position, next stretch's anchor); with no stretch ahead it is done.  A read with more stretches than
+// the list holds is walked without jumps.
+// Positions: start = z_f - c and end = z_f - prev_err (:449), z_f = z - (samples dropped before z), c = (z - s) -
+// (samples dropped inside the run), prev_err = the out-of-band samples since the run's last in-band one.
+constexpr int W4_ITEMS = 8;            // stretches noted per read
+
+template <int E1C>                     // E + 1 at compile time (0: at run time)
+__global__ __launch_bounds__(64)
+void k_seg_walk4(const uint4 *__restrict__ mask2, int row16, const int32_t *__restrict__ len, int64_t stride,
+                 int nreads, WalkParams p, int32_t *__restrict__ segs, int32_t *__restrict__ nsegs, int max_segs,
+                 int use_jumps, const unsigned *__restrict__ hints)
+{
+    __shared__ unsigned w4_items[2 * W4_ITEMS * 64];
+    const int lane = threadIdx.x;
+    unsigned *items = w4_items + lane;                         // stretch i: items[128 i] = anchor | kb << 16, items[128 i + 64] = drops
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r < nreads;
+    const int M = live ? min(max(len[r], 0), (int)min(stride, (int64_t)row16 * 64)) : 0;
+    const uint4 *mrow = mask2 + (int64_t)(live ? r : 0) * row16;
+    int32_t *my = segs + (int64_t)(live ? r : 0) * 2 * max_segs;
+    const int E1 = E1C ? E1C : max(p.error, 0) + 1;
+
+    const int nent = (M + 63) >> 6;
+    int nmax = nent;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+
+    // ---- first pass: quiet stretches, anchors ----
+    int nitems = 0;
+    const unsigned *myhints = hints + (int64_t)(live ? r : 0) * SEG_HINTS;   // (the statistics kernel's, when it wrote any)
+    if (hints) {
+        nitems = live ? (int)myhints[0] : 0;                   // SEG_HINT_NONE: more than W4_ITEMS, no jumps
+    } else if (use_jumps) {
+        int dcum = 0, anchor = 0, anchor_d = 0, anchor_prev = 0, anchor_prev_d = 0, quiet_prev = 0;
+        unsigned zprev = 0u, cur_anchor = 0u;  // zprev: the previous entry's upper 32 out-of-band bits (before the read: none)
+        unsigned t1prev = 0u, t2prev = 0u;
+        for (int e0 = 0; e0 < nmax; e0 += 8) {
+            // eight entries = one 128-byte line of my row per visit (the rows of a wave's 64 lanes are 1 KB apart)
+            uint4 buf[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) buf[k] = (e0 + k < nent) ? mrow[e0 + k] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (e0 + k >= nmax) break;                     // (wave-uniform)
+                const unsigned olo = buf[k].x & buf[k].z, ohi = buf[k].y & buf[k].w;       // kept and in band
+                const unsigned zlo = ~buf[k].x & buf[k].z, zhi = ~buf[k].y & buf[k].w;     // kept and out of band
+                const int quiet = (e0 + k < nent) && __builtin_popcount(zlo) + __builtin_popcount(zhi) < E1;
+                if (quiet) {
+                    if (!quiet_prev) {
+                        cur_anchor = (unsigned)anchor_prev;
+                        if (nitems < W4_ITEMS) items[128 * nitems + 64] = (unsigned)anchor_prev_d;
+                        nitems++;
+                    }
+                    if (nitems <= W4_ITEMS) items[128 * (nitems - 1)] = cur_anchor | ((unsigned)(e0 + k) << 16);
+                }
+                quiet_prev = quiet;
+                anchor_prev = anchor; anchor_prev_d = anchor_d;
+                // bit i of (alo, ahi): the E1 samples before sample i of this entry are all kept and out of band
+                unsigned alo, ahi;
+                if (E1C == 6) {
+                    // by doubling: t1 = the sample before, t2 = the two before, then four, then six (t1 / t2 of the
+                    // previous entry's upper half ride along)
+                    const unsigned t1lo = __builtin_amdgcn_alignbit(zlo, zprev, 31), t1hi = __builtin_amdgcn_alignbit(zhi, zlo, 31);
+                    const unsigned t2lo = t1lo & __builtin_amdgcn_alignbit(t1lo, t1prev, 31), t2hi = t1hi & __builtin_amdgcn_alignbit(t1hi, t1lo, 31);
+                    const unsigned t4lo = t2lo & __builtin_amdgcn_alignbit(t2lo, t2prev, 30), t4hi = t2hi & __builtin_amdgcn_alignbit(t2hi, t2lo, 30);
+                    alo = t4lo & __builtin_amdgcn_alignbit(t2lo, t2prev, 28);
+                    ahi = t4hi & __builtin_amdgcn_alignbit(t2hi, t2lo, 28);
+                    t1prev = t1hi; t2prev = t2hi;
+                } else {
+                    alo = ~0u; ahi = ~0u;
+                    for (int j = 1; j <= E1; j++) {
+                        alo &= __builtin_amdgcn_alignbit(zlo, zprev, 32 - j);
+                        ahi &= __builtin_amdgcn_alignbit(zhi, zlo, 32 - j);
+                    }
+                }
+                alo &= olo; ahi &= ohi;
+                if (alo | ahi) {
+                    anchor = 64 * (e0 + k) + (ahi ? 63 - __builtin_clz(ahi) : 31 - __builtin_clz(alo));
+                    anchor_d = dcum;
+                }
+                zprev = zhi;
+                dcum += 64 - __builtin_popcount(buf[k].z) - __builtin_popcount(buf[k].w);
+            }
+        }
+    }
+    const bool jumps = use_jumps && nitems <= (hints ? SEG_HINTS - 1 : W4_ITEMS);
+    // stretch i: its anchor, last entry, samples dropped before the anchor's entry
+    auto stretch = [&](int i, int &a, int &kb, int &d) __attribute__((always_inline)) {
+        if (hints) { const unsigned h = myhints[1 + i]; a = (int)(h & 0xfffu); kb = (int)((h >> 12) & 63u); d = (int)(h >> 18); }
+        else { const unsigned h = items[128 * i]; a = (int)(h & 0xffffu); kb = (int)(h >> 16); d = (int)items[128 * i + 64]; }
+    };
+    int item = 0;
+
+    // ---- the walk ----
+    RunState st;                                               // (last1 holds prev_err here)
+    st.in_run = 0; st.zl = 0; st.start = 0; st.last1 = 0; st.nseg = 0; st.last_end = 0;
+    st.thr = (unsigned)min(p.window, p.first_len);
+    int pos = 0, ce = -2, dcur = 0, jump_d = 0, rundrops = 0;
+    unsigned long long Oc = 0ull, Zc = 0ull, On = 0ull, Zn = 0ull;
+    while (true) {
+        bool act = pos < M;
+        if (act && jumps && !st.in_run && st.nseg > 0) {
+            int a = 0, kb = 0, d = 0;
+            bool found = false;
+            while (item < nitems) {
+                stretch(item, a, kb, d);
+                if (kb * 64 + 63 >= pos) { found = true; break; }
+                item++;
+            }
+            if (found) {
+                if (a > pos) { pos = a; jump_d = d; ce = -2; }
+            } else {
+                pos = M; act = false;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+        if (!act) continue;
+        const int e = pos >> 6;
+        if (e != ce) {                                         // the two entries my window lies in
+            if (e == ce + 1) { dcur += 64 - __builtin_popcountll(Oc | Zc); Oc = On; Zc = Zn; }
+            else {
+                const uint4 v = mrow[e];                       // (e < nent: pos < M)
+                Oc = ((unsigned long long)(v.y & v.w) << 32) | (v.x & v.z);
+                Zc = ((unsigned long long)(~v.y & v.w) << 32) | (~v.x & v.z);
+                dcur = jump_d;
+            }
+            const uint4 v = (e + 1 < nent) ? mrow[e + 1] : make_uint4(0u, 0u, 0u, 0u);
+            On = ((unsigned long long)(v.y & v.w) << 32) | (v.x & v.z);
+            Zn = ((unsigned long long)(~v.y & v.w) << 32) | (~v.x & v.z);
+            ce = e;
+        }
+        const int sh = pos & 63;
+        unsigned long long Ow = (Oc >> sh) | ((On << 1) << (63 - sh));
+        unsigned long long Zw = (Zc >> sh) | ((Zn << 1) << (63 - sh));
+        int V = 64;
+        if (!st.in_run) {
+            if (Ow == 0ull) { pos += 64; continue; }
+            const int t = __builtin_ctzll(Ow);
+            pos += t; Ow >>= t; Zw >>= t; V -= t;
+            st.in_run = 1; st.start = pos; st.zl = E1; st.last1 = 0; rundrops = 0;
+        }
+        // One piece of the run: up to its closing sample (the zl-th out-of-band one of the window) or, when the
+        // run outlives the window, all V samples of it.  Both cases share the bookkeeping below.
+        const unsigned long long Z = Zw & ((2ull << (V - 1)) - 1ull);
+        const int nz = __builtin_popcountll(Z);
+        const bool closes = nz >= st.zl;
+        unsigned long long Zk = Z;
+        const int kth = closes ? st.zl : 1;
+        for (int i = 1; i < kth; i++) Zk &= Zk - 1ull;
+        const int L = closes ? (int)__builtin_ctzll(Zk) : V;                  // samples of the piece (without the closing one)
+        const int zeros = closes ? st.zl - 1 : nz;                           // out-of-band samples in it
+        const unsigned long long below = (L == 64) ? ~0ull : ((1ull << L) - 1ull);
+        const unsigned long long ones = Ow & below;
+        rundrops += L - zeros - __builtin_popcountll(ones);                  // neither in band nor out of band: dropped
+        if (ones) st.last1 = zeros - __builtin_popcountll(Z & below & ((2ull << (63 - __builtin_clzll(ones))) - 1ull));
+        else st.last1 += zeros;                                              // prev_err (:445, :449)
+        st.zl -= zeros;
+        if (closes) {
+            const int z = pos + L;
+            const int c = (z - st.start) - rundrops;
+            if ((unsigned)c >= st.thr) {                       // :448-454, in filtered coordinates
+                const int off = z - 64 * ce;                   // z lies in one of my two entries
+                const unsigned long long dc = ~(Oc | Zc), dn = ~(On | Zn);
+                const int dz = dcur + (off >= 64 ? __builtin_popcountll(dc) + __builtin_popcountll(dn & ((1ull << (off - 64)) - 1ull))
+                                                 : __builtin_popcountll(dc & ((1ull << off) - 1ull)));
+                const int zf = z - dz;
+                run_report(st, zf - c, zf - st.last1, p, my, max_segs);
+            }
+            st.in_run = 0;
+            pos = z + 1;
+        } else pos += V;
+    }
     if (live) nsegs[r] = st.nseg;
 }
 
+// k_seg_walk4's preconditions (else: k_seg_walk3 / k_seg_walk2)
+bool walk_jumps_apply(const WalkParams &wp, bool fast, bool by_runs, int row16)
+{
+    return fast && by_runs && wp.error < 32 && wp.window >= 127 && (int64_t)row16 * 64 <= 65536 &&
+           sk_tune("SK_WALK_SYNC") == nullptr;
+}
+
 void launch_walk(hipStream_t ws, const uint4 *mask2, int row16, const int32_t *len, int64_t stride, int nr,
-                 const WalkParams &wp, bool fast, bool by_runs, int32_t *d_segs, int32_t *d_nsegs, int max_segs)
+                 const WalkParams &wp, bool fast, bool by_runs, int32_t *d_segs, int32_t *d_nsegs, int max_segs,
+                 const unsigned *d_hints = nullptr)
 {
     const int wgrid = (nr + 63) / 64;
-    if (fast && by_runs)
+    if (walk_jumps_apply(wp, fast, by_runs, row16)) {
+        const int use_jumps = sk_tune("SK_WALK_NOJUMP") == nullptr;
+        if (wp.error == 5)
+            hipLaunchKernelGGL(k_seg_walk4<6>, dim3(wgrid), dim3(64), 0, ws, mask2, row16, len, stride, nr, wp, d_segs,
+                               d_nsegs, max_segs, use_jumps, use_jumps ? d_hints : nullptr);
+        else
+            hipLaunchKernelGGL(k_seg_walk4<0>, dim3(wgrid), dim3(64), 0, ws, mask2, row16, len, stride, nr, wp, d_segs,
+                               d_nsegs, max_segs, use_jumps, use_jumps ? d_hints : nullptr);
+    } else if (fast && by_runs)
         hipLaunchKernelGGL(k_seg_walk3, dim3(wgrid), dim3(64), 0, ws, mask2, row16, len, stride, nr, wp, d_segs, d_nsegs,
                            max_segs);
     else if (fast)
@@ -711,7 +993,9 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
     // workgroups per CU (78 VGPRs x 24 waves) nothing else fits and the overlap gained nothing (round 2: 3.35 / 3.33 /
     // 3.38 / 3.78 ms for 1 / 2 / 4 / 8 chunks); with four workgroups per CU the statistics kernel is as fast (it is
     // co-limited by HBM) and the step drops from 2.89 to 2.70 ms per 1 M reads (round 3, same box).
-    int nchunks = nreads >= 262144 ? 4 : 1;
+    // (round 4) k_seg_walk4 takes a fifth of the statistics kernel's time and gains nothing beside it (1 / 2 / 3 / 4 / 6
+    // chunks: 2.53 / 2.56 / 2.57 / 2.58 / 2.60 ms per 1 M reads): one chunk; the older walks keep the four.
+    int nchunks = nreads >= 262144 && !walk_jumps_apply(wp, fast, by_runs, a.row16) ? 4 : 1;
     if (const char *e = sk_tune("SK_SEG_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 8) nchunks = v; }
     if (nreads < 65536) nchunks = 1;
     if (nchunks > 1 && !c->stream2) {
@@ -722,6 +1006,13 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
     if (const char *e = sk_tune("SK_PREP_ROUNDS")) { int v = atoi(e); if (v > 0) rounds = v; }
     if (const char *e = sk_tune("SK_PREP_PERCU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }
 
+    // the walk's hints come out of the statistics kernel (reads of up to 4 096 samples, the jumping walk)
+    a.hints = nullptr; a.e1 = (p->error > 0 ? p->error : 0) + 1;
+    if (walk_jumps_apply(wp, fast, by_runs, a.row16) && stride <= 4096 && sk_tune("SK_WALK_OWNPASS") == nullptr) {
+        if (int rch = sk_reserve(c, &c->seghints, (size_t)nreads * SEG_HINTS * sizeof(unsigned))) return rch;
+        a.hints = (unsigned *)c->seghints.p;
+    }
+    unsigned *const hints0 = a.hints;
     SK_HIP(hipMemsetAsync(d_retry, 0, ((size_t)nreads + 16) * sizeof(int32_t), c->stream));
     SK_HIP(hipEventRecord(c->ev[0], c->stream));
     if (nchunks > 1) {                                             // the second stream starts behind the memsets
@@ -736,6 +1027,7 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
         int32_t *retry = d_retry + r0 + ci;
         a.sig = d_sig + (int64_t)r0 * stride; a.len = d_len + r0; a.nreads = nr;
         a.prep = d_prep + r0; a.mask2 = (uint4 *)d_mask2 + (int64_t)r0 * a.row16; a.retry = retry;
+        a.hints = hints0 ? hints0 + (int64_t)r0 * SEG_HINTS : nullptr;
         // persistent grid: a whole number of "rounds" of what the chip actually holds (6 workgroups per CU at 78
         // VGPRs, not the 8 the thread limit allows) -- with 8 assumed the last round ran a third full
         int resident = per_cu;
@@ -768,7 +1060,7 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
             SK_HIP(hipEventRecord(c->ev[2], c->stream));
         }
         launch_walk(ws, (const uint4 *)a.mask2, a.row16, a.len, stride, nr, wp, fast, by_runs,
-                    d_segs + (int64_t)r0 * 2 * max_segs, d_nsegs + r0, max_segs);
+                    d_segs + (int64_t)r0 * 2 * max_segs, d_nsegs + r0, max_segs, a.hints);
         SK_HIP(hipGetLastError());
     }
     if (nchunks > 1) {
