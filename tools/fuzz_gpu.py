@@ -66,8 +66,14 @@ def main():
             print("MOTIFSEQ mismatch R=%d M=%d N=%d %s lo=%d hi=%d QL=%s read %d: got %s want %s"
                   % (R, M, N, scale, lo, hi, ql, r, got[r], want[r]))
         # ---- segmenter ----
+        # (round 4: the default walk jumps between stretches of quiet mask entries, k_seg_walk4 -- window >= 127 and
+        # error < min(corrector, 32) take it, with the statistics kernel's hints up to 4 096 samples and a pass of its
+        # own beyond or under SK_WALK_OWNPASS; the other draws take the older walks)
         kw = [dict(), dict(error=10, corrector=3), dict(window=20, seg_dist=5), dict(std_scale=1.5, stall_len=0.9),
-              dict(lim_low=300, lim_hi=800)][int(rng.integers(5))]
+              dict(lim_low=300, lim_hi=800), dict(error=3), dict(window=127, stall_len=0.05), dict(error=0, seg_dist=0),
+              dict(window=400, error=8, corrector=20), dict(std_scale=0.4, stall_len=1.2)][int(rng.integers(10))]
+        if rng.random() < 0.25:
+            os.environ["SK_WALK_OWNPASS"] = "1"
         p = SegParams(**kw)
         segs, nsegs = api.segment_batch(sig, lens, p, max_segs=64)
         okw = {a: b for a, b in kw.items() if a not in ("lim_low", "lim_hi")}
@@ -76,7 +82,8 @@ def main():
         if not np.array_equal(nsegs, onsegs) or any(
                 not np.array_equal(segs[r, :nsegs[r]], osegs[r, :nsegs[r]]) for r in range(R)):
             bad += 1
-            print("SEGMENTER mismatch R=%d M=%d %s" % (R, M, kw))
+            print("SEGMENTER mismatch R=%d M=%d %s ownpass=%s" % (R, M, kw, os.environ.get("SK_WALK_OWNPASS")))
+        os.environ.pop("SK_WALK_OWNPASS", None)
         # ---- float64 reads (pA-like), per-read oracle composition ----
         # (round 4: reads of up to 4 096 samples take the streaming statistics kernel, sk_f64stat.hip -- histogram median,
         # certified comparisons, numpy-order redo list; longer ones, and everything under SK_F64_OLD, the numpy-order
