@@ -357,9 +357,18 @@ void k_seg_stats(const SegStatArgs a)
                 // bit i of (alo, ahi): the e1 samples before sample i of my entry are all kept and out of band
                 const unsigned zprev = wave_shr1(zhi);
                 unsigned alo = ~0u, ahi = ~0u;
-                for (int j = 1; j <= a.e1; j++) {
-                    alo &= __builtin_amdgcn_alignbit(zlo, zprev, 32 - j);
-                    ahi &= __builtin_amdgcn_alignbit(zhi, zlo, 32 - j);
+                if (a.e1 == 6) {                                             // (the default) by doubling: 1, 2, 4, then 6 before
+                    const unsigned t1lo = __builtin_amdgcn_alignbit(zlo, zprev, 31), t1hi = __builtin_amdgcn_alignbit(zhi, zlo, 31);
+                    const unsigned t2lo = t1lo & __builtin_amdgcn_alignbit(t1lo, wave_shr1(t1hi), 31);
+                    const unsigned t2hi = t1hi & __builtin_amdgcn_alignbit(t1hi, t1lo, 31);
+                    const unsigned t2prev = wave_shr1(t2hi);
+                    alo = t2lo & __builtin_amdgcn_alignbit(t2lo, t2prev, 30) & __builtin_amdgcn_alignbit(t2lo, t2prev, 28);
+                    ahi = t2hi & __builtin_amdgcn_alignbit(t2hi, t2lo, 30) & __builtin_amdgcn_alignbit(t2hi, t2lo, 28);
+                } else {
+                    for (int j = 1; j <= a.e1; j++) {
+                        alo &= __builtin_amdgcn_alignbit(zlo, zprev, 32 - j);
+                        ahi &= __builtin_amdgcn_alignbit(zhi, zlo, 32 - j);
+                    }
                 }
                 alo &= olo; ahi &= ohi;
                 unsigned key = 0u;                                           // newest anchor of my entry << 16 | dcum
