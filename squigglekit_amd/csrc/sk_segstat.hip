@@ -722,15 +722,22 @@ void k_seg_walk3(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
 // (samples dropped inside the run), prev_err = the out-of-band samples since the run's last in-band one.
 constexpr int W4_ITEMS = 8;            // stretches noted per read
 
-template <int E1C>                     // E + 1 at compile time (0: at run time)
+template <int E1C, bool HINTS>         // E + 1 at compile time (0: at run time); HINTS: the statistics kernel's list
 __global__ __launch_bounds__(64)
 void k_seg_walk4(const uint4 *__restrict__ mask2, int row16, const int32_t *__restrict__ len, int64_t stride,
                  int nreads, WalkParams p, int32_t *__restrict__ segs, int32_t *__restrict__ nsegs, int max_segs,
                  int use_jumps, const unsigned *__restrict__ hints)
 {
-    __shared__ unsigned w4_items[2 * W4_ITEMS * 64];
+    // LDS: with hints, one 128-byte line (8 entries) of every lane's mask row -- a lane asks for its row 16 bytes at a
+    // time, the rows are 1 KB apart, and with 32 wavefronts per CU in flight a line did not survive in the L2 until
+    // its next entry was wanted: 1.75 GB fetched per 1 M reads for 1 GB of rows.  Staged, a line is fetched once; and
+    // the 8 KB leave 20 wavefronts per CU, which is where this kernel runs best anyway (0.338 ms at 32 per CU, 0.318
+    // at 20, 0.456 at 10 with nothing else changed).  Without hints: the list of stretches of the kernel's own pass.
+    __shared__ uint4 w4_lds[HINTS ? 8 * 64 : (2 * W4_ITEMS * 64) / 4];
     const int lane = threadIdx.x;
-    unsigned *items = w4_items + lane;                         // stretch i: items[128 i] = anchor | kb << 16, items[128 i + 64] = drops
+    unsigned *items = (unsigned *)w4_lds + lane;               // stretch i: items[128 i] = anchor | kb << 16, items[128 i + 64] = drops
+    uint4 *line = w4_lds + lane;                               // entry k of my line at line[64 k]
+    int have = -1;                                             // which line of my row that is
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < nreads;
     const int M = live ? min(max(len[r], 0), (int)min(stride, (int64_t)row16 * 64)) : 0;
@@ -746,8 +753,17 @@ void k_seg_walk4(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
     // ---- first pass: quiet stretches, anchors ----
     int nitems = 0;
     const unsigned *myhints = hints + (int64_t)(live ? r : 0) * SEG_HINTS;   // (the statistics kernel's, when it wrote any)
-    if (hints) {
-        nitems = live ? (int)myhints[0] : 0;                   // SEG_HINT_NONE: more than W4_ITEMS, no jumps
+    uint4 ha = make_uint4(0u, 0u, 0u, 0u), hb = ha;            // (HINTS) my read's hints, all eight dwords
+    if (HINTS) {
+        // everything the walk will ask for first, in one round trip: the hints and the first line of the row (a lane's
+        // loads depend on each other from here on -- the latency of those chains is what this kernel's time is made of)
+        if (live) { ha = ((const uint4 *)myhints)[0]; hb = ((const uint4 *)myhints)[1]; }
+        if (nent > 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) line[64 * j] = mrow[j];
+            have = 0;
+        }
+        nitems = (int)ha.x;                                    // SEG_HINT_NONE: more than the list holds, no jumps
     } else if (use_jumps) {
         int dcum = 0, anchor = 0, anchor_d = 0, anchor_prev = 0, anchor_prev_d = 0, quiet_prev = 0;
         unsigned zprev = 0u, cur_anchor = 0u;  // zprev: the previous entry's upper 32 out-of-band bits (before the read: none)
@@ -801,10 +817,13 @@ void k_seg_walk4(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
             }
         }
     }
-    const bool jumps = use_jumps && nitems <= (hints ? SEG_HINTS - 1 : W4_ITEMS);
+    const bool jumps = use_jumps && nitems <= (HINTS ? SEG_HINTS - 1 : W4_ITEMS);
     // stretch i: its anchor, last entry, samples dropped before the anchor's entry
     auto stretch = [&](int i, int &a, int &kb, int &d) __attribute__((always_inline)) {
-        if (hints) { const unsigned h = myhints[1 + i]; a = (int)(h & 0xfffu); kb = (int)((h >> 12) & 63u); d = (int)(h >> 18); }
+        if (HINTS) {
+            const unsigned h = i == 0 ? ha.y : i == 1 ? ha.z : i == 2 ? ha.w : i == 3 ? hb.x : i == 4 ? hb.y : i == 5 ? hb.z : hb.w;
+            a = (int)(h & 0xfffu); kb = (int)((h >> 12) & 63u); d = (int)(h >> 18);
+        }
         else { const unsigned h = items[128 * i]; a = (int)(h & 0xffffu); kb = (int)(h >> 16); d = (int)items[128 * i + 64]; }
     };
     int item = 0;
@@ -835,14 +854,24 @@ void k_seg_walk4(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
         if (!act) continue;
         const int e = pos >> 6;
         if (e != ce) {                                         // the two entries my window lies in
+            auto entry = [&](int k) __attribute__((always_inline)) -> uint4 {
+                if (k >= nent) return make_uint4(0u, 0u, 0u, 0u);
+                if (!HINTS) return mrow[k];
+                if ((k >> 3) != have) {                        // my row's line with entry k, all of it, once
+                    have = k >> 3;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) line[64 * j] = mrow[8 * have + j];
+                }
+                return line[64 * (k & 7)];
+            };
             if (e == ce + 1) { dcur += 64 - __builtin_popcountll(Oc | Zc); Oc = On; Zc = Zn; }
             else {
-                const uint4 v = mrow[e];                       // (e < nent: pos < M)
+                const uint4 v = entry(e);                      // (e < nent: pos < M)
                 Oc = ((unsigned long long)(v.y & v.w) << 32) | (v.x & v.z);
                 Zc = ((unsigned long long)(~v.y & v.w) << 32) | (~v.x & v.z);
                 dcur = jump_d;
             }
-            const uint4 v = (e + 1 < nent) ? mrow[e + 1] : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 v = entry(e + 1);
             On = ((unsigned long long)(v.y & v.w) << 32) | (v.x & v.z);
             Zn = ((unsigned long long)(~v.y & v.w) << 32) | (~v.x & v.z);
             ce = e;
@@ -905,12 +934,11 @@ void launch_walk(hipStream_t ws, const uint4 *mask2, int row16, const int32_t *l
     const int wgrid = (nr + 63) / 64;
     if (walk_jumps_apply(wp, fast, by_runs, row16)) {
         const int use_jumps = sk_tune("SK_WALK_NOJUMP") == nullptr;
-        if (wp.error == 5)
-            hipLaunchKernelGGL(k_seg_walk4<6>, dim3(wgrid), dim3(64), 0, ws, mask2, row16, len, stride, nr, wp, d_segs,
-                               d_nsegs, max_segs, use_jumps, use_jumps ? d_hints : nullptr);
-        else
-            hipLaunchKernelGGL(k_seg_walk4<0>, dim3(wgrid), dim3(64), 0, ws, mask2, row16, len, stride, nr, wp, d_segs,
-                               d_nsegs, max_segs, use_jumps, use_jumps ? d_hints : nullptr);
+        const unsigned *h = use_jumps ? d_hints : nullptr;
+        auto fn = wp.error == 5 ? (h ? k_seg_walk4<6, true> : k_seg_walk4<6, false>)
+                                : (h ? k_seg_walk4<0, true> : k_seg_walk4<0, false>);
+        hipLaunchKernelGGL(fn, dim3(wgrid), dim3(64), 0, ws, mask2, row16, len, stride, nr, wp, d_segs, d_nsegs, max_segs,
+                           use_jumps, h);
     } else if (fast && by_runs)
         hipLaunchKernelGGL(k_seg_walk3, dim3(wgrid), dim3(64), 0, ws, mask2, row16, len, stride, nr, wp, d_segs, d_nsegs,
                            max_segs);
