@@ -747,8 +747,10 @@ void k_seg_walk4(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
 
     const int nent = (M + 63) >> 6;
     int nmax = nent;
+    if (!HINTS) {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+        for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+    }
 
     // ---- first pass: quiet stretches, anchors ----
     int nitems = 0;
@@ -757,8 +759,8 @@ void k_seg_walk4(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
     if (HINTS) {
         // everything the walk will ask for first, in one round trip: the hints and the first line of the row (a lane's
         // loads depend on each other from here on -- the latency of those chains is what this kernel's time is made of)
-        if (live) { ha = ((const uint4 *)myhints)[0]; hb = ((const uint4 *)myhints)[1]; }
-        if (nent > 0) {
+        if (live) {                                            // (not "if the read has samples": that would wait for len[r])
+            ha = ((const uint4 *)myhints)[0]; hb = ((const uint4 *)myhints)[1];
 #pragma unroll
             for (int j = 0; j < 8; j++) line[64 * j] = mrow[j];
             have = 0;
