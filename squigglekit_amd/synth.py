@@ -109,3 +109,44 @@ def drna_reads(n_reads, seed, min_len=6000, max_len=40000):
         sig[pos] = SPIKES[rng.integers(0, 4, 6)].astype(np.float64) + rng.integers(0, 2, 6) * 300
         out.append(np.clip(np.rint(sig), -32768, 32767).astype(np.int16))
     return out
+
+
+def pattern_reads(rng, R, M):
+    """Reads whose in-band mask is built from pieces chosen to stress the jumping walk (k_seg_walk4): quiet stalls,
+    alternating stretches (never quiet, never E + 1 out-of-band samples in a row: no anchor for thousands of samples),
+    long out-of-band holes, noise, 70-in / 10-out trains (isolated quiet entries), plus a few dropped samples."""
+    sig = np.empty((R, M), dtype=np.int16)
+    for r in range(R):
+        bits = []
+        total = 0
+        while total < M:
+            kind = rng.integers(0, 7) if r % 4 else rng.choice([0, 1, 1, 4])
+            ln = int(rng.integers(20, 2600 if kind == 1 else 700))
+            if kind == 0:                                        # a stall: few out-of-band samples
+                b = (rng.random(ln) > rng.choice([0.0, 0.01, 0.03])).astype(np.uint8)
+            elif kind == 1:                                      # alternating, period 2 .. 5
+                per = int(rng.integers(2, 6))
+                b = (np.arange(ln) % per != 0).astype(np.uint8) if rng.random() < 0.5 else (np.arange(ln) % per == 0).astype(np.uint8)
+            elif kind == 2:                                      # a hole
+                b = np.zeros(ln, dtype=np.uint8)
+            elif kind == 3:                                      # noise
+                b = (rng.random(ln) < rng.uniform(0.3, 0.9)).astype(np.uint8)
+            elif kind == 4:                                      # trains of in-band samples between short gaps
+                on, off = int(rng.integers(30, 140)), int(rng.integers(1, 12))
+                b = ((np.arange(ln) % (on + off)) < on).astype(np.uint8)
+            elif kind == 5:                                      # event-like: runs of random length
+                b = np.repeat(rng.random(ln // 6 + 1) < 0.6, rng.integers(3, 14, ln // 6 + 1))[:ln].astype(np.uint8)
+            else:                                                # exactly E, E + 1, E + 2 out-of-band samples between runs
+                gap = int(rng.integers(4, 9))
+                on = int(rng.integers(5, 60))
+                b = ((np.arange(ln) % (on + gap)) < on).astype(np.uint8)
+            bits.append(b)
+            total += len(b)
+        b = np.concatenate(bits)[:M]
+        far = np.where(np.arange(M) % 2 == 0, 300, 700)
+        x = np.where(b == 1, 500 + rng.integers(-12, 13, M), far + rng.integers(-12, 13, M))
+        if r % 3 == 0:                                           # dropped samples: the squeeze moves every later position
+            k = int(rng.integers(1, 40))
+            x[rng.integers(0, M, k)] = rng.choice([0, 950, -7])
+        sig[r] = x
+    return sig

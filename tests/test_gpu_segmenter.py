@@ -186,57 +186,16 @@ def test_streaming_statistics_path_vs_oracle(gpu, ora):
                          "width %d" % width)
 
 
-def _pattern_reads(rng, R, M):
-    """Reads whose in-band mask is built from pieces chosen to stress the jumping walk (k_seg_walk4): quiet stalls,
-    alternating stretches (never quiet, never E + 1 out-of-band samples in a row: no anchor for thousands of samples),
-    long out-of-band holes, noise, 70-in / 10-out trains (isolated quiet entries), plus a few dropped samples."""
-    sig = np.empty((R, M), dtype=np.int16)
-    for r in range(R):
-        bits = []
-        total = 0
-        while total < M:
-            kind = rng.integers(0, 7) if r % 4 else rng.choice([0, 1, 1, 4])
-            ln = int(rng.integers(20, 2600 if kind == 1 else 700))
-            if kind == 0:                                        # a stall: few out-of-band samples
-                b = (rng.random(ln) > rng.choice([0.0, 0.01, 0.03])).astype(np.uint8)
-            elif kind == 1:                                      # alternating, period 2 .. 5
-                per = int(rng.integers(2, 6))
-                b = (np.arange(ln) % per != 0).astype(np.uint8) if rng.random() < 0.5 else (np.arange(ln) % per == 0).astype(np.uint8)
-            elif kind == 2:                                      # a hole
-                b = np.zeros(ln, dtype=np.uint8)
-            elif kind == 3:                                      # noise
-                b = (rng.random(ln) < rng.uniform(0.3, 0.9)).astype(np.uint8)
-            elif kind == 4:                                      # trains of in-band samples between short gaps
-                on, off = int(rng.integers(30, 140)), int(rng.integers(1, 12))
-                b = ((np.arange(ln) % (on + off)) < on).astype(np.uint8)
-            elif kind == 5:                                      # event-like: runs of random length
-                b = np.repeat(rng.random(ln // 6 + 1) < 0.6, rng.integers(3, 14, ln // 6 + 1))[:ln].astype(np.uint8)
-            else:                                                # exactly E, E + 1, E + 2 out-of-band samples between runs
-                gap = int(rng.integers(4, 9))
-                on = int(rng.integers(5, 60))
-                b = ((np.arange(ln) % (on + gap)) < on).astype(np.uint8)
-            bits.append(b)
-            total += len(b)
-        b = np.concatenate(bits)[:M]
-        far = np.where(np.arange(M) % 2 == 0, 300, 700)
-        x = np.where(b == 1, 500 + rng.integers(-12, 13, M), far + rng.integers(-12, 13, M))
-        if r % 3 == 0:                                           # dropped samples: the squeeze moves every later position
-            k = int(rng.integers(1, 40))
-            x[rng.integers(0, M, k)] = rng.choice([0, 950, -7])
-        sig[r] = x
-    return sig
-
-
 @pytest.mark.parametrize("M", [4096, 9000])
 def test_jumping_walk_on_pattern_reads(gpu, ora, monkeypatch, M):
     """k_seg_walk4 against the oracle on reads built to defeat its jumps: anchors thousands of samples behind the
     stretch they serve, more stretches than its list holds, isolated quiet entries before the first segment, dropped
     samples inside runs and between anchor and stretch, window at and around the 127 samples the jumps need, error
     0 .. 32; and the same batch through the walk without jumps and the word-synchronous walk."""
-    from squigglekit_amd import api
+    from squigglekit_amd import api, synth
     rng = np.random.default_rng(M)
     R = 256
-    sig = _pattern_reads(rng, R, M)
+    sig = synth.pattern_reads(rng, R, M)
     lens = rng.integers(M // 2, M + 1, size=R).astype(np.int32)
     lens[:64] = M
     cases = [dict(), dict(stall_len=1.5), dict(window=127), dict(window=126), dict(window=300, stall_len=0.1),

@@ -31,6 +31,8 @@ def main():
         sig = synth.squiggle_batch(R, M, int(rng.integers(1 << 30)))
         if rng.random() < 0.3:
             sig = np.clip(sig, 300, 700).astype(np.int16)
+        elif rng.random() < 0.3 and M >= 512:
+            sig = synth.pattern_reads(rng, R, M)          # in-band masks built to defeat the jumping walk (round 4)
         k = int(rng.integers(0, 40))
         sig[rng.integers(0, R, k), rng.integers(0, M, k)] = rng.choice([-9, 0, 899, 900, 1199, 1200, 3000], k)
         lens = rng.integers(0, M + 1, R).astype(np.int32)
