@@ -120,7 +120,7 @@ def pattern_reads(rng, R, M):
         bits = []
         total = 0
         while total < M:
-            kind = rng.integers(0, 7) if r % 4 else rng.choice([0, 1, 1, 4])
+            kind = rng.integers(0, 8) if r % 4 else rng.choice([0, 1, 1, 4, 7])
             ln = int(rng.integers(20, 2600 if kind == 1 else 700))
             if kind == 0:                                        # a stall: few out-of-band samples
                 b = (rng.random(ln) > rng.choice([0.0, 0.01, 0.03])).astype(np.uint8)
@@ -136,10 +136,19 @@ def pattern_reads(rng, R, M):
                 b = ((np.arange(ln) % (on + off)) < on).astype(np.uint8)
             elif kind == 5:                                      # event-like: runs of random length
                 b = np.repeat(rng.random(ln // 6 + 1) < 0.6, rng.integers(3, 14, ln // 6 + 1))[:ln].astype(np.uint8)
-            else:                                                # exactly E, E + 1, E + 2 out-of-band samples between runs
+            elif kind == 6:                                      # exactly E, E + 1, E + 2 out-of-band samples between runs
                 gap = int(rng.integers(4, 9))
                 on = int(rng.integers(5, 60))
                 b = ((np.arange(ln) % (on + gap)) < on).astype(np.uint8)
+            else:                                                # a near-miss anchor: a run with its whole error budget left, a gap
+                # of 4 .. 7 samples (E + 1 = 6 makes an anchor), two entries and more that are neither quiet nor hold
+                # an anchor, then a stall -- the sample behind the gap is the newest candidate for the stall's anchor
+                on, off = int(rng.integers(2, 6)), int(rng.integers(1, 3))
+                alt = ((np.arange(int(rng.integers(130, 420))) % (on + off)) < on).astype(np.uint8)
+                stall = np.ones(int(rng.integers(140, 420)), dtype=np.uint8)
+                stall[rng.integers(0, stall.size, int(rng.integers(0, 4)))] = 0
+                b = np.concatenate([np.ones(int(rng.integers(8, 60)), dtype=np.uint8),
+                                    np.zeros(int(rng.integers(4, 8)), dtype=np.uint8), alt, stall])
             bits.append(b)
             total += len(b)
         b = np.concatenate(bits)[:M]
