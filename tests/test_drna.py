@@ -52,14 +52,21 @@ def test_gpu_matches_oracle_and_reference(gpu, ora, example_read):
     assert _lines(ids, got[:len(ids)]) == gold["stdout"]
     # other parameter corners vs the oracle
     from squigglekit_amd._lib import DrnaParams
+    # (round 4: w >= 64 takes the scan by runs, k_drna_walk_runs -- pieces cut at the re-arming sample, at no_err_thresh
+    # and at the window's end; reads with alternating / train / near-miss masks from synth.pattern_reads join the batch)
+    from squigglekit_amd import synth
+    reads = reads + [r for r in synth.pattern_reads(np.random.default_rng(5), 12, 9000)]
     for kw in (dict(error=2, no_err_thresh=0, w=50, window=30, seg_dist=100),
-               dict(t_start=0, t_end=2000, std_scale=0.2), dict(lim_low=300, lim_hi=700)):
+               dict(t_start=0, t_end=2000, std_scale=0.2), dict(lim_low=300, lim_hi=700),
+               dict(error=0), dict(w=64, window=500, seg_dist=50), dict(no_err_thresh=100000, error=1),
+               dict(error=9, w=100, window=250, seg_dist=10, std_scale=1.5), dict(window=0, seg_dist=0, w=65),
+               dict(no_err_thresh=777, w=128, window=64, error=3, t_start=0, t_end=9000)):
         p = DrnaParams(**kw)
         got = api.drna_segment_reads(reads, p)
         okw = {k: v for k, v in kw.items() if not k.startswith("lim")}
         for r, g in zip(reads, got):
             f = ora.scale_outliers(r.astype(float), p.lim_low, p.lim_hi)
-            assert g == ora.drna_segs(f, ora.DrnaParams(**okw))[0], kw
+            assert g == ora.drna_segs(f, ora.DrnaParams(**okw), max_segs=16384)[0], kw
 
 
 @pytest.mark.gpu

@@ -150,16 +150,23 @@ def main():
         os.environ.pop("SK_F64_OLD", None)
         os.environ.pop("SK_SEG_DELTA_SCALE", None)
         # ---- dRNA_segmenter: both branches on a few long ragged reads ----
-        if rounds % 4 == 0:
+        if rounds % 2 == 0:
             from squigglekit_amd._lib import DrnaParams, RollParams
             dreads = synth.drna_reads(int(rng.integers(1, 9)), int(rng.integers(1 << 30)),
                                       min_len=int(rng.choice([300, 3000, 9000])), max_len=26000)
+            if rng.random() < 0.5:                              # masks with structure (alternating, trains, near-miss gaps)
+                dreads = dreads + [x for x in synth.pattern_reads(rng, int(rng.integers(1, 5)), int(rng.choice([3000, 9000])))]
             dkw = [dict(), dict(error=2, no_err_thresh=0, w=50, window=30, seg_dist=100),
-                   dict(t_start=0, t_end=2000, std_scale=0.2)][int(rng.integers(3))]
+                   dict(t_start=0, t_end=2000, std_scale=0.2), dict(error=0), dict(w=64, window=500, seg_dist=50),
+                   dict(no_err_thresh=100000, error=1), dict(error=9, w=100, window=250, seg_dist=10, std_scale=1.5),
+                   dict(no_err_thresh=777, w=128, window=64, error=3, t_start=0, t_end=9000)][int(rng.integers(8))]
+            if rng.random() < 0.2:
+                os.environ["SK_DRNA_STEP"] = "1"
             for x, g in zip(dreads, api.drna_segment_reads(dreads, DrnaParams(**dkw))):
                 if g != ora.drna_segs(ora.scale_outliers(x.astype(float), 0, 1200), ora.DrnaParams(**dkw))[0]:
                     bad += 1
-                    print("DRNA mismatch n=%d %s" % (len(x), dkw))
+                    print("DRNA mismatch n=%d %s step=%s" % (len(x), dkw, os.environ.get("SK_DRNA_STEP")))
+            os.environ.pop("SK_DRNA_STEP", None)
             rkw = [dict(), dict(w=int(rng.choice([3, 64, 999, 2000, 5000]))),
                    dict(w=800, lo_thresh=200, seg_dist=int(rng.choice([1, 300, 5000])), std_scale=0.25)][int(rng.integers(3))]
             for x, g in zip(dreads, api.drna_roll_reads(dreads, RollParams(**rkw))):
