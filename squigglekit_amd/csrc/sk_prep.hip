@@ -945,18 +945,22 @@ void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off,
 // the window sums from an exact int64 prefix sum.  mn = t.mean() and std = t.std() are pandas nanops:
 // NaN (the first w - 1 entries) replaced by 0, numpy sums, ddof = 1 -- the numpy-order summation
 // above.  Output: mn / std / bot in the read's record and the two bit masks t < bot, t > bot.
+// PT: int64_t, or uint32_t when every window sum fits 31 bits (w < 65 536: the prefix sums wrap, their differences do
+// not) -- the kernel is bound by the traffic of its prefix sums (one write, six reads per sample), and this halves it.
+template <typename PT>
 __global__ __launch_bounds__(TPB)
 void k_roll_stats(const int16_t *__restrict__ comp, int64_t stride, sk_prep *__restrict__ prep, int nreads,
-                  int w, double std_scale, int64_t *__restrict__ psum,
+                  int w, double std_scale, void *__restrict__ psum_,
                   uint64_t *__restrict__ below, uint64_t *__restrict__ above, int64_t mask_rows)
 {
+    PT *psum = (PT *)psum_;
     __shared__ Scratch sc_;
     Scratch *sc = &sc_;
     const int r = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int n = prep[r].n;
     const int16_t *crow = comp + (int64_t)r * stride;
-    int64_t *P = psum + (int64_t)r * (stride + 1);           // P[i] = sum of the first i filtered samples
+    PT *P = psum + (int64_t)r * (stride + 1);                // P[i] = sum of the first i filtered samples
     if (tid == 0) { sc->tree_m = -1; P[0] = 0; }
 
     long long carry = 0;
@@ -972,7 +976,7 @@ void k_roll_stats(const int16_t *__restrict__ comp, int64_t stride, sk_prep *__r
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             run += v[k];
-            if (i0 + k < n) P[i0 + k + 1] = run;
+            if (i0 + k < n) P[i0 + k + 1] = (PT)run;
         }
         carry += total;
     }
@@ -980,7 +984,10 @@ void k_roll_stats(const int16_t *__restrict__ comp, int64_t stride, sk_prep *__r
 
     const long long cnt = (n >= w) ? (long long)n - w + 1 : 0;               // entries of t that are not NaN
     const double dw = (double)w;
-    auto tval = [&](int i) -> double { return (double)(P[i + 1] - P[i + 1 - w]) / dw; };   // i >= w - 1
+    auto tval = [&](int i) -> double {                        // i >= w - 1
+        if (sizeof(PT) == 4) return (double)(int)(P[i + 1] - P[i + 1 - w]) / dw;
+        return (double)(P[i + 1] - P[i + 1 - w]) / dw;
+    };
     const double mn = numpy_sum(n, sc, [&](int i) { return (i >= w - 1) ? tval(i) : 0.0; }) / (double)cnt;
     const double ss = numpy_sum(n, sc, [&](int i) {
         if (i < w - 1) return 0.0;
@@ -1016,8 +1023,12 @@ int sk_launch_roll_stats(sk_ctx *c, const int16_t *d_comp, int64_t stride, sk_pr
                          int32_t w, double std_scale, int64_t *d_psum, uint64_t *d_below, uint64_t *d_above)
 {
     if (nreads <= 0) return SK_OK;
-    hipLaunchKernelGGL(k_roll_stats, dim3(nreads), dim3(TPB), 0, c->stream, d_comp, stride, d_prep, nreads, w,
-                       std_scale, d_psum, d_below, d_above, (int64_t)nreads);
+    if (w < 65536 && sk_tune("SK_DRNA_STEP") == nullptr)
+        hipLaunchKernelGGL(k_roll_stats<uint32_t>, dim3(nreads), dim3(TPB), 0, c->stream, d_comp, stride, d_prep, nreads, w,
+                           std_scale, (void *)d_psum, d_below, d_above, (int64_t)nreads);
+    else
+        hipLaunchKernelGGL(k_roll_stats<int64_t>, dim3(nreads), dim3(TPB), 0, c->stream, d_comp, stride, d_prep, nreads, w,
+                           std_scale, (void *)d_psum, d_below, d_above, (int64_t)nreads);
     SK_HIP(hipGetLastError());
     return SK_OK;
 }

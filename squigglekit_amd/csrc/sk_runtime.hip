@@ -87,7 +87,7 @@ static const sk_tunable SK_TUNABLES[] = {
     {"SK_WALK_SYNC",          "1",           "segmenter walk: run hopping with the 64 lanes of a wavefront on the same word (k_seg_walk3)"},
     {"SK_WALK_OWNPASS",       "1",           "segmenter walk: finds the quiet stretches and anchors in a pass of its own instead of taking the statistics kernel's hints"},
     {"SK_WALK_NOJUMP",        "1",           "segmenter walk: every run is hopped through, no jumps between the stretches of quiet entries"},
-    {"SK_DRNA_STEP",          "1",           "dRNA_segmenter slow5 branch: the per-sample scan instead of the scan by runs"},
+    {"SK_DRNA_STEP",          "1",           "dRNA_segmenter, both branches: the per-sample scans instead of the scans by runs / by transitions"},
     {"SK_INGEST_MB",          "1 4",         "sub-batch size of the host entry points in MB"},
     {"SK_F64_OLD",            "1",           "float64 reads: numpy-order statistics kernel for every read"},
 };

@@ -324,6 +324,7 @@ void k_drna_walk_runs(const uint64_t *__restrict__ maskT, int64_t mask_rows,
 // can only be judged once the next one has been appended (or the read ends), because merges extend it.
 struct RollWalk { int seg_dist, hi_thresh, lo_thresh, shift; };
 
+template <bool BY_RUNS>
 __global__ __launch_bounds__(64)
 void k_roll_walk(const uint64_t *__restrict__ below, const uint64_t *__restrict__ above, int64_t mask_rows,
                  const sk_prep *__restrict__ prep, int nreads, RollWalk p,
@@ -342,6 +343,37 @@ void k_roll_walk(const uint64_t *__restrict__ below, const uint64_t *__restrict_
         const uint64_t B = below[(int64_t)wi * mask_rows + r], A = above[(int64_t)wi * mask_rows + r];
         if (!begin && B == 0ull) continue;                    // nothing opens in this word
         const int lim = min(64, n - wi * 64);
+        if (BY_RUNS) {
+            // by transitions instead of by samples (round 4): a word without one costs a dozen instructions -- the
+            // rolling mean crosses `bot` a few times per read, the words are 270 per read
+            const uint64_t valid = (lim == 64) ? ~0ull : ((1ull << lim) - 1ull);
+            const uint64_t Bm = B & valid, Am = A & ~B & valid;
+            int b = 0;
+            while (b < 64) {
+                const uint64_t from = ~0ull << b;
+                if (!begin) {
+                    const uint64_t t = Bm & from;
+                    if (!t) break;
+                    const int s1 = __builtin_ctzll(t);
+                    start = wi * 64 + s1; begin = true;                      // :297-299
+                    b = s1 + 1;
+                } else {
+                    const uint64_t t = Am & from;
+                    const uint64_t upto = t ? ((1ull << __builtin_ctzll(t)) - 1ull) : ~0ull;
+                    const uint64_t mid = Bm & from & upto;                   // `below` samples of the open run: end = the last (:300-301)
+                    if (mid) end = wi * 64 + 63 - __builtin_clzll(mid);
+                    if (!t) break;
+                    if (nseg > 0 && start - sb < p.seg_dist) sb = end;       // :302-309
+                    else {
+                        if (nseg > 0) judge();
+                        sa = start; sb = end; nseg++;
+                    }
+                    start = 0; end = 0; begin = false;
+                    b = __builtin_ctzll(t) + 1;
+                }
+            }
+            continue;
+        }
         for (int b = 0; b < lim; b++) {
             const int i = wi * 64 + b;
             if ((B >> b) & 1) {
@@ -372,8 +404,12 @@ int sk_launch_roll_walk(sk_ctx *c, const uint64_t *d_below, const uint64_t *d_ab
     wp.seg_dist = p->seg_dist; wp.hi_thresh = p->hi_thresh; wp.lo_thresh = p->lo_thresh; wp.shift = p->shift;
     const int grid = (nreads + 63) / 64;
     SK_HIP(hipEventRecord(c->ev[2], c->stream));
-    hipLaunchKernelGGL(k_roll_walk, dim3(grid), dim3(64), 0, c->stream, d_below, d_above, (int64_t)nreads, d_prep,
-                       nreads, wp, d_xy, d_found);
+    if (sk_tune("SK_DRNA_STEP") == nullptr)
+        hipLaunchKernelGGL(k_roll_walk<true>, dim3(grid), dim3(64), 0, c->stream, d_below, d_above, (int64_t)nreads, d_prep,
+                           nreads, wp, d_xy, d_found);
+    else
+        hipLaunchKernelGGL(k_roll_walk<false>, dim3(grid), dim3(64), 0, c->stream, d_below, d_above, (int64_t)nreads, d_prep,
+                           nreads, wp, d_xy, d_found);
     SK_HIP(hipGetLastError());
     SK_HIP(hipEventRecord(c->ev[3], c->stream));
     return SK_OK;

@@ -166,13 +166,13 @@ def main():
                 if g != ora.drna_segs(ora.scale_outliers(x.astype(float), 0, 1200), ora.DrnaParams(**dkw))[0]:
                     bad += 1
                     print("DRNA mismatch n=%d %s step=%s" % (len(x), dkw, os.environ.get("SK_DRNA_STEP")))
-            os.environ.pop("SK_DRNA_STEP", None)
             rkw = [dict(), dict(w=int(rng.choice([3, 64, 999, 2000, 5000]))),
                    dict(w=800, lo_thresh=200, seg_dist=int(rng.choice([1, 300, 5000])), std_scale=0.25)][int(rng.integers(3))]
             for x, g in zip(dreads, api.drna_roll_reads(dreads, RollParams(**rkw))):
                 if g != ora.drna_roll(ora.scale_outliers(x.astype(float), 0, 1200), ora.RollParams(**rkw)):
                     bad += 1
-                    print("DRNA ROLL mismatch n=%d %s" % (len(x), rkw))
+                    print("DRNA ROLL mismatch n=%d %s step=%s" % (len(x), rkw, os.environ.get("SK_DRNA_STEP")))
+            os.environ.pop("SK_DRNA_STEP", None)
     print("fuzz: %d rounds, %d mismatching configurations" % (rounds, bad))
     sys.exit(1 if bad else 0)
 
