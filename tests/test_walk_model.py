@@ -155,3 +155,91 @@ def test_jumping_walk_model_equals_get_segs(ora, seed):
             total += len(got)
             jumped += len(_hints(inband & kept, ~inband & kept, kept, p.error + 1))
     assert total > 20 and jumped > 20                            # the cases do produce segments and stretches to jump between
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# k_drna_walk_runs (csrc/sk_segment.hip): the dRNA slow5-branch scan by pieces, trip for trip as the kernel takes them
+# ---------------------------------------------------------------------------------------------------------------
+def _drna_pieces(mask, error, no_err_thresh, w, window, seg_dist):
+    """The kernel's loop on a Python bool mask (True = a < top): 64-sample windows at the lane's own position, a piece cut
+    at the re-arming sample / at no_err_thresh / at the window's end, close at the (budget + 1)-th out-of-band sample."""
+    n = len(mask)
+    kw0 = (max(window, w) + w - 1) // w * w
+    prev = err = prev_err = start = last_end = refill = 0
+    segs = []
+    pos = 0
+    while pos < n:
+        V = min(64, n - pos)
+        win = mask[pos:pos + V]
+        if not prev:
+            ones = np.flatnonzero(win)
+            o = int(ones[0]) if ones.size else V
+            if segs and o > 0 and pos + o - 1 - last_end > seg_dist:
+                break                                            # adapter found (:152)
+            if o == V:
+                pos += V
+                continue
+            pos += o
+            win = win[o:]
+            V -= o
+            prev, start, err, prev_err = 1, pos, 0, 0
+            refill = start + kw0 - 1
+        L = min(V, refill - pos + 1)
+        counted = pos >= no_err_thresh
+        if not counted:
+            L = min(L, no_err_thresh - pos)
+        piece = win[:L]
+        zs = np.flatnonzero(~piece)
+        tol = max(error - err, 0) if counted else (64 if err < error else 0)
+        if zs.size > tol:
+            q = int(zs[tol])
+            before = np.flatnonzero(piece[:q])
+            if before.size:
+                prev_err = int((~piece[int(before[-1]) + 1:q]).sum()) if counted else 0
+            else:
+                prev_err += tol if counted else 0
+            i = pos + q
+            if i - start >= window:
+                end = i - prev_err
+                if segs and start - last_end < seg_dist:
+                    segs[-1][1] = end
+                else:
+                    segs.append([start, end])
+                last_end = end
+            prev = err = prev_err = 0
+            pos = i + 1
+        else:
+            ones = np.flatnonzero(piece)
+            if ones.size:
+                prev_err = int((~piece[int(ones[-1]) + 1:]).sum()) if counted else 0
+            else:
+                prev_err += int(zs.size) if counted else 0
+            err += int(zs.size) if counted else 0
+            pos += L
+            if pos - 1 == refill:
+                err -= 1
+                refill += w
+    return segs
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_drna_scan_by_pieces_model_equals_oracle(ora, seed):
+    from squigglekit_amd import synth
+    rng = np.random.default_rng(500 + seed)
+    reads = synth.drna_reads(6, 900 + seed, min_len=3000, max_len=16000) + \
+        [x for x in synth.pattern_reads(rng, 6, int(rng.choice([3000, 9000])))]
+    # the stop test at its boundary: a segment, exactly seg_dist idle out-of-band samples, another segment
+    reads.append(np.r_[np.full(300, 400), np.full(51, 700), np.full(200, 400), np.full(6000, 700)].astype(np.int16))
+    total = 0
+    for kw in (dict(), dict(error=0), dict(w=64, window=500, seg_dist=50), dict(no_err_thresh=100000, error=1),
+               dict(error=9, w=100, window=250, seg_dist=10, std_scale=1.5), dict(window=0, seg_dist=0, w=65),
+               dict(no_err_thresh=777, w=128, window=64, error=3, t_start=0, t_end=9000),
+               dict(no_err_thresh=0, error=0, seg_dist=50, window=100), dict(no_err_thresh=0, error=0, seg_dist=49, window=100)):
+        p = ora.DrnaParams(**kw)
+        for x in reads:
+            f = ora.scale_outliers(x.astype(float), 0, 1200)
+            want, top = ora.drna_segs(f, p, max_segs=16384)
+            got = _drna_pieces(f < top, p.error, p.no_err_thresh, p.w, p.window, p.seg_dist)
+            assert got == want, (seed, kw, len(f))
+            total += len(got)
+    assert total > 50
