@@ -136,8 +136,12 @@ def test_gpu_rolling_branch(gpu, ora):
                      np.full(2000, 400, dtype=np.int16), np.full(2001, 400, dtype=np.int16),
                      np.r_[np.full(6000, 300), np.full(20000, 600)].astype(np.int16)]
     extra[3][::97] = 2000                                   # outliers: the filter shifts every coordinate
+    # (w >= 65 536 keeps 64-bit prefix sums, smaller windows store them as wrapping uint32: a read long enough for both)
+    from squigglekit_amd import synth
+    extra.append(np.concatenate(synth.drna_reads(4, 77, min_len=30000, max_len=40000)))
     for kw in (dict(), dict(w=7, lo_thresh=3, seg_dist=2, shift=0), dict(w=1200, std_scale=0.1, lo_thresh=100),
-               dict(w=500, seg_dist=100000), dict(lim_low=300, lim_hi=700, w=300, lo_thresh=50)):
+               dict(w=500, seg_dist=100000), dict(lim_low=300, lim_hi=700, w=300, lo_thresh=50),
+               dict(w=65535, lo_thresh=100, std_scale=0.05), dict(w=70000, lo_thresh=100, std_scale=0.05)):
         p = RollParams(**kw)
         got = api.drna_roll_reads(extra, p)
         okw = {k: v for k, v in kw.items() if not k.startswith("lim")}
