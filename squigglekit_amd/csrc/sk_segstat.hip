@@ -709,15 +709,20 @@ void k_seg_walk3(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
 //
 // Jumps.  Once a read has its first segment only runs of c >= window samples count (:448).  Such a run [s, z) spans
 // >= 127 raw samples, so it covers the aligned entry k1 = ceil(s / 64) completely -- an entry with <= E out-of-band
-// samples, "quiet".  A first pass over the read's entries (uniform across the wavefront, ~40 instructions per entry) notes
-// every stretch [ka, kb] of quiet entries together with an ANCHOR: the newest position <= 64 (ka - 1) at which the state
+// samples, "quiet".  Somebody who sees every entry of the read's mask row once -- the statistics kernel, which holds
+// entry e in lane e when it stores the row (HINTS: k_seg_stats above, 8 dwords per read), or else a first pass of this
+// kernel over the row (uniform across the wavefront, ~55 instructions per entry; float64 reads, reads beyond 4 096
+// samples, SK_WALK_OWNPASS) -- notes every stretch [ka, kb] of quiet entries together with an ANCHOR: the newest position <= 64 (ka - 1) at which the state
 // of the chain is known without walking it -- an in-band sample whose E + 1 raw predecessors are all kept and out of
 // band opens a run whatever came before (a run open there has closed inside them, the scan was idle behind it), or
 // sample 0 -- and the number of samples dropped before the anchor's entry.  Every run of interest that opens in a stretch
 // (s in (64 (ka - 1), 64 kb]) opens at or behind the stretch's anchor, and no anchor lies inside a run with E
 // out-of-band samples.  So an idle lane whose read has a segment drops the stretches that end before its position and
 // continues at max(position, next stretch's anchor); with no stretch ahead it is done.  A read with more stretches than
-// the list holds is walked without jumps.
+// the list holds (7 with hints, 8 without), or whose masks the numpy-order redo rewrote, is walked without jumps.
+// What the kernel's time is made of is the latency of a lane's dependent 16-byte loads (rows 1 KB apart): with hints
+// the row goes through LDS a 128-byte line at a time and the first line leaves with the hints in one round trip
+// (tests/test_walk_model.py is this scheme sample by sample against the oracle).
 // Positions: start = z_f - c and end = z_f - prev_err (:449), z_f = z - (samples dropped before z), c = (z - s) -
 // (samples dropped inside the run), prev_err = the out-of-band samples since the run's last in-band one.
 constexpr int W4_ITEMS = 8;            // stretches noted per read
