@@ -51,7 +51,10 @@ def test_product_never_imports_oracle_or_torch():
         assert not re.search(r"^\s*(from|import)\s+torch\b", src, flags=re.M), path
     for path in glob.glob(os.path.join(pkg, "csrc", "*")):
         if path.endswith((".hip", ".h", ".cpp")):
-            assert "oracle" not in open(path).read(), path
+            # code only: comments may say what a test compares a kernel with, no identifier, include or string may
+            code = re.sub(r"/\*.*?\*/", " ", open(path).read(), flags=re.S)
+            code = re.sub(r"//[^\n]*", " ", code)
+            assert "oracle" not in code.lower(), path
 
 
 def test_fails_loudly_without_gpu():

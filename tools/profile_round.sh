@@ -62,4 +62,5 @@ python "$R/tools/pmc_traffic.py" 250000 1 "$OUT/pmc_FETCH_SIZE_other" "$OUT/pmc_
 rm -rf "$OUT/kt_other" "$OUT/pmc_FETCH_SIZE_other" "$OUT/pmc_WRITE_SIZE_other"
 python "$R/tools/cli_throughput.py" 200000 1000000 > "$OUT/cli_throughput.txt" 2>&1
 (cd "$R" && python tools/parity_at_scale.py 400000 128 && python tools/parity_at_scale.py segmenter 1000000 128) > "$OUT/parity_at_scale.txt" 2>&1
+(cd "$R" && tools/check.sh) > "$OUT/cpu_suite.txt" 2>&1
 ls -la "$OUT"
