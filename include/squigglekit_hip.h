@@ -336,6 +336,19 @@ int sk_last_dtw_retries(void);
 /* Reads of the most recent DTW call whose path crossed the window pass's first (short) look-back and were redone
  * by its second tier (diagnostic; 0 when the call did not use the screening scheme). */
 int sk_last_dtw_tier2(void);
+/* Run-time guard of the screening scheme (the default DTW path: fixed-point screening + certified exact window).
+ * Its exactness rests on a premise -- every screening cost lies within E = N + n + 2 units of the exact one -- that
+ * is derived, not observed; the guard observes it.  out[0] results the window pass refused because the exact distance
+ * contradicted the screening values (premise violations), out[1] reads the audit re-ran with the exact single pass
+ * (one in 4 096, hashed), out[2] audited reads whose record differed (the exact record wins), out[3] reads kept
+ * away from the screening because their sample image cannot be bounded tightly enough (exact pass, by design),
+ * out[4] = out[0] + out[2] (the alarm), out[5] = 1 when the alarm made the library redo the WHOLE call with the
+ * exact single pass, out[6..7] reserved.  In a healthy build out[0] = out[2] = out[4] = out[5] = 0, always.  The
+ * two short forms return out[0] / out[2] (or a negative status).  The reference has no counterpart: mlpy's one
+ * exact pass (/root/reference/MotifSeq.py:437-439) is what every record must equal. */
+int sk_last_dtw_guard(int32_t *out /* [8] */);
+int sk_last_dtw_premise_violations(void);
+int sk_last_dtw_audit_mismatches(void);
 /* Reads of the most recent float64 call (sk_segment_*_f64, sk_motifseq_*_f64 with medmad) whose comparisons /
  * selection the streaming statistics kernel could not certify and that were redone in numpy's order (diagnostic);
  * -1 when the call did not use the streaming kernel (reads longer than 4 096 samples, zscale). */

@@ -157,6 +157,9 @@ ABI = {
     "sk_last_kernel_ms": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sk_last_dtw_retries": (C.c_int, []),
     "sk_last_dtw_tier2": (C.c_int, []),
+    "sk_last_dtw_guard": (C.c_int, [_i32p]),
+    "sk_last_dtw_premise_violations": (C.c_int, []),
+    "sk_last_dtw_audit_mismatches": (C.c_int, []),
     "sk_last_f64_retries": (C.c_int, []),
     "sk_last_dtw_clock": (C.c_int, [_dp]),
     "sk_last_dtw_profile": (C.c_int, [C.POINTER(C.c_float), _i32p, C.POINTER(C.c_float), _i32p, _i32p]),

@@ -413,6 +413,19 @@ def motifseq_batch(sig, lens, motif, scale="medmad", scale_low=0, scale_hi=1200,
     return out
 
 
+GUARD_FIELDS = ("premise_violations", "audited", "audit_mismatches", "image_rejects", "alarm", "exact_fallback")
+
+
+def last_dtw_guard():
+    """Run-time guard counters of the most recent DTW call on this thread's device (sk_last_dtw_guard): premise
+    violations the window pass found, reads audited by the exact pass and how many of them differed, reads kept from
+    the screening because their sample image could not be bounded, the alarm count, and whether the whole call was
+    redone by the exact pass.  A healthy build reports 0 violations / 0 mismatches, always."""
+    g = (C.c_int32 * 8)()
+    check(_lib.load().sk_last_dtw_guard(g))
+    return dict(zip(GUARD_FIELDS, (int(v) for v in g)))
+
+
 def motifseq_reads_f64(reads, motif, scale="medmad", scale_low=0, scale_hi=1200):
     """Same as motifseq_batch for float64 (pA) reads given as a list (MotifSeq.py:270)."""
     L = _lib.ensure_init()

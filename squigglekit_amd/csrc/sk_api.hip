@@ -163,6 +163,22 @@ int sk_host_free(void *p)
 }
 
 // ------------------------------------------------------------------ MotifSeq, device resident
+// Last step of the host-facing DTW entry points: the guard counters of the screening scheme (sk_last_dtw_guard) ride
+// with the final synchronisation, and an alarm -- something that cannot happen in a healthy build -- is said out loud
+// once per call (the records are right either way: the library redid the call with the exact pass).
+static int finish_dtw_host(sk_ctx *c)
+{
+    int32_t g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c->retry_dev && c->dtwcnt.p)
+        SK_HIP(hipMemcpyAsync(g, (const int32_t *)c->dtwcnt.p + 8, sizeof g, hipMemcpyDeviceToHost, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));
+    if (g[4])
+        fprintf(stderr, "squigglekit: DTW screening guard: %d premise violation(s), %d audit mismatch(es) of %d audited reads -- "
+                        "the call was %s by the exact pass; please report this\n", g[0], g[2], g[1],
+                g[5] ? "redone" : "NOT redone");
+    return SK_OK;
+}
+
 int sk_motifseq_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
                         const double *motif, int32_t nmotif, int32_t scale_mode,
                         int32_t scale_low, int32_t scale_hi, sk_hit *d_out)
@@ -257,7 +273,7 @@ int sk_motifseq_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len
         if (rc) return rc;
     }
     SK_HIP(hipMemcpyAsync(out, c->out.p, (size_t)nreads * sizeof(sk_hit), hipMemcpyDeviceToHost, c->stream));
-    SK_HIP(hipStreamSynchronize(c->stream));
+    if ((rc = finish_dtw_host(c))) return rc;
     return SK_OK;
 }
 
@@ -375,7 +391,7 @@ int sk_motifseq_multi_batch_i16(const int16_t *sig, int64_t stride, const int32_
     }
     c->ev_valid = true;
     SK_HIP(hipMemcpyAsync(out, c->out.p, ob, hipMemcpyDeviceToHost, c->stream));
-    SK_HIP(hipStreamSynchronize(c->stream));
+    if ((rc = finish_dtw_host(c))) return rc;
     return SK_OK;
 }
 
@@ -463,7 +479,7 @@ int sk_motifseq_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
                           scale_mode, scale_low, scale_hi, (sk_hit *)c->out.p);
     if (rc) return rc;
     SK_HIP(hipMemcpyAsync(out, c->out.p, (size_t)nreads * sizeof(sk_hit), hipMemcpyDeviceToHost, c->stream));
-    SK_HIP(hipStreamSynchronize(c->stream));
+    if ((rc = finish_dtw_host(c))) return rc;
     return SK_OK;
 }
 
@@ -518,7 +534,7 @@ int sk_dtw_subsequence_batch(const double *x, int32_t nx, const double *y, const
     if ((rc = sk_launch_sdtw(c, &a))) return rc;
     c->ev_valid = true;
     SK_HIP(hipMemcpyAsync(out, c->out.p, (size_t)nreads * sizeof(sk_hit), hipMemcpyDeviceToHost, c->stream));
-    SK_HIP(hipStreamSynchronize(c->stream));
+    if ((rc = finish_dtw_host(c))) return rc;
     return SK_OK;
 }
 

@@ -77,7 +77,8 @@ struct sk_ctx {
     std::vector<double> motifw_host;
     int    motifq_L = 0;   // lanes per read of the layouts in motifq / motifw
     sk_buf retry;     // DTW retry list: [0] = count, [1] = pad, [2 ..] = reads (segmenter: [0] = count, [1 ..] = reads)
-    sk_buf dtwcnt;    // [0] = reads retried by the exact pass, summed over the launches of one API call (device)
+    sk_buf dtwcnt;    // [0] = reads retried by the exact pass, summed over the launches of one API call (device); [1] second tier; +16 clock; +32 guard counters
+    sk_buf audit;     // the audit's read list ([0] = count, [2 ..] = reads) and its exact records
     bool   retry_dev = false;   // the last DTW call left its retry count on the device (read lazily)
     std::vector<unsigned> motifq_host;
     bool   motifq_valid = false;

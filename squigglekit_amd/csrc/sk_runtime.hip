@@ -72,6 +72,9 @@ static const sk_tunable SK_TUNABLES[] = {
     {"SK_DTW_NOSORT",         "1",           "window passes take the reads in file order"},
     {"SK_DTW_SORT_MIN",       "1",           "window passes sort chunks of at least this many reads"},
     {"SK_DTW_NO_EARLY",       "1",           "no early exact retry beside the window passes"},
+    {"SK_DTW_NOGUARD",        "1",           "screening scheme without its run-time guard (premise test in the window pass, audit, gated exact fallback): A/B cost runs"},
+    {"SK_DTW_AUDIT_PERIOD",   "0 1 64",      "the audit re-runs one read in this many with the exact pass (default 4096; 0: no audit)"},
+    {"SK_DTW_HOLE",           "qerr1 fma64 fma64x", "tests: a known precision hole put back (E = 1; the fma sample image for float64 reads, with / without the image-error guard) -- the guard has to notice and the records must not change"},
     {"SK_DTW_SCRATCH_MB",     "8 64",        "checkpoint scratch budget in MB (small values force many chunks)"},
     {"SK_DTW_NO_SMALL",       "1",           "small batches keep the batch lane layout"},
     {"SK_DTW_SMALL_MAX",      "0 100000",    "largest batch that spreads a read over 64 lanes"},
@@ -190,7 +193,7 @@ int sk_shutdown(void)
         (void)hipStreamSynchronize(c->stream);
         sk_buf *bufs[] = {&c->sig, &c->len, &c->off, &c->comp, &c->prep, &c->mask,
                           &c->motif, &c->out, &c->out2, &c->misc, &c->ckpt, &c->retry, &c->motifq, &c->lastq, &c->qflag,
-                          &c->motif64, &c->commbuf, &c->dtwcnt, &c->wsoft, &c->wstate, &c->wrec, &c->motifw, &c->lsum, &c->wrecq, &c->order, &c->pacal, &c->seghints};
+                          &c->motif64, &c->commbuf, &c->dtwcnt, &c->wsoft, &c->wstate, &c->wrec, &c->motifw, &c->lsum, &c->wrecq, &c->order, &c->pacal, &c->seghints, &c->audit};
         for (sk_buf *b : bufs) free_buf(b);
         for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev[i]);
         for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
@@ -346,6 +349,37 @@ int sk_last_dtw_clock(double *ghz)
         return sk_fail(SK_ERR_HIP, "reading the clock sample failed");
     if (t[1]) *ghz = (double)t[0] / ((double)t[1] / 100e6) / 1e9;
     return SK_OK;
+}
+
+// The guard counters of the last DTW call (sk_sdtw_dev.h SK_GUARD_*): out[0] premise violations found by the window
+// pass, [1] reads audited by the exact pass, [2] audit mismatches, [3] reads whose sample image could not be bounded
+// (exact pass by design), [4] alarm (= [0] + [2]), [5] 1 if the whole call was redone by the exact pass.  All zero
+// for a call that did not take the screening scheme.
+int sk_last_dtw_guard(int32_t *out)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (!out) return sk_fail(SK_ERR_INVALID, "NULL pointer");
+    memset(out, 0, 8 * sizeof(int32_t));
+    if (!(c->retry_dev && c->dtwcnt.p)) return SK_OK;
+    if (hipMemcpyAsync(out, (const int32_t *)c->dtwcnt.p + 8, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return sk_fail(SK_ERR_HIP, "reading the guard counters failed");
+    return SK_OK;
+}
+
+int sk_last_dtw_premise_violations(void)
+{
+    int32_t g[8];
+    const int rc = sk_last_dtw_guard(g);
+    return rc ? rc : g[0];
+}
+
+int sk_last_dtw_audit_mismatches(void)
+{
+    int32_t g[8];
+    const int rc = sk_last_dtw_guard(g);
+    return rc ? rc : g[2];
 }
 
 int sk_last_dtw_tier2(void)

@@ -60,6 +60,10 @@ void k_sdtw(const sdtw_kargs a)
     const int g = lane / L, l = lane % L;
     int slot = wave * G + g;
     int nreads = a.nreads;
+    if (a.gate_ptr) {                               // whole-call fallback: runs only when the guard raised an alarm
+        if (*a.gate_ptr == 0) return;               // (launch-uniform)
+        if (a.guard && blockIdx.x == 0 && threadIdx.x == 0) a.guard[SK_GUARD_FELLBACK] = 1;
+    }
     if (a.count_ptr) {                              // retry pass: the list length is only known on the device
         const int cnt = *a.count_ptr;
         if (a.total_ptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.total_ptr, cnt);
@@ -282,9 +286,46 @@ void k_sdtw(const sdtw_kargs a)
             else       { h.dist = __builtin_nan(""); h.start = -1; h.end = -1; }
             h.n = n;
             h.flags = flags;
-            a.out[r] = h;
+            a.out[a.out_by_slot ? a.list_off + slot : r] = h;
         }
     }
+}
+
+// ---- the audit (round 5): which reads, and the comparison -----------------------------------------------------
+// read of audit slot s: a hashed position inside [s * period, (s + 1) * period)
+__global__ void k_audit_pick(int32_t *list, int naudit, int period, int nreads)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0) { list[0] = naudit; list[1] = 0; }
+    if (s >= naudit) return;
+    const int64_t base = (int64_t)s * period;
+    const int span = (int)min((int64_t)period, (int64_t)nreads - base);
+    unsigned h = (unsigned)s * 2654435761u + 0x9E3779B9u;
+    h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
+    list[2 + s] = (int)(base + (int64_t)(h % (unsigned)span));
+}
+
+// exact record vs the screening scheme's: distance bit for bit (two NaNs agree), start, end, n.  The exact one wins.
+__global__ void k_audit_compare(const int32_t *list, const sk_hit *exact, sk_hit *out, int naudit, int32_t *guard)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= naudit) return;
+    const int r = list[2 + s];
+    const sk_hit e = exact[s], g = out[r];
+    const bool same_d = (__double_as_longlong(e.dist) == __double_as_longlong(g.dist)) || (e.dist != e.dist && g.dist != g.dist);
+    if (same_d && e.start == g.start && e.end == g.end && e.n == g.n) return;
+    out[r] = e;
+    atomicAdd(&guard[SK_GUARD_MISMATCH], 1);
+    atomicAdd(&guard[SK_GUARD_ALARM], 1);
+}
+
+static void sk_audit_pick(int32_t *list, int naudit, int period, int nreads, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_audit_pick, dim3((naudit + 255) / 256), dim3(256), 0, st, list, naudit, period, nreads);
+}
+static void sk_audit_compare(const int32_t *list, const sk_hit *exact, sk_hit *out, int naudit, int32_t *guard, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_audit_compare, dim3((naudit + 255) / 256), dim3(256), 0, st, list, exact, out, naudit, guard);
 }
 
 typedef void (*sdtw_fn)(const sdtw_kargs);
@@ -558,7 +599,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
     int32_t *ecnt = cnt + a->nreads + 2;                   // a second list of the same shape: the early retry's
     SK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), c->stream));
     SK_HIP(hipMemsetAsync(ecnt, 0, sizeof(int32_t), c->stream));
-    if (!a->accumulate) SK_HIP(hipMemsetAsync(c->dtwcnt.p, 0, 32, c->stream));   // [0] retried, [1] second tier, +16: clock
+    if (!a->accumulate) SK_HIP(hipMemsetAsync(c->dtwcnt.p, 0, 64, c->stream));   // [0] retried, [1] second tier, +16: clock, +32: guard counters
     c->retry_dev = true;
     // the motif laid out for 64 lanes (the short retry list is swept with a read per wavefront): uploaded here, ahead
     // of everything the call enqueues, because the early retry runs on another stream
@@ -598,6 +639,58 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
         return launch(c, ff, kr, L, stream);
     };
     if (a->fuse && !qok) return sk_fail(SK_ERR_INVALID, "internal: fused prologue without a screening pass");
+    // ---- the guard around the screening scheme (round 5) -----------------------------------------
+    // (a) pass W tests the certificate's premise on every result it accepts (k_sdtw_w: premise_holds);
+    // (b) AUDIT: one read in every `period` (hashed position inside each run of `period` reads; 4 096) is also swept
+    //     by the exact single pass, on the third stream beside the window passes, into records of its own; a compare
+    //     kernel behind everything counts the records that differ, and the exact one wins;
+    // (c) FALLBACK: if (a) or (b) counted anything the premise is broken for reasons unknown, so no record of this call
+    //     is trusted: the exact single pass over ALL reads is enqueued behind a gate word and returns at once while
+    //     that word is zero (no host synchronisation anywhere).  sk_last_dtw_guard() reports the counters.
+    int32_t *guard = (int32_t *)c->dtwcnt.p + 8;
+    const bool guarded = qok && sk_tune("SK_DTW_NOGUARD") == nullptr;
+    int audit_period = 4096;
+    if (const char *e = sk_tune("SK_DTW_AUDIT_PERIOD")) { const int v = atoi(e); if (v >= 0) audit_period = v; }
+    const int naudit = (guarded && audit_period > 0) ? (int)((a->nreads + audit_period - 1) / audit_period) : 0;
+    int32_t *alist = nullptr;  sk_hit *aout = nullptr;
+    if (naudit) {
+        if ((rc = sk_reserve(c, &c->audit, ((size_t)naudit + 2) * sizeof(int32_t) + 16 + (size_t)naudit * sizeof(sk_hit)))) return rc;
+        alist = (int32_t *)c->audit.p;
+        aout = (sk_hit *)((char *)c->audit.p + ((((size_t)naudit + 2) * sizeof(int32_t) + 15) & ~(size_t)15));
+    }
+    auto launch_audit = [&](hipStream_t stream) -> int {    // the exact pass over the audit reads (records by slot)
+        if (!naudit) return SK_OK;
+        sk_audit_pick(alist, naudit, audit_period, a->nreads, stream ? stream : c->stream);
+        SK_HIP(hipGetLastError());
+        sdtw_kargs kr = k;
+        kr.read0 = 0; kr.ridx = alist + 2; kr.count_ptr = alist; kr.ckpt = nullptr; kr.out = aout; kr.out_by_slot = 1;
+        kr.total_ptr = guard + SK_GUARD_AUDITED; kr.list_off = 0;
+        const int R64 = (N + 63) / 64, P64 = 64 * R64 - N;
+        sdtw_fn f64 = (L == 16) ? pick_any(a->feed, 64, R64, MODE_FULL) : nullptr;
+        if (f64) {                                          // a short list: one read per wavefront, as the retry
+            sdtw_kargs k64 = kr;
+            k64.xlay = (const double *)c->motif64.p; k64.P = P64;
+            k64.nreads = naudit < 8192 ? naudit : 8192;
+            int rc2;
+            if ((rc2 = launch(c, f64, k64, 64, stream))) return rc2;
+            if (naudit <= 8192) return SK_OK;
+            kr.list_off = 8192; kr.total_ptr = nullptr; kr.nreads = naudit - 8192;
+            return launch(c, ff, kr, L, stream);
+        }
+        kr.nreads = naudit;
+        return launch(c, ff, kr, L, stream);
+    };
+    auto finish_guard = [&]() -> int {                      // on the main stream, behind every writer of out[]
+        if (!guarded) return SK_OK;
+        if (naudit) {
+            sk_audit_compare(alist, aout, a->out, naudit, guard, c->stream);
+            SK_HIP(hipGetLastError());
+        }
+        sdtw_kargs kf = k;                                  // the gated exact pass over the whole call
+        kf.read0 = 0; kf.nreads = a->nreads; kf.ridx = nullptr; kf.count_ptr = nullptr; kf.ckpt = nullptr;
+        kf.gate_ptr = guard + SK_GUARD_ALARM; kf.guard = guard;
+        return launch(c, ff, kf, L);
+    };
     if (qok) {
         // The reads pass Q itself finds unscreenable (on the C4 batch: all of the ~190 that retry) get their exact
         // pass on a third stream as soon as pass Q is done -- one sweep's latency (0.5 ms) that then runs beside the
@@ -612,10 +705,13 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
         if (early) {
             SK_HIP(hipStreamWaitEvent(c->stream3, c->ev_r[0], 0));
             if ((rc = launch_retry(ecnt, c->stream3))) return rc;
+            if ((rc = launch_audit(c->stream3))) return rc;
             SK_HIP(hipEventRecord(c->ev_r[1], c->stream3));
         }
         if ((rc = launch_retry())) return rc;
         if (early) SK_HIP(hipStreamWaitEvent(c->stream, c->ev_r[1], 0));
+        else if ((rc = launch_audit(nullptr))) return rc;
+        if ((rc = finish_guard())) return rc;
         SK_HIP(hipEventRecord(c->ev[3], c->stream));
         return SK_OK;
     }

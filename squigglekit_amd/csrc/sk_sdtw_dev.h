@@ -22,6 +22,16 @@ constexpr double   QLIM   = 400.0;              // |x|, |y| must stay below this
 constexpr unsigned QINF   = 0xFFFFFFFFu;        // "+inf" cost, and the sample fed outside [0, n)
 constexpr unsigned QSAFE  = 0xF0000000u;        // a minimum at or above this may have saturated
 
+// Guard counters of one DTW call (device, ints 8.. of sk_ctx::dtwcnt; sk_last_dtw_guard()):
+enum { SK_GUARD_VIOL = 0,       // window pass: an accepted result contradicted the screening values it rests on
+       SK_GUARD_AUDITED = 1,    // reads the audit re-ran with the exact single pass
+       SK_GUARD_MISMATCH = 2,   // ... whose record differed from the screening scheme's (the exact record then wins)
+       SK_GUARD_IMGREJ = 3,     // reads whose sample image cannot be bounded tightly enough: exact pass, by design
+       SK_GUARD_ALARM = 4,      // VIOL + MISMATCH: non-zero opens the gate of the whole-call exact fallback
+       SK_GUARD_FELLBACK = 5,   // the whole call was redone by the exact single pass
+       SK_GUARD_WORDS = 8 };
+enum { SK_HOLE_NONE = 0, SK_HOLE_QERR1 = 1, SK_HOLE_FMA64 = 2, SK_HOLE_FMA64_UNGUARDED = 3 };
+
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int old, int src)
 {
@@ -87,6 +97,11 @@ struct sdtw_kargs {
     int32_t       *early_cnt;   // range): their exact retry starts right behind pass Q, beside the window passes
     unsigned long long *clk;    // pass Q: {shader cycles, 100 MHz reference ticks} of the first wave's sweep, or nullptr
     int            force_retry; // sensitivity runs: reads whose hash (10 bits) is below this take the exact retry
+    // run-time guard of the screening certificate: counters in device memory, see SK_GUARD_*
+    int32_t       *guard;       // [SK_GUARD_WORDS] or nullptr
+    int            hole;        // tests only (SK_DTW_HOLE): SK_HOLE_* -- a known precision hole re-introduced on purpose
+    int            out_by_slot; // exact kernel: the record of launch slot s goes to out[s], not out[read] (audit pass)
+    const int32_t *gate_ptr;    // exact kernel: the whole launch returns at once unless *gate_ptr != 0 (whole-call fallback)
     // window pass, second tier: the reads of one chunk whose path crossed the first (short) look-back
     const int32_t *wl_list;     // reads to process (nullptr: all of the chunk); wl_count: their number (device)
     const int32_t *wl_count;

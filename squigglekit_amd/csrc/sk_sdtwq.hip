@@ -258,11 +258,29 @@ void k_sdtw_q(const sdtw_kargs a)
     // first, exactly for samples near c.  Rounding to the nearest integer by adding 1.5 * 2^52: the sum's low word is
     // the two's complement integer.
     const double qa = inv_scale * QSCALE, qb = -center * qa;
+    // Guard, per read (round 5): the certificate's E = N + n + 2 leaves every sample image 1/2 unit of rounding plus
+    // an evaluation error of at most 1 / (N + n) units.  What the evaluation can be off by is known here: the fma form
+    // is t (e1 + e3) - c qa e2 with |e| <= 2^-53 (the reciprocal, the fma's rounding, the rounding of the constant
+    // -c qa), i.e. <= 3.8e-7 + |c| qa 1.2e-16 units for |t| < 400 * 2^22; the difference form (float64 reads) is three
+    // roundings of t, <= 5.7e-7.  A read whose bound times (N + n) exceeds 1 -- a level of 30 000 over a MAD of 1 in a
+    // 50 000-sample read, or any near-constant float64 read if the fma form were used for it (the hole the round-4
+    // fuzz found; SK_DTW_HOLE=fma64 puts it back for the tests) -- is not screened: exact pass, counted (IMGREJ).
+    const bool fma64 = FEED == SK_FEED_F64_NORM && a.hole >= SK_HOLE_FMA64;
+    if (live && n > 0) {
+        double imgerr = 0.0;
+        if (FEED == SK_FEED_I16 || fma64)            imgerr = 3.8e-7 + fabs(center) * qa * 1.2e-16;
+        else if constexpr (FEED == SK_FEED_F64_NORM) imgerr = 5.7e-7;
+        const bool rej = !(imgerr * (double)a.qerr <= 1.0) && a.hole != SK_HOLE_FMA64_UNGUARDED;   // (NaN: rejected)
+        if (rej) {
+            bad = 1;
+            if (l == 0 && a.guard) atomicAdd(&a.guard[SK_GUARD_IMGREJ], 1);
+        }
+    }
     auto toq = [&](auto raw_, int idx) -> unsigned {
         const double raw = (double)raw_;
         double t;
         if constexpr (FEED == SK_FEED_I16)           t = __builtin_fma(raw, qa, qb);
-        else if constexpr (FEED == SK_FEED_F64_NORM) t = (raw - center) * qa;
+        else if constexpr (FEED == SK_FEED_F64_NORM) t = fma64 ? __builtin_fma(raw, qa, qb) : (raw - center) * qa;
         else                                         t = raw * QSCALE;
         const bool ok = fabs(t) < QLIM * QSCALE;     // false for NaN / inf too
         const unsigned q = (unsigned)__double2loint(t + 6755399441055744.0) ^ 0x80000000u;
@@ -708,15 +726,33 @@ void k_sdtw_w(const sdtw_kargs a)
         F = Fnext;
     }
 
+    // Guard (round 5).  The certificate is a theorem ABOUT the screening values: it assumes |Dq - D| <= E in every
+    // cell, which is argued (E's derivation, the sample image) and which nothing used to check -- the round-4 fuzz found
+    // it silently false for float64 reads after three rounds of green tests.  A certified winner is an exact cell of the
+    // last row, so the assumption can be tested where it is about to be relied on: the exact distance must lie within
+    // E of the screening value of ITS OWN column, and not more than E above the screening minimum of the whole row
+    // (the column that holds that minimum has an exact cost of at most minimum + E, and the winner beats it).  Two loads
+    // per read.  A violation is counted, raises the call's alarm (the whole call is then redone by the exact pass,
+    // sk_launch_sdtw) and sends the read to the exact retry.
+    auto premise_holds = [&](double bestD, int j) -> bool {
+        if (!a.guard) return true;
+        const unsigned lq = a.lastq[(int64_t)(r - a.read0) * a.lq_stride + j + L];   // (rows start L early)
+        const unsigned bq = (unsigned)a.qflag[r - a.read0];
+        const double u = bestD * QSCALE, e = (double)a.qerr;
+        const bool ok = fabs(u - (double)lq) <= e && u <= (double)bq + e;
+        if (!ok) { atomicAdd(&a.guard[SK_GUARD_VIOL], 1); atomicAdd(&a.guard[SK_GUARD_ALARM], 1); }
+        return ok;
+    };
     if (live && l == L - 1) {
         sk_hit h;
         h.n = n; h.flags = flags;
         // tuning / sensitivity runs only: send a share of the reads to the exact retry whatever the window found
         const bool forced = a.force_retry && (((unsigned)r * 2654435761u) >> 22) < (unsigned)a.force_retry;
+        bool certified = false;
         if (n <= 0) {
             h.dist = __builtin_nan(""); h.start = -1; h.end = -1;
             a.out[r] = h;
-        } else if (screened && bestS >= 0 && !forced) {
+        } else if (screened && bestS >= 0 && !forced && (certified = premise_holds(best, bestJ))) {
             h.dist = best; h.start = bestS; h.end = bestJ;
             a.out[r] = h;
         } else if (!screened && a.early_cnt) {
@@ -724,8 +760,9 @@ void k_sdtw_w(const sdtw_kargs a)
         } else {
             h.dist = __builtin_nan(""); h.start = -1; h.end = -1;    // overwritten by a later pass
             a.out[r] = h;
-            if (screened && a.soft && !forced) a.soft[atomicAdd(a.soft_cnt, 1)] = r;   // path wider than this look-back: next tier
-            else                               a.retry[atomicAdd(a.retry_cnt, 1)] = r; // the exact single pass
+            const bool violated = screened && bestS >= 0 && !forced && !certified;     // (a wider look-back cannot mend that)
+            if (screened && a.soft && !forced && !violated) a.soft[atomicAdd(a.soft_cnt, 1)] = r;   // path wider than this look-back: next tier
+            else                                            a.retry[atomicAdd(a.retry_cnt, 1)] = r; // the exact single pass
         }
     }
 }
@@ -971,6 +1008,12 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
     k.early_cnt = d_early_cnt; k.early = d_early;
     k.qerr = (unsigned)(N + maxlen + 2);
     k.wmax = 4 * ck;
+    k.guard = sk_tune("SK_DTW_NOGUARD") ? nullptr : (int32_t *)c->dtwcnt.p + 8;
+    if (const char *e = sk_tune("SK_DTW_HOLE")) {                 // tests: a known hole back in, for the guard to find
+        k.hole = strcmp(e, "qerr1") == 0 ? SK_HOLE_QERR1 : strcmp(e, "fma64") == 0 ? SK_HOLE_FMA64
+               : strcmp(e, "fma64x") == 0 ? SK_HOLE_FMA64_UNGUARDED : SK_HOLE_NONE;
+        if (k.hole == SK_HOLE_QERR1) k.qerr = 1;                  // "E = 1": lower bounds that are none, too few candidates
+    }
     if (const char *e = sk_tune("SK_DTW_FORCE_RETRY_PM")) {       // sensitivity runs: per-mille of reads sent to the retry
         const int pm = atoi(e);
         if (pm > 0) k.force_retry = pm >= 1000 ? 1024 : (pm * 1024 + 999) / 1000;

@@ -92,6 +92,12 @@ def _full_size(gpu, ora, R, M, N, seed, nsample, min_chunks):
         check(L.sk_sync())
         launches, per_launch = _dtw_profile(L)
         assert launches >= min_chunks, "expected the chunked path (%d launches)" % launches
+        # the run-time guard of the screening certificate: one read in 4 096 re-run by the exact pass, every accepted
+        # window result tested against the screening values it rests on -- nothing to report on a healthy build
+        from squigglekit_amd import api
+        g = api.last_dtw_guard()
+        assert g["audited"] == (R + 4095) // 4096, g
+        assert g["premise_violations"] == 0 and g["audit_mismatches"] == 0 and g["exact_fallback"] == 0, g
         hits = np.empty(R, dtype=HIT_DTYPE)
         check(L.sk_dev_download(ptr(hits), d_out, hits.nbytes))
         # size-independent properties over the WHOLE batch
