@@ -207,11 +207,39 @@ def segment_reads_f64(reads, params=None, max_segs=64):
         return [segs[i, :nsegs[i]].tolist() if nsegs[i] else False for i in range(R)]
 
 
-def segment_batch_pa(sig, lens, calib, params=None, max_segs=64):
+def _over_devices(devices, R, call):
+    """call(lo, hi) -> status on the calling thread's GPU, or -- with several devices -- on one host thread per GPU
+    over the block split of the R reads (multigpu.run_sharded; every shard writes its slice of the caller's arrays).
+    Returns SK_ERR_OVERFLOW if any shard overflowed, else 0; any other failure raises."""
+    devices = _devs(devices)
+    if devices is not None and len(devices) > 1 and R >= len(devices):
+        from . import multigpu
+        rcs = []
+
+        def shard(lo, hi, comm):
+            if hi > lo:
+                rc = call(lo, hi)
+                if rc != _lib.SK_ERR_OVERFLOW:
+                    check(rc)
+                rcs.append(rc)
+        multigpu.run_sharded(devices, R, shard)
+        return _lib.SK_ERR_OVERFLOW if _lib.SK_ERR_OVERFLOW in rcs else 0
+    if devices:
+        _lib.init(devices[0])
+    else:
+        _lib.ensure_init()
+    rc = call(0, R)
+    if rc != _lib.SK_ERR_OVERFLOW:
+        check(rc)
+    return rc
+
+
+def segment_batch_pa(sig, lens, calib, params=None, max_segs=64, devices=None):
     """Raw int16 rows through the pA route (segmenter.py:345-349: fast5 / slow5 input without --raw_signal): the
     conversion np.round((raw + offset) * (float("%.2f" % range) / digitisation), 2) runs on the GPU, then the float64
-    segmenter path.  calib: float64 [R, 3] = digitisation, offset, range per read.  Returns (segs, nsegs)."""
-    L = _lib.ensure_init()
+    segmenter path.  calib: float64 [R, 3] = digitisation, offset, range per read.  Returns (segs, nsegs).
+    devices (or api.set_devices / --gpus): the reads are block-sharded like segment_batch's."""
+    L = _lib.load()
     sig = np.ascontiguousarray(sig, dtype=np.int16)
     R = sig.shape[0]
     lens = np.ascontiguousarray(lens, dtype=np.int32)
@@ -220,19 +248,21 @@ def segment_batch_pa(sig, lens, calib, params=None, max_segs=64):
     while True:
         segs = np.zeros((max(R, 1), max_segs, 2), dtype=np.int32)
         nsegs = np.zeros(max(R, 1), dtype=np.int32)
-        rc = L.sk_segment_batch_i16_pa(ptr(sig), sig.shape[1], ptr(lens), R, ptr(calib), C.byref(params), ptr(segs),
-                                       ptr(nsegs), max_segs)
+        rc = _over_devices(devices, R, lambda lo, hi, ms=max_segs: L.sk_segment_batch_i16_pa(
+            ptr(sig[lo:hi]), sig.shape[1], ptr(lens[lo:hi]), hi - lo, ptr(calib[lo:hi]), C.byref(params),
+            ptr(segs[lo:hi]), ptr(nsegs[lo:hi]), ms))
         if rc == _lib.SK_ERR_OVERFLOW:
             max_segs = int(nsegs.max()) + 8
             continue
-        check(rc)
         return segs[:R], nsegs[:R]
 
 
-def segment_ragged_f64(values, off, lens=None, params=None, max_segs=64):
+def segment_ragged_f64(values, off, lens=None, params=None, max_segs=64, devices=None):
     """scale_outliers + get_segs for a ragged float64 batch as a tokenizer leaves it: read r is the first lens[r]
-    (default: all) of values[off[r]:off[r+1]].  Returns (segs int32 [R, max_segs, 2], nsegs int32 [R])."""
-    L = _lib.ensure_init()
+    (default: all) of values[off[r]:off[r+1]].  Returns (segs int32 [R, max_segs, 2], nsegs int32 [R]).
+    devices (or api.set_devices / --gpus): block-sharded over the GPUs (a shard is a run of offsets into the same
+    `values`: nothing is repacked)."""
+    L = _lib.load()
     values = np.ascontiguousarray(values, dtype=np.float64)
     off = np.ascontiguousarray(off, dtype=np.int64)
     R = off.size - 1
@@ -241,29 +271,35 @@ def segment_ragged_f64(values, off, lens=None, params=None, max_segs=64):
     while True:
         segs = np.zeros((max(R, 1), max_segs, 2), dtype=np.int32)
         nsegs = np.zeros(max(R, 1), dtype=np.int32)
-        rc = L.sk_segment_batch_f64_len(ptr(values), ptr(off), None if ln is None else ptr(ln), R, C.byref(params),
-                                        ptr(segs), ptr(nsegs), max_segs)
+        rc = _over_devices(devices, R, lambda lo, hi, ms=max_segs: L.sk_segment_batch_f64_len(
+            ptr(values), ptr(off[lo:hi + 1]), None if ln is None else ptr(ln[lo:hi]), hi - lo, C.byref(params),
+            ptr(segs[lo:hi]), ptr(nsegs[lo:hi]), ms))
         if rc == _lib.SK_ERR_OVERFLOW:
             max_segs = int(nsegs.max()) + 8
             continue
-        check(rc)
         return segs[:R], nsegs[:R]
 
 
-def motifseq_multi_ragged_f64(values, off, motifs, scale="medmad", scale_low=0, scale_hi=1200):
-    """Every motif against a ragged float64 batch (read r = values[off[r]:off[r+1]]): one record array per motif."""
-    L = _lib.ensure_init()
+def motifseq_multi_ragged_f64(values, off, motifs, scale="medmad", scale_low=0, scale_hi=1200, devices=None):
+    """Every motif against a ragged float64 batch (read r = values[off[r]:off[r+1]]): one record array per motif.
+    devices (or api.set_devices / --gpus): block-sharded over the GPUs."""
+    L = _lib.load()
     values = np.ascontiguousarray(values, dtype=np.float64)
     off = np.ascontiguousarray(off, dtype=np.int64)
     R = off.size - 1
-    out = []
-    for m in motifs:
-        m = np.ascontiguousarray(m, dtype=np.float64)
-        hits = np.zeros(max(R, 1), dtype=HIT_DTYPE)
-        check(L.sk_motifseq_batch_f64(ptr(values), ptr(off), R, ptr(m), m.size, _lib.SK_SCALE[scale], int(scale_low),
-                                      int(scale_hi), ptr(hits)))
-        out.append(hits[:R])
-    return out
+    ms = [np.ascontiguousarray(m, dtype=np.float64) for m in motifs]
+    out = [np.zeros(max(R, 1), dtype=HIT_DTYPE) for _ in ms]
+
+    def call(lo, hi):
+        for m, hits in zip(ms, out):
+            rc = L.sk_motifseq_batch_f64(ptr(values), ptr(off[lo:hi + 1]), hi - lo, ptr(m), m.size, _lib.SK_SCALE[scale],
+                                         int(scale_low), int(scale_hi), ptr(hits[lo:hi]))
+            if rc:
+                return rc
+        return 0
+    if R:
+        _over_devices(devices, R, call)
+    return [h[:R] for h in out]
 
 
 def drna_segment_batch(sig, lens, params=None, max_segs=32):

@@ -801,9 +801,15 @@ int sk_segment_batch_f64_len(const double *sig, const int64_t *off, const int32_
         for (int32_t r = 0; r < nreads; r++)
             if (len[r] < 0 || (int64_t)len[r] > off[r + 1] - off[r])
                 return sk_fail(SK_ERR_INVALID, "len[%d] = %d is outside [0, %lld]", r, len[r], (long long)(off[r + 1] - off[r]));
-        if ((rc = sk_reserve(c, &c->len, (size_t)nreads * sizeof(int32_t)))) return rc;
-        SK_HIP(hipMemcpyAsync(c->len.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        d_rlen = (const int32_t *)c->len.p;
+        // (a buffer of its own: segment_dev_f64 hands c->len to the statistics kernel as the place for the lengths the
+        // walk reads, and the numpy-order redo looks at the cut again afterwards)
+        if ((rc = sk_reserve(c, &c->rlen, (size_t)nreads * sizeof(int32_t)))) return rc;
+        SK_HIP(hipMemcpyAsync(c->rlen.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        d_rlen = (const int32_t *)c->rlen.p;
+        // the cut, not the slot, decides the mask row size and which statistics kernel runs (-n 3000 on 40 000-sample
+        // lines takes the 4 096-sample kernel)
+        maxlen = 0;
+        for (int32_t r = 0; r < nreads; r++) if (len[r] > maxlen) maxlen = len[r];
     }
     const size_t gb = (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t);
     if ((rc = sk_reserve(c, &c->out, gb))) return rc;

@@ -50,6 +50,7 @@ struct sk_ctx {
     // scratch (grown on demand, reused across calls)
     sk_buf sig;       // staged input samples
     sk_buf len;       // int32 per read
+    sk_buf rlen;      // int32 per read: the caller's per-read cut of a ragged float64 batch (sk_segment_batch_f64_len)
     sk_buf off;       // int64 per read (+1) for ragged f64
     sk_buf comp;      // compacted samples
     sk_buf prep;      // sk_prep per read

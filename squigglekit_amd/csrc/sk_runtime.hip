@@ -193,7 +193,7 @@ int sk_shutdown(void)
         (void)hipStreamSynchronize(c->stream);
         sk_buf *bufs[] = {&c->sig, &c->len, &c->off, &c->comp, &c->prep, &c->mask,
                           &c->motif, &c->out, &c->out2, &c->misc, &c->ckpt, &c->retry, &c->motifq, &c->lastq, &c->qflag,
-                          &c->motif64, &c->commbuf, &c->dtwcnt, &c->wsoft, &c->wstate, &c->wrec, &c->motifw, &c->lsum, &c->wrecq, &c->order, &c->pacal, &c->seghints, &c->audit};
+                          &c->motif64, &c->commbuf, &c->dtwcnt, &c->wsoft, &c->wstate, &c->wrec, &c->motifw, &c->lsum, &c->wrecq, &c->order, &c->pacal, &c->seghints, &c->audit, &c->rlen};
         for (sk_buf *b : bufs) free_buf(b);
         for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev[i]);
         for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);

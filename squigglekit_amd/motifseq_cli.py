@@ -15,7 +15,7 @@ import sys
 
 import numpy as np
 
-from . import api, fastio, tsvio
+from . import _lib, api, fastio, tsvio
 from ._warm import mark as _mark
 
 _KEEP = []       # input mappings / page-locked buffers of a finished reader: released with the process
@@ -169,7 +169,14 @@ class _Batcher:
                 # equals the median
                 if norm is None:
                     norm = api.normalise(sig, a.scale, a.scale_low, a.scale_hi)
-                dist, start, end = api.dtw_subsequence_cref(np.asarray(self.models[name], dtype=np.float64), norm)
+                try:
+                    dist, start, end = api.dtw_subsequence_cref(np.asarray(self.models[name], dtype=np.float64), norm)
+                except _lib.SquiggleKitError as e:
+                    if e.code != -5:                                # SK_ERR_UNSUPPORTED: more than 2^28 cells of cost matrix
+                        raise
+                    sys.stderr.write("MotifSeq: {} has MAD 0 and is too long for the literal evaluation of the reference's "
+                                     "nan row ({} samples x {} points); skipped\n".format(read_id, len(norm), len(self.models[name])))
+                    break
             else:
                 dist, start, end = float(h["dist"]), int(h["start"]), int(h["end"])
             mod_mean = (a.slope * self.lens[c]) + a.intercept
@@ -284,6 +291,11 @@ class _Batcher:
         if self.table(n, fast5_col, id_col, hits):
             _mark("table written")
             return
+        if self._pending is not None and (self.args.sig_extract or self.args.strict_compat):
+            # emit() may call the GPU from THIS thread (api.normalise, api.dtw_subsequence_cref for a MAD = 0 read under
+            # --strict-compat) while the worker runs the next block on the same device context -- one stream, one set
+            # of scratch buffers, no lock: the next block's call has to be over first (its result stays in the future)
+            self._pending[0].exception()
         for i in range(n):
             self.emit(name_of(i), id_of(i), [hits[c][i] for c in range(len(self.order))],
                       sig_of(i) if (self.args.sig_extract or self.args.strict_compat) else None, None)

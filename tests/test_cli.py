@@ -336,6 +336,30 @@ def test_packed_and_blow5_inputs_equal_the_tsv_route(gpu, tmp_path):
 
 
 @pytest.mark.gpu
+def test_strict_compat_rows_while_the_next_block_is_on_the_gpu(gpu, scrappy_stub, tmp_path, monkeypatch):
+    """--strict-compat prints a MAD = 0 read's nan row by calling the GPU from the MAIN thread (normalise + the literal
+    mlpy kernel) -- while the worker thread may already run the next block on the same context (one stream, shared
+    scratch).  Many small blocks, a constant read in every one: the table must equal the one-block run, where nothing
+    overlaps (round-4 advisor finding: the worker has to be finished first)."""
+    from squigglekit_amd import synth
+    from squigglekit_amd.motifseq_cli import main as mmain
+    R, M = 3000, 2000
+    motif = synth.synthetic_motif(163, seed=11)
+    sig = synth.squiggle_batch(R, M, 4242, motif=motif)
+    sig[5::37, :] = 500                                       # MAD = 0 reads in every block
+    np.save(tmp_path / "r.npy", sig)
+    fa = os.path.join(GOLD, "CATCTATCCAGGGTTAAATT.fa")        # (-m under --strict-compat is the reference's header-only defect)
+    monkeypatch.setenv("SK_I16_BLOCK_MB", "1024")
+    one, err1, code = run_cli(mmain, ["--i16", str(tmp_path / "r.npy"), "-i", fa, "--strict-compat"])
+    nan_rows = one.count("\tnan\t")                            # (one per constant read and motif of the fasta)
+    assert code == 0 and nan_rows and nan_rows % len(range(5, R, 37)) == 0, err1[-300:]
+    monkeypatch.setenv("SK_I16_BLOCK_MB", "1")                # 262 reads per block: a dozen blocks in flight one after the other
+    for _ in range(3):
+        many, err2, code = run_cli(mmain, ["--i16", str(tmp_path / "r.npy"), "-i", fa, "--strict-compat"])
+        assert code == 0 and many == one
+
+
+@pytest.mark.gpu
 def test_launchers_as_processes_flush_everything_before_the_fast_exit(gpu, tmp_path):
     """The root launchers leave through os._exit once main() has returned (no interpreter / HIP teardown): everything
     printed must still arrive -- through a pipe, the case in which Python block-buffers stdout -- with exit code 0,

@@ -173,6 +173,24 @@ def test_product_api_two_ranks_on_one_device(gpu, ora, monkeypatch):
     segs, nsegs = api.segment_batch(sig, lens - 1, devices=[0, 0])
     segs1, nsegs1 = api.segment_batch(sig, lens - 1)
     assert np.array_equal(segs, segs1) and np.array_equal(nsegs, nsegs1)
+    # the pA (float64) block routes of the tools -- the reference's default input kind -- shard the same way (round 5;
+    # before, --gpus N left them on one GPU without a word): a ragged float64 batch with the per-read -n cut, raw rows
+    # through the on-device pA conversion, every motif against a ragged batch
+    pa = [np.round((sig[r, :lens[r]].astype(np.int64) + 16.0) * (1493.94 / 8192.0), 2) for r in range(501)]
+    flat = np.concatenate(pa)
+    off = np.concatenate([[0], np.cumsum([x.size for x in pa])]).astype(np.int64)
+    cut = np.minimum(lens, 2500).astype(np.int32)
+    one = api.segment_ragged_f64(flat, off, cut)
+    two = api.segment_ragged_f64(flat, off, cut, devices=[0, 0, 0])
+    assert np.array_equal(one[0], two[0]) and np.array_equal(one[1], two[1]) and one[1].sum() > 100
+    calib = np.tile(np.array([8192.0, 16.0, 1493.94]), (501, 1))
+    one = api.segment_batch_pa(sig, lens, calib)
+    two = api.segment_batch_pa(sig, lens, calib, devices=[0, 0])
+    assert np.array_equal(one[0], two[0]) and np.array_equal(one[1], two[1]) and one[1].sum() > 100
+    motifs = [motif, motif[20:120]]
+    one = api.motifseq_multi_ragged_f64(flat, off, motifs)
+    two = api.motifseq_multi_ragged_f64(flat, off, motifs, devices=[0, 0])
+    assert [h.tobytes() for h in one] == [h.tobytes() for h in two]
     multigpu.close_groups()
     gpu.init(0)                                                       # back to the plain binding for later tests
 
