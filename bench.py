@@ -27,7 +27,7 @@ per-GPU launcher) puts every rank on device D with its own context slot; the gat
 shard, read out of the gathered buffer, against the oracle (`parity.ranks_checked`): the device generator is
 deterministic in (seed + rank, row), so rank 0 regenerates any rank's rows.
 
-Rank 0 prints ONE JSON line with the driver's contract plus `roofline` (HIP-event kernel time vs algorithmic
+Rank 0 prints the headline JSON line LAST (extras, when asked for, as {"extra": ...} lines before it); it holds the driver's contract plus `roofline` (HIP-event kernel time vs algorithmic
 bytes, and the VALU-issue view that actually binds this kernel -- DESIGN.md 4.3), `cpu_baseline` (the oracle
 timed on the host: the only place it is timed), `parity` (a sample strided over the whole batch, checked
 against the oracle) and, at N = 1, `secondary` (segmenter line), `exact_only_reads_per_s` and `end_to_end`.
@@ -73,6 +73,11 @@ def parse(argv=None):
                     help="skip the N = 1 sensitivity block (real-signal windows, retry-fraction sweep)")
     ap.add_argument("--only-other-paths", action="store_true",
                     help="N = 1: after the timed region run only the other_paths block of the extras")
+    ap.add_argument("--sweep-reads", action="store_true",
+                    help="N = 1 with --no-extras: still run the reads-per-call sweep (1 M ... 31 250 reads per call; the "
+                         "one-GPU prediction of the strong-scaling curve).  Part of the default extras")
+    ap.add_argument("--full-json", default=None, metavar="PATH",
+                    help="also write headline + every extra block as ONE JSON object to PATH (tools/)")
     ap.add_argument("--ranks-on-device", type=int, default=None, metavar="D",
                     help="dry run: all --gpus ranks share device D (own context slot each, host-backend gather)")
     ap.add_argument("--force-comm", action="store_true",
@@ -240,6 +245,11 @@ def timed(w, comm, steps, warmup):
                 prof["retries"] += rt
     fence()
     elapsed = time.perf_counter() - t0
+    if w.R and w.kind == "motifseq":                       # the screening scheme's run-time guard, last timed step
+        g = (C.c_int32 * 8)()
+        check(w.L.sk_last_dtw_guard(g))
+        prof["guard"] = {"premise_violations": int(g[0]), "audited_reads": int(g[1]), "audit_mismatches": int(g[2]),
+                         "image_rejects": int(g[3]), "exact_fallback": int(g[5])}
     w.own_elapsed = elapsed                                # (this rank's; the return value is the maximum over ranks)
     if comm is not None:
         elapsed = float(comm.allgather_host(np.array([elapsed], dtype=np.float64)).max())
@@ -590,6 +600,85 @@ def sensitivity_block(a, L, main):
     out["stretched_motif_in_half_of_the_reads"] = wide
     main.regenerate()                                                 # the default batch again
     return out
+
+
+def sweep_block(a, L, main):
+    """N = 1: the headline's kernels on 1 M / 500 k / 250 k / 125 k / 62.5 k / 31 250 of the resident reads per call --
+    what each GPU sees when C4 (1 M reads IN TOTAL) is block-sharded over 1 / 2 / 4 / 8 / 16 / 32 GPUs -- for MotifSeq and
+    for the segmenter.  No multi-GPU node was available to any round so far: this is the one-GPU prediction of the
+    strong-scaling curve (the per-rank work is exactly a call of that size; what it leaves out is the 24 B/read
+    all-gather, 3 MB per GPU at N = 8, and PCIe ingest, which bench.py's end_to_end block times).  Fit: ms = fixed + per_read * R
+    over the sizes; predicted efficiency at N GPUs = rate(R / N) / rate(R)."""
+    from squigglekit_amd._lib import SegParams, check, ptr
+    sizes = [main.R // d for d in (1, 2, 4, 8, 16, 32) if main.R // d >= 4096]
+
+    def fit(rows):
+        x = np.array([r["reads_per_call"] for r in rows], dtype=np.float64)
+        y = np.array([r["ms"] for r in rows], dtype=np.float64)
+        b, c = np.polyfit(x, y, 1)
+        return {"fixed_ms_per_call": float(c), "us_per_1000_reads": float(b * 1e6),
+                "note": "least-squares line through (reads per call, ms)"}
+
+    def run(call, cells_per_read=None, bytes_per_read=None):
+        rows = []
+        clk = None
+        for R in sizes:
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                call(R)
+                check(L.sk_sync())
+                ts.append(time.perf_counter() - t0)
+            t = min(ts[1:])
+            row = {"reads_per_call": R, "ms": t * 1e3, "reads_per_s": R / t}
+            if cells_per_read:
+                ghz = C.c_double(0.0)
+                L.sk_last_dtw_clock(C.byref(ghz))
+                clk = ghz.value if 0.5 < ghz.value < 3.0 else clk
+                roof = WAVE_ISSUE_SLOTS / 8.0 * ((clk or 2.4) / 2.4)
+                row["issue_roof_frac"] = R * cells_per_read / t / roof
+            if bytes_per_read:
+                row["hbm_frac"] = R * bytes_per_read / t / 1e9 / HBM_PEAK_GBS
+            rows.append(row)
+        base = rows[0]["reads_per_s"]
+        for r in rows:
+            r["vs_full_batch_rate"] = r["reads_per_s"] / base
+        return rows
+
+    out = {"note": sweep_block.__doc__.split("\n\n")[0].replace("\n    ", " ")}
+    if main.kind == "motifseq":
+        rows = run(lambda R: check(L.sk_motifseq_dev_i16(main.d_sig, main.stride, main.d_len, R, ptr(main.motif), main.N,
+                                                          main.mode, 0, 1200, main.d_out)),
+                   cells_per_read=float(main.N) * main.M)
+        out["motifseq"] = {"by_reads_per_call": rows, "fit": fit(rows)}
+        out["predicted_strong_scaling"] = {
+            "what": "C4 (%d reads in total) over N GPUs from one GPU's rate at %d / N reads per call; gather and ingest not included" % (main.R, main.R),
+            "efficiency": {str(main.R // r["reads_per_call"]): r["vs_full_batch_rate"] for r in rows},
+            "reads_per_s": {str(main.R // r["reads_per_call"]): r["reads_per_s"] * (main.R // r["reads_per_call"]) for r in rows}}
+    return out
+
+
+def sweep_segmenter(L, w):
+    """the segmenter leg of sweep_block, on a resident segmenter workload"""
+    from squigglekit_amd._lib import check
+    sizes = [w.R // d for d in (1, 2, 4, 8, 16, 32) if w.R // d >= 4096]
+    rows = []
+    for R in sizes:
+        ts = []
+        for _ in range(6):
+            t0 = time.perf_counter()
+            check(L.sk_segment_dev_i16(w.d_sig, w.stride, w.d_len, R, C.byref(w.sp), w.d_segs, w.d_out, MAX_SEGS))
+            check(L.sk_sync())
+            ts.append(time.perf_counter() - t0)
+        t = min(ts[2:])
+        rows.append({"reads_per_call": R, "ms": t * 1e3, "reads_per_s": R / t,
+                     "hbm_frac": R * (2 * w.M + 4 + 16) / t / 1e9 / HBM_PEAK_GBS})
+    for r in rows:
+        r["vs_full_batch_rate"] = r["reads_per_s"] / rows[0]["reads_per_s"]
+    x = np.array([r["reads_per_call"] for r in rows], dtype=np.float64)
+    y = np.array([r["ms"] for r in rows], dtype=np.float64)
+    b, c = np.polyfit(x, y, 1)
+    return {"by_reads_per_call": rows, "fit": {"fixed_ms_per_call": float(c), "us_per_1000_reads": float(b * 1e6)}}
 
 
 PA_OFFSET, PA_RANGE, PA_DIGITISATION = 16.0, 1493.94, 8192.0      # channel constants of the pA image (as tests/test_gpu_f64.py)
@@ -1053,6 +1142,7 @@ def extras_single_gpu(a, L, main):
                                 "roofline": segmenter_roofline(w, *seg_kernel_prof(w, prof, 10), step_ms=el / 10 * 1e3),
                                 "cpu_baseline": cpu,
                                 "parity": par}
+            out["secondary"]["sweep"] = sweep_segmenter(L, w)
         finally:
             w.free()
     # ---- what the screening buys: the exact-only schemes on 200 000 of the same reads ------------------------
@@ -1226,16 +1316,45 @@ def rank_body(a, comm, rank, world, shape):
                               "note": "every rank at once: pinned host arrays -> sk_motifseq_batch_i16 (H2D of one "
                                       "sub-batch under the kernels of the previous one) -> host records; one feeder "
                                       "thread / process per GPU, slowest rank's wall clock, best of 2 after a warm-up"}
+    if prof.get("guard") is not None:
+        line["guard"] = dict(prof["guard"], note="run-time check of the screening certificate's premise, last timed step: "
+                             "0 / 0 on a healthy build (sk_last_dtw_guard; DESIGN.md 4.3)")
+    # Everything beyond the contract goes out as lines of its own BEFORE the headline ({"extra": name, ...}); the
+    # headline is printed last and stays a few KB, so that a tail of stdout always holds it whole (round 4's record lost
+    # its `secondary` and `parity` blocks to a line of 14 KB).  --full-json PATH writes headline + extras as one object.
+    extras = {}
     if world == 1 and a.only_other_paths:
-        line["other_paths"] = other_paths_block(a, L, w)
+        extras["other_paths"] = other_paths_block(a, L, w)
     elif world == 1 and not a.no_extras:
-        line.update(extras_single_gpu(a, L, w))
+        extras.update(extras_single_gpu(a, L, w))
+        extras["sweep"] = sweep_block(a, L, w)
         if a.workload == "motifseq" and not a.no_sensitivity:
-            line["other_paths"] = other_paths_block(a, L, w)
-            line["cli"] = cli_block(a, L, w)
-            line["sensitivity"] = sensitivity_block(a, L, w)
+            extras["other_paths"] = other_paths_block(a, L, w)
+            extras["cli"] = cli_block(a, L, w)
+            extras["sensitivity"] = sensitivity_block(a, L, w)
+    elif world == 1 and a.sweep_reads:
+        extras["sweep"] = sweep_block(a, L, w)
+    sec = extras.get("secondary")
+    if sec:
+        rf = sec["roofline"]
+        line["secondary"] = {"metric": sec["metric"], "value": sec["value"], "unit": "reads/s", "ms_per_step": sec["ms_per_step"],
+                             "workload": sec["config"]["workload"],
+                             "roofline": {"bound": "hbm", "whole_step_frac": rf["whole_step"]["frac"],
+                                          "dominant_kernel": rf["kernel"], "dominant_kernel_frac": rf["frac"],
+                                          "kernel_ms": rf["kernel_ms"], "traffic_ratio": rf["traffic_ratio"]},
+                             "cpu_baseline_reads_per_s": (sec["cpu_baseline"] or {}).get("value"),
+                             "parity": sec["parity"],
+                             "predicted_strong_scaling_efficiency": {
+                                 str(w.R // r["reads_per_call"]): round(r["vs_full_batch_rate"], 4)
+                                 for r in sec.get("sweep", {}).get("by_reads_per_call", [])},
+                             "full": "the {\"extra\": \"secondary\"} line above"}
+    sw = extras.get("sweep", {})
+    if sw.get("predicted_strong_scaling"):
+        line["predicted_strong_scaling"] = dict(sw["predicted_strong_scaling"],
+                                                fixed_ms_per_call=sw["motifseq"]["fit"]["fixed_ms_per_call"])
+    line["extras"] = sorted(extras)
     w.free()
-    return line
+    return line, extras
 
 
 def main(argv=None):
@@ -1270,13 +1389,19 @@ def main(argv=None):
         _lib.init(0)
         line = rank_body(a, None, 0, 1, shape)
     if line is not None:
-        # the JSON line is the last thing on stdout: RCCL prints a version banner through C stdio, which would
+        line, extras = line
+        # the headline is the last thing on stdout: RCCL prints a version banner through C stdio, which would
         # otherwise be flushed at exit, after Python's own buffer
         sys.stdout.flush()
         try:
             C.CDLL(None).fflush(None)
         except Exception:
             pass
+        for key in sorted(extras):
+            print(json.dumps({"extra": key, key: extras[key]}), flush=True)
+        if a.full_json:
+            with open(a.full_json, "w") as fh:
+                json.dump(dict(line, **extras), fh)
         print(json.dumps(line), flush=True)
 
 

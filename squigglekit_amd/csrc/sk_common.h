@@ -43,6 +43,8 @@ struct sk_ctx {
     hipStream_t stream2 = nullptr;    // second stream (created on first use): overlapped walks / copies
     hipStream_t stream3 = nullptr;    // third stream (created on first use): the early exact retry beside the window passes
     hipEvent_t  ev_r[2] = {nullptr, nullptr};   // its ordering events: pass Q done / early retry done
+    hipStream_t stream4 = nullptr;    // fourth stream (created on first use): the audit's exact sweep beside the window passes
+    hipEvent_t  ev_a = nullptr;       // audit sweep done
     hipEvent_t  ev_chunk[9] = {};     // ordering events between the two streams (no timing)
     hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};   // prep start/stop, main start/stop
     bool        ev_valid = false;

@@ -207,6 +207,11 @@ int sk_shutdown(void)
             for (int i = 0; i < 2; i++) if (c->ev_r[i]) (void)hipEventDestroy(c->ev_r[i]);
             (void)hipStreamDestroy(c->stream3);
         }
+        if (c->stream4) {
+            (void)hipStreamSynchronize(c->stream4);
+            if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+            (void)hipStreamDestroy(c->stream4);
+        }
         (void)hipStreamDestroy(c->stream);
         *c = sk_ctx();
     }

@@ -858,14 +858,17 @@ __device__ __forceinline__ int order_key(const order_args &a, int i)
 {
     const wrec q = a.rec[i];
     const unsigned b = (unsigned)a.qflag[i];
-    if (!((b < QSAFE) && (q.jhi >= q.jlo) && (q.jhi - q.jlo <= a.wmax))) return 0;   // not screened: no work in P / W
+    // Longest first (round 5): the sorted list used to end with the reads that need the most window blocks, so the last
+    // wavefronts to start were the longest-running ones; in descending order the short ones fill the tail of the launch
+    // (window passes 2.03 -> 1.78 ms at 125 000 reads per call, 12.1 -> 11.9 at 1 M).
+    if (!((b < QSAFE) && (q.jhi >= q.jlo) && (q.jhi - q.jlo <= a.wmax))) return ORDER_BINS - 1;   // not screened: no work in P / W, last
     const int tx = max(0, q.jlo - a.span);             // (pass P's arithmetic)
     int c0 = tx / a.ck;
     if (c0 > a.nck) c0 = a.nck;
     const int npre = c0 > 0 ? (tx - c0 * a.ck) / a.L : 0;
     const int tbase = c0 * a.ck + npre * a.L;
     const int nblk = (q.jhi + a.L - tbase + a.L - 1) / a.L;
-    return min(max(nblk, 1), 63) * 16 + min(npre, 15);
+    return ORDER_BINS - 1 - (min(max(nblk, 1), 63) * 16 + min(npre, 15));
 }
 
 // (1 024 threads x 4 reads per workgroup: the global reservations -- a few dozen hot bins -- serialise in the L2, so

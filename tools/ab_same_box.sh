@@ -5,7 +5,7 @@ R=$(pwd); OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 for rep in 1 2; do
   for v in base new; do
     if [ $v = base ]; then export SK_LIB_PATH=$R/squigglekit_amd/libsk_alt_base.so; else unset SK_LIB_PATH; fi
-    python bench.py --steps 5 --warmup 1 --no-extras --cpu-seconds 0 "$@" > $OUT/ab_${v}_$rep.json 2> $OUT/ab_${v}_$rep.err
+    python bench.py --steps 5 --warmup 1 --no-extras --cpu-seconds 0 "$@" --full-json $OUT/ab_${v}_$rep.json > $OUT/ab_${v}_$rep.lines 2> $OUT/ab_${v}_$rep.err
   done
 done
 unset SK_LIB_PATH

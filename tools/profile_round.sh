@@ -7,19 +7,19 @@
 # microbenchmark the DTW roof rests on, the command-line tools end to end, and the multi-rank dry run.
 export SK_TUNING=1        # the library reads its tuning switches only with this set
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 "$R/tools/ubench/valu_rate" > "$OUT/valu_rate.txt" 2>&1
 "$R/tools/ubench/hbm_stream" 8 > "$OUT/hbm_stream.txt" 2>&1
-python "$R/bench.py" > "$OUT/bench_motifseq.json" 2> "$OUT/bench_motifseq.err"
-python "$R/bench.py" --workload segmenter --no-extras --steps 20 --warmup 3 > "$OUT/bench_segmenter.json" 2> "$OUT/bench_segmenter.err"   # (a pass is 2.4 ms: the first two after the buffers are allocated run 5-10 % slower)
-python "$R/bench.py" --reads 10000 --motif 163 --no-extras --steps 20 --warmup 3 > "$OUT/bench_c3_10k_x_163pt.json" 2>/dev/null
-python "$R/bench.py" --reads 100000 --samples 20000 --motif 500 --no-extras --cpu-seconds 6 > "$OUT/bench_c5_100k_x_20000_x_500pt.json" 2>/dev/null
-python "$R/bench.py" --workload segmenter --reads 10000 --no-extras --steps 20 --warmup 3 > "$OUT/bench_c2_10k_segmenter.json" 2>/dev/null
-python "$R/bench.py" --gpus 2 --ranks-on-device 0 --reads 200000 --steps 3 --warmup 1 --cpu-seconds 2 > "$OUT/bench_2ranks_on_one_gpu.json" 2>/dev/null
+python "$R/bench.py" --full-json "$OUT/bench_motifseq.json" > "$OUT/bench_motifseq.lines" 2> "$OUT/bench_motifseq.err"
+python "$R/bench.py" --workload segmenter --no-extras --steps 20 --warmup 3 --full-json "$OUT/bench_segmenter.json" > "$OUT/bench_segmenter.lines" 2> "$OUT/bench_segmenter.err"   # (a pass is 2.4 ms: the first two after the buffers are allocated run 5-10 % slower)
+python "$R/bench.py" --reads 10000 --motif 163 --no-extras --steps 20 --warmup 3 --full-json "$OUT/bench_c3_10k_x_163pt.json" > "$OUT/bench_c3_10k_x_163pt.lines" 2>/dev/null
+python "$R/bench.py" --reads 100000 --samples 20000 --motif 500 --no-extras --cpu-seconds 6 --full-json "$OUT/bench_c5_100k_x_20000_x_500pt.json" > "$OUT/bench_c5_100k_x_20000_x_500pt.lines" 2>/dev/null
+python "$R/bench.py" --workload segmenter --reads 10000 --no-extras --steps 20 --warmup 3 --full-json "$OUT/bench_c2_10k_segmenter.json" > "$OUT/bench_c2_10k_segmenter.lines" 2>/dev/null
+python "$R/bench.py" --gpus 2 --ranks-on-device 0 --reads 200000 --steps 3 --warmup 1 --cpu-seconds 2 --full-json "$OUT/bench_2ranks_on_one_gpu.json" > "$OUT/bench_2ranks_on_one_gpu.lines" 2>/dev/null
 SQ1="SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
 SQ2="SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"
 for WL in motifseq segmenter; do
@@ -48,7 +48,7 @@ for WL in motifseq segmenter; do
 done
 # the paths the headline does not take (bench.py other_paths: float64 pA segmenter, 4 000- and 20 000-sample reads, float64
 # medmad, int16 zscale, four motifs): the bench block, a kernel-trace summary and the FETCH / WRITE passes of the same command
-python "$R/bench.py" --only-other-paths --steps 3 --cpu-seconds 0 > "$OUT/bench_other_paths.json" 2> "$OUT/bench_other_paths.err"
+python "$R/bench.py" --only-other-paths --steps 3 --cpu-seconds 0 --full-json "$OUT/bench_other_paths.json" > "$OUT/bench_other_paths.lines" 2> "$OUT/bench_other_paths.err"
 rocprofv3 --kernel-trace --stats -d "$OUT/kt_other" -- python "$R/bench.py" --only-other-paths --steps 1 --warmup 0 \
     --cpu-seconds 0 > "$OUT/kt_other.log" 2>&1
 DB=$(find "$OUT/kt_other" -name '*_results.db' | head -1)
