@@ -767,44 +767,82 @@ def other_paths_block(a, L, main):
             "parity": {"reads_checked": int(len(rows)), "segments_bit_exact": bool(ok),
                        "segments_in_sample": int(nsegs[rows].sum())}}
 
-        # ---------------- the same on long reads (C5-shaped: 20 000 samples): the window-by-window float64 kernel -------
-        RL, ML = 50_000, 20_000
-        d_raw_l = alloc(RL * ML * 2)
-        check(L.sk_synth_squiggles_dev(d_raw_l, ML, RL, ML, synth.SEED_C5, None, 0))
-        MLf = ML - 1
-        d_pa_l, d_off_l = alloc(RL * MLf * 8), alloc((RL + 1) * 8)
-        check(L.sk_synth_pa_dev(d_raw_l, ML, RL, MLf, PA_OFFSET, PA_RANGE, PA_DIGITISATION, d_pa_l, d_off_l))
-        MAXS_L = 64
-        d_segs_l, d_nsegs_l = alloc(RL * MAXS_L * 2 * 4), alloc(RL * 4)
-        secs, ev = best_of(lambda: check(L.sk_segment_dev_f64(d_pa_l, d_off_l, RL, RL * MLf, MLf, C.byref(sp), d_segs_l,
-                                                              d_nsegs_l, MAXS_L)))
-        retried_l = int(L.sk_last_f64_retries())
-        rows_l = strided_rows(RL, 128)
-        pa_l = download_rows(L, d_pa_l, MLf * 8, rows_l, np.float64, MLf)
-        segs_l = np.empty((RL, MAXS_L, 2), dtype=np.int32)
-        nsegs_l = np.empty(RL, dtype=np.int32)
-        check(L.sk_dev_download(ptr(segs_l), d_segs_l, segs_l.nbytes))
-        check(L.sk_dev_download(ptr(nsegs_l), d_nsegs_l, nsegs_l.nbytes))
+        # ---------------- the same at real read lengths: 20 000 samples (C5-shaped) and 36 977 (the one measured read the
+        # reference ships, example/slow5/0.blow5) -- segmenter AND MotifSeq: `MotifSeq.py --signal` parses every sample as a
+        # float (MotifSeq.py:270), so this, not the int16 headline, is what the reference's default input looks like
+        import gzip
+        with gzip.open(os.path.join(ROOT, "tests", "golden", "motifseq_cli.json.gz"), "rt") as fh:
+            model163 = np.array(json.load(fh)["model_expanded"]["values"], dtype=np.float64)
+        for RL, ML, tag in ((50_000, 20_000, "20k"), (25_000, 36_978, "37k")):
+            MLs = (ML + 7) // 8 * 8
+            d_raw_l = alloc(RL * MLs * 2)
+            check(L.sk_synth_squiggles_dev(d_raw_l, MLs, RL, ML, synth.SEED_C5, None, 0))
+            MLf = ML - 1
+            d_pa_l, d_off_l = alloc(RL * MLf * 8), alloc((RL + 1) * 8)
+            check(L.sk_synth_pa_dev(d_raw_l, MLs, RL, MLf, PA_OFFSET, PA_RANGE, PA_DIGITISATION, d_pa_l, d_off_l))
+            MAXS_L = 128
+            d_segs_l, d_nsegs_l = alloc(RL * MAXS_L * 2 * 4), alloc(RL * 4)
+            secs, ev = best_of(lambda: check(L.sk_segment_dev_f64(d_pa_l, d_off_l, RL, RL * MLf, MLf, C.byref(sp), d_segs_l,
+                                                                  d_nsegs_l, MAXS_L)))
+            retried_l = int(L.sk_last_f64_retries())
+            rows_l = strided_rows(RL, 128)
+            pa_l = download_rows(L, d_pa_l, MLf * 8, rows_l, np.float64, MLf)
+            segs_l = np.empty((RL, MAXS_L, 2), dtype=np.int32)
+            nsegs_l = np.empty(RL, dtype=np.int32)
+            check(L.sk_dev_download(ptr(segs_l), d_segs_l, segs_l.nbytes))
+            check(L.sk_dev_download(ptr(nsegs_l), d_nsegs_l, nsegs_l.nbytes))
 
-        def seg_ok_l(k):
-            want = ora.get_segs(ora.scale_outliers(pa_l[k], sp.lim_low, sp.lim_hi), op) or []
-            r = rows_l[k]
-            return nsegs_l[r] == len(want) and segs_l[r, :nsegs_l[r]].tolist() == want
-        with ThreadPoolExecutor(T) as ex:
-            ok_l = all(ex.map(seg_ok_l, range(len(rows_l))))
-        alg = RL * (8 * MLf + 4 + 16)
-        out["segmenter_f64_pA_20k"] = {
-            "workload": "%d reads x %d float64 pA samples (2 decimals), default flags" % (RL, MLf),
-            "value": RL / secs, "unit": "reads/s", "ms_per_step": secs * 1e3,
-            "kernel_ms": {"statistics": ev[0], "walk": ev[1]}, "reads_redone_in_numpy_order": retried_l,
-            "roofline": {"bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
-                         "note": "window-by-window kernel (k_f64_long): the read is looked at four times"},
-            "parity": {"reads_checked": int(len(rows_l)), "segments_bit_exact": bool(ok_l),
-                       "segments_in_sample": int(nsegs_l[rows_l].sum())}}
-        for q in (d_raw_l, d_pa_l, d_off_l, d_segs_l, d_nsegs_l):
-            L.sk_dev_free(q)
-            bufs.remove(q)
+            def seg_ok_l(k):
+                want = ora.get_segs(ora.scale_outliers(pa_l[k], sp.lim_low, sp.lim_hi), op) or []
+                r = rows_l[k]
+                return nsegs_l[r] == len(want) and segs_l[r, :nsegs_l[r]].tolist() == want
+            with ThreadPoolExecutor(T) as ex:
+                ok_l = all(ex.map(seg_ok_l, range(len(rows_l))))
+            alg = RL * (8 * MLf + 4 + 16)
+            out["segmenter_f64_pA_%s" % tag] = {
+                "workload": "%d reads x %d float64 pA samples (2 decimals), default flags" % (RL, MLf),
+                "value": RL / secs, "unit": "reads/s", "ms_per_step": secs * 1e3,
+                "kernel_ms": {"statistics": ev[0], "walk": ev[1]}, "reads_redone_in_numpy_order": retried_l,
+                "roofline": {"bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
+                             "statistics_kernel_frac": (alg / (ev[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ev[0] > 0 else None},
+                "parity": {"reads_checked": int(len(rows_l)), "segments_bit_exact": bool(ok_l),
+                           "segments_in_sample": int(nsegs_l[rows_l].sum())}}
+            # MotifSeq, float64 medmad, against the example model (163 points)
+            d_hits_l = alloc(RL * HIT_BYTES)
+            secs, ev = best_of(lambda: check(L.sk_motifseq_dev_f64(d_pa_l, d_off_l, RL, RL * MLf, MLf, ptr(model163),
+                                                                   model163.size, 0, 0, 1200, d_hits_l)))
+            g = (C.c_int32 * 8)()
+            check(L.sk_last_dtw_guard(g))
+            hits_l = np.empty(RL, dtype=HIT_DTYPE)
+            check(L.sk_dev_download(ptr(hits_l), d_hits_l, hits_l.nbytes))
+            rows_m = rows_l[::4]
+            pa_m = pa_l[::4]
+
+            def want_long(k):
+                y = ora.medmad(ora.scale_outliers(pa_m[k], 0, 1200))[0]
+                return ora.dtw_subsequence(model163, y)
+            with ThreadPoolExecutor(T) as ex:
+                want_m = list(ex.map(want_long, range(len(rows_m))))
+            got_m = hits_l[rows_m]
+            alg = RL * (8 * MLf + HIT_BYTES)
+            cells = float(model163.size) * float(np.mean(hits_l["n"]))
+            out["motifseq_f64_medmad_%s" % tag] = {
+                "workload": "%d reads x %d float64 pA samples vs the example model (%d points), medmad" % (RL, MLf, model163.size),
+                "value": RL / secs, "unit": "reads/s", "ms_per_step": secs * 1e3,
+                "kernel_ms": {"prep": ev[0], "dtw": ev[1]},
+                "guard": {"premise_violations": int(g[0]), "audited_reads": int(g[1]), "audit_mismatches": int(g[2])},
+                "roofline": {"bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
+                             "prep_kernel_frac": (alg / (ev[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ev[0] > 0 else None,
+                             "valu": dtw_view(RL, cells, secs)},
+                "parity": {"reads_checked": int(len(rows_m)),
+                           "dist_bit_identical": bool(all(got_m["dist"][k] == w[0] for k, w in enumerate(want_m))),
+                           "start_end_exact": bool(all((got_m["start"][k], got_m["end"][k]) == (w[1], w[2])
+                                                       for k, w in enumerate(want_m)))}}
+            for q in (d_raw_l, d_pa_l, d_off_l, d_segs_l, d_nsegs_l, d_hits_l):
+                L.sk_dev_free(q)
+                bufs.remove(q)
 
         # ---------------- dRNA_segmenter.py, both branches (host arrays in: these entry points have no device-resident form) --
         from squigglekit_amd import api

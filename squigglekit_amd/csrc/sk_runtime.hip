@@ -93,6 +93,7 @@ static const sk_tunable SK_TUNABLES[] = {
     {"SK_DRNA_STEP",          "1",           "dRNA_segmenter, both branches: the per-sample scans instead of the scans by runs / by transitions"},
     {"SK_INGEST_MB",          "1 4",         "sub-batch size of the host entry points in MB"},
     {"SK_F64_OLD",            "1",           "float64 reads: numpy-order statistics kernel for every read"},
+    {"SK_F64_LONG_LOOKS",     "1",           "float64 reads of 4 097 .. 40 960 samples: the window-by-window kernel (three to five looks at a read) instead of the workgroup-per-read one (one look)"},
 };
 
 const char *sk_tune(const char *name)

@@ -303,6 +303,86 @@ def test_f64_long_reads_medmad_vs_oracle(gpu, ora, example_model):
             assert (got["dist"][r], got["start"][r], got["end"][r], got["n"][r]) == w, r
 
 
+def _class_reads(rng, cap):
+    """A batch whose longest read is exactly `cap` samples (the batch's longest read picks the kernel: 10 240 / 20 480 /
+    41 472 = the workgroup-per-read kernel with 4 / 8 / 12 wavefronts, round 5): the kinds of _long_reads at lengths
+    around the wavefronts' 64 x GNJ-sample shares, plus reads far shorter than the cap -- wavefronts with nothing to do."""
+    per = cap // {10240: 4, 20480: 8, 41472: 12}[cap]
+    reads = []
+    for n in (cap, cap - 1, cap - 63, cap - 64, cap - 65, per, per + 1, per - 1, 2 * per + 7, 4097, 64, 3, 1, 0):
+        reads.append(np.round(rng.normal(96.0, 15.0, n), 2))
+    for n in (cap, cap // 2 + 13, 5000):
+        reads.append(rng.normal(96.0, 15.0, n))                                  # ungridded: hundreds of distinct values in a bin
+        reads.append(rng.choice([80.25, 95.5, 95.51], n))                        # more than 512 equal-bin members
+        x = np.round(rng.normal(90.0, 6.0, n), 2)
+        x[rng.integers(0, n, 3)] = [899.99, np.nan, 0.011]                       # an outlier-stretched range, NaN inside
+        reads.append(x)
+        reads.append(90.0 + rng.integers(0, 100000, n) * 2.0 ** -30)             # dense: the select recurses on the members' range
+    reads.append(np.full(cap - 5, 77.77))
+    x = np.round(rng.normal(96.0, 15.0, cap), 2)
+    x[per - 10:per + 700] = 2000.0                                               # a whole stretch dropped across two wavefronts
+    reads.append(x)
+    return reads
+
+
+@pytest.mark.parametrize("cap", [10240, 20480, 41472])
+def test_f64_workgroup_kernel_segmenter_vs_oracle(gpu, ora, monkeypatch, cap):
+    """k_f64_wg (one look, a workgroup per read) for every wavefront count, against the oracle and against the
+    window-by-window kernel it replaces (SK_F64_LONG_LOOKS=1), with and without the forced numpy-order redo."""
+    from squigglekit_amd import api
+    from squigglekit_amd._lib import SegParams
+    reads = _class_reads(np.random.default_rng(cap), cap)
+    for kw in (dict(), dict(lim_low=60, lim_hi=130, window=40)):
+        p = SegParams(**kw)
+        op = ora.SegParams(p.error, p.corrector, p.window, p.seg_dist, p.std_scale, p.stall_len)
+        want = [ora.get_segs(f, op) if f.size else False
+                for f in (ora.scale_outliers(sig, p.lim_low, p.lim_hi) for sig in reads)]
+        for delta in (None, "1e13"):
+            if delta:
+                monkeypatch.setenv("SK_SEG_DELTA_SCALE", delta)
+            got = api.segment_reads_f64(reads, p)
+            retried = gpu.load().sk_last_f64_retries()
+            monkeypatch.setenv("SK_F64_LONG_LOOKS", "1")
+            old = api.segment_reads_f64(reads, p)
+            monkeypatch.delenv("SK_F64_LONG_LOOKS")
+            monkeypatch.delenv("SK_SEG_DELTA_SCALE", raising=False)
+            assert retried >= 0
+            if not delta:
+                assert retried <= 6, retried             # (the all-equal read, the tiny ones; nothing else should need the redo)
+            bad = [r for r in range(len(reads)) if got[r] != want[r]]
+            assert not bad, (cap, kw, delta, bad[:8], retried)
+            assert got == old
+
+
+def test_f64_workgroup_kernel_medmad_vs_oracle(gpu, ora, example_model, monkeypatch):
+    """medmad takes the workgroup kernel for batches whose longest read has 20 481 .. 41 472 samples."""
+    from concurrent.futures import ThreadPoolExecutor
+    from squigglekit_amd import api
+    reads = _class_reads(np.random.default_rng(77), 41472)
+    got = api.motifseq_reads_f64(reads, example_model, scale="medmad", scale_low=0, scale_hi=900)
+    assert 0 <= gpu.load().sk_last_f64_retries() <= 4
+    monkeypatch.setenv("SK_F64_LONG_LOOKS", "1")
+    old = api.motifseq_reads_f64(reads, example_model, scale="medmad", scale_low=0, scale_hi=900)
+    monkeypatch.delenv("SK_F64_LONG_LOOKS")
+    assert got.tobytes() == old.tobytes()
+
+    def one(sig):
+        f = ora.scale_outliers(sig, 0, 900)
+        if f.size == 0:
+            return None
+        y = ora.medmad(f)[0]
+        return (ora.dtw_subsequence(example_model, y) + (f.size,)) if np.all(np.isfinite(y)) else (f.size,)
+    with ThreadPoolExecutor(16) as ex:
+        want = list(ex.map(one, reads))
+    for r, w in enumerate(want):
+        if w is None:
+            assert got["n"][r] == 0 and got["flags"][r] & 1, r
+        elif len(w) == 1:
+            assert got["n"][r] == w[0] and got["flags"][r] & 2, r
+        else:
+            assert (got["dist"][r], got["start"][r], got["end"][r], got["n"][r]) == w, r
+
+
 @pytest.mark.parametrize("scale", ["medmad", "zscale"])
 def test_f64_screening_of_near_constant_reads(gpu, ora, example_model, scale):
     """Reads whose spread is 1e-14 of their level, enough of them for the screening scheme: the fixed-point image of a

@@ -110,9 +110,15 @@ def main():
                 x = np.round(rng.normal(96.0, 9.0, n), 2)
                 x[rng.integers(0, n)] = rng.choice([899.99, 0.01, np.nan, np.inf, -np.inf, 1199.0])
             freads.append(x)
-        if rng.random() < 0.1:
-            freads.append(np.round(rng.normal(96.0, 15.0, int(rng.integers(4097, 9000))), 2))   # -> the old kernel for the batch
+        if rng.random() < 0.25:
+            # a longer read decides the batch's kernel: the workgroup-per-read one (4 / 8 / 12 wavefronts by length, round 5),
+            # the window-by-window one under SK_F64_LONG_LOOKS or beyond 41 472 samples
+            top = int(rng.choice([9000, 10240, 12000, 20480, 30000, 41472, 45000]))
+            freads.append(np.round(rng.normal(96.0, 15.0, int(rng.integers(4097, top + 1))), 2))
+            if rng.random() < 0.5:
+                freads.append(rng.normal(96.0, 15.0, int(rng.integers(4097, top + 1))))
         for key, val in (("SK_F64_OLD", "1" if rng.random() < 0.15 else None),
+                         ("SK_F64_LONG_LOOKS", "1" if rng.random() < 0.2 else None),
                          ("SK_SEG_DELTA_SCALE", "1e13" if rng.random() < 0.2 else None)):
             if val is None:
                 os.environ.pop(key, None)
@@ -148,6 +154,7 @@ def main():
                 bad += 1
                 print("F64 SEGMENTER mismatch kind %d n=%d %s" % (kinds, len(x), fkw))
         os.environ.pop("SK_F64_OLD", None)
+        os.environ.pop("SK_F64_LONG_LOOKS", None)
         os.environ.pop("SK_SEG_DELTA_SCALE", None)
         # ---- dRNA_segmenter: both branches on a few long ragged reads ----
         if rounds % 2 == 0:
