@@ -732,7 +732,7 @@ def other_paths_block(a, L, main):
 
     try:
         # ---------------- float64 pA reads: segmenter and MotifSeq --------------------------------------------
-        Rf = min(main.R, 250_000)
+        Rf = min(main.R, 500_000)                                    # (16 GB: enough wavefronts for the lane-per-read walk to fill the chip)
         Mf = M - 1                                                    # segmenter.py:207 with the default -n: sig[:-1]
         total = Rf * Mf
         d_pa, d_off = alloc(total * 8), alloc((Rf + 1) * 8)
@@ -844,42 +844,41 @@ def other_paths_block(a, L, main):
                 L.sk_dev_free(q)
                 bufs.remove(q)
 
-        # ---------------- dRNA_segmenter.py, both branches (host arrays in: these entry points have no device-resident form) --
+        # ---------------- dRNA_segmenter.py, both branches, device resident at a size that fills the chip ----------------
+        # (round 4 timed 20 000 reads = 313 wavefronts on 1 024 SIMDs: one wavefront's latency.  250 000 reads, 15 GB.)
         from squigglekit_amd import api
         from squigglekit_amd._lib import DrnaParams, RollParams
         # dRNA-shaped reads (synth.drna_reads: adapter stretch, poly(A) plateau, body; 6 000 .. 30 000 samples): 1 000
         # distinct ones, tiled -- the scans stop where the script stops ("adapter found"), which generic squiggles never reach
         base_reads = synth.drna_reads(1000, synth.SEED_C5 + 7, min_len=6000, max_len=30000)
-        RD, MD = 20_000, 30_000
-        host_d = api.pinned_empty((RD, MD), np.int16)
-        lens_d = np.zeros(RD, dtype=np.int32)
-        for r in range(RD):
-            x = base_reads[r % len(base_reads)]
-            host_d[r, :x.size] = x
-            lens_d[r] = x.size
+        RD, MD = 250_000, 30_000
+        NB_ = len(base_reads)
+        host_b = api.pinned_empty((NB_, MD), np.int16)
+        host_b[:] = 0
+        lens_b = np.zeros(NB_, dtype=np.int32)
+        for r, x in enumerate(base_reads):
+            host_b[r, :x.size] = x
+            lens_b[r] = x.size
+        d_sig_d, d_len_d = alloc(RD * MD * 2), alloc(RD * 4)
+        lens_d = np.tile(lens_b, RD // NB_)
+        check(L.sk_dev_upload(d_len_d, ptr(lens_d), lens_d.nbytes))
+        base_p = C.cast(d_sig_d, C.c_void_p).value
+        for k in range(RD // NB_):                                    # the 1 000 distinct reads, 250 times
+            check(L.sk_dev_upload(C.c_void_p(base_p + k * NB_ * MD * 2), ptr(host_b), host_b.nbytes))
         dp, rp = DrnaParams(), RollParams()
+        d_dsegs, d_dn = alloc(RD * 32 * 2 * 4), alloc(RD * 4)
+        d_xy, d_found = alloc(RD * 2 * 4), alloc(RD * 4)
+        secs, ev = best_of(lambda: check(L.sk_drna_segment_dev_i16(d_sig_d, MD, d_len_d, RD, C.byref(dp), d_dsegs, d_dn, 32)))
         dsegs = np.zeros((RD, 32, 2), dtype=np.int32)
         dn = np.zeros(RD, dtype=np.int32)
-        xy = np.zeros((RD, 2), dtype=np.int32)
-        found = np.zeros(RD, dtype=np.int32)
-
-        def host_best(fn, n=3):
-            fn()
-            ts, ev = [], None
-            for _ in range(n):
-                t0 = time.perf_counter()
-                fn()
-                ts.append(time.perf_counter() - t0)
-                if ts[-1] == min(ts):
-                    ev = main.kernel_ms()
-            return min(ts), ev
-        secs, ev = host_best(lambda: check(L.sk_drna_segment_batch_i16(ptr(host_d), MD, ptr(lens_d), RD, C.byref(dp), ptr(dsegs),
-                                                                        ptr(dn), 32)))
-        rows_d = strided_rows(RD, 64)
+        check(L.sk_dev_download(ptr(dsegs), d_dsegs, dsegs.nbytes))
+        check(L.sk_dev_download(ptr(dn), d_dn, dn.nbytes))
+        rows_d = strided_rows(RD, 96)
         odp = ora.DrnaParams()
 
         def drna_ok(r):
-            want = ora.drna_segs(ora.scale_outliers(host_d[r, :lens_d[r]].astype(float), dp.lim_low, dp.lim_hi), odp)[0]
+            b = r % NB_
+            want = ora.drna_segs(ora.scale_outliers(host_b[b, :lens_b[b]].astype(float), dp.lim_low, dp.lim_hi), odp)[0]
             return dsegs[r, :dn[r]].tolist() == want
         with ThreadPoolExecutor(T) as ex:
             ok1 = all(ex.map(drna_ok, rows_d))
@@ -887,33 +886,41 @@ def other_paths_block(a, L, main):
         alg = int(2 * lens_d.astype(np.int64).sum() + RD * 12)
         out["drna_slow5_branch"] = {
             "workload": "%d dRNA-shaped reads of 6 000 .. 30 000 int16 samples (mean %d), dRNA_segmenter.py:85-176 constants; "
-                        "pinned host arrays in" % (RD, int(lens_d.mean())),
-            "value": RD / secs, "unit": "reads/s", "ms_per_step": secs * 1e3, "kernels_only_reads_per_s": RD / (kms * 1e-3),
+                        "device resident" % (RD, int(lens_d.mean())),
+            "value": RD / secs, "unit": "reads/s", "ms_per_step": secs * 1e3,
             "kernel_ms": {"statistics": ev[0], "scan": ev[1]},
-            "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
-                         "note": "kernels only (HIP events); the call itself is bound by the host-to-device copy"},
+            "roofline": {"bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "kernels_only_frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_step": alg},
             "parity": {"reads_checked": int(len(rows_d)), "segments_bit_exact": bool(ok1)}}
-        secs, ev = host_best(lambda: check(L.sk_drna_roll_batch_i16(ptr(host_d), MD, ptr(lens_d), RD, C.byref(rp), ptr(xy), ptr(found))))
+        secs, ev = best_of(lambda: check(L.sk_drna_roll_dev_i16(d_sig_d, MD, d_len_d, RD, C.byref(rp), d_xy, d_found)))
+        xy = np.zeros((RD, 2), dtype=np.int32)
+        found = np.zeros(RD, dtype=np.int32)
+        check(L.sk_dev_download(ptr(xy), d_xy, xy.nbytes))
+        check(L.sk_dev_download(ptr(found), d_found, found.nbytes))
         orp = ora.RollParams()
 
         def roll_ok(r):
-            want = ora.drna_roll(ora.scale_outliers(host_d[r, :lens_d[r]].astype(float), rp.lim_low, rp.lim_hi), orp)
+            b = r % NB_
+            want = ora.drna_roll(ora.scale_outliers(host_b[b, :lens_b[b]].astype(float), rp.lim_low, rp.lim_hi), orp)
             got = (int(xy[r, 0]), int(xy[r, 1])) if found[r] else None
             return got == want
         with ThreadPoolExecutor(T) as ex:
             ok2 = all(ex.map(roll_ok, rows_d))
         kms = ev[0] + ev[1]
         out["drna_rolling_mean_branch"] = {
-            "workload": "%d dRNA-shaped reads (mean %d samples), dRNA_segmenter.py:272-326, w = 2000; pinned host arrays in"
+            "workload": "%d dRNA-shaped reads (mean %d samples), dRNA_segmenter.py:272-326, w = 2000; device resident"
                         % (RD, int(lens_d.mean())),
-            "value": RD / secs, "unit": "reads/s", "ms_per_step": secs * 1e3, "kernels_only_reads_per_s": RD / (kms * 1e-3),
+            "value": RD / secs, "unit": "reads/s", "ms_per_step": secs * 1e3,
             "kernel_ms": {"filter_prefix_sums_statistics": ev[0], "scan": ev[1]},
-            "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
-                         "note": "kernels only (HIP events); the kernel keeps an int64 prefix sum per sample in HBM"},
+            "roofline": {"bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "kernels_only_frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_step": alg},
             "parity": {"reads_checked": int(len(rows_d)), "pairs_exact": bool(ok2), "found_in_sample": int(found[rows_d].sum())}}
-        del host_d
+        del host_b
+        for q in (d_sig_d, d_len_d, d_dsegs, d_dn, d_xy, d_found):
+            L.sk_dev_free(q)
+            bufs.remove(q)
 
         d_hits = alloc(max(Rf, main.R) * HIT_BYTES * 4)
 

@@ -178,6 +178,13 @@ typedef struct sk_roll_params {
 /* xy[2r], xy[2r+1] = the reported pair of read r when found[r] != 0. */
 int sk_drna_roll_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
                            const sk_roll_params *p, int32_t *xy, int32_t *found);
+/* Device-resident forms of the two dRNA_segmenter.py branches (same kernels; d_sig, d_len and the outputs are device
+ * pointers, every len[r] is clamped into [0, stride] by the kernels; nothing is synchronised -- sk_sync()).  What
+ * bench.py times at 250 000 reads per call.  Reference: dRNA_segmenter.py:85-176 (slow5 branch), :272-326 (--signal). */
+int sk_drna_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                            const sk_drna_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs);
+int sk_drna_roll_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                         const sk_roll_params *p, int32_t *d_xy, int32_t *d_found);
 
 /* ---- MotifSeq path ---------------------------------------------------- */
 /* Replaces, per read r: scale_outliers (MotifSeq.py:274,317-324), medmad

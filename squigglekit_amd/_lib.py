@@ -116,6 +116,8 @@ ABI = {
     "sk_segment_dev_f64": (C.c_int, [_vp, _vp, C.c_int32, C.c_int64, C.c_int64, C.POINTER(SegParams), _vp, _vp, C.c_int32]),
     "sk_drna_segment_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32]),
     "sk_drna_roll_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, _vp]),
+    "sk_drna_segment_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32]),
+    "sk_drna_roll_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, _vp]),
     "sk_motifseq_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, _vp]),
     "sk_motifseq_multi_batch_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,

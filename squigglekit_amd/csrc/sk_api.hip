@@ -905,6 +905,105 @@ int sk_segment_dev_f64(const double *d_sig, const int64_t *d_off, int32_t nreads
 
 // ------------------------------------------------------------------ dRNA adapter segmenter
 // ------------------------------------------------------------------ dRNA --signal branch (rolling mean)
+// device-resident cores of the two dRNA branches (d_sig / d_len / outputs are device pointers)
+static int drna_roll_dev(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                         const sk_roll_params *p, int32_t *d_xy, int32_t *d_found)
+{
+    int rc;
+    int32_t lo = p->lim_low, hi = p->lim_hi;
+    clamp_limits(&lo, &hi);
+    const int64_t words = (stride + 63) / 64;
+    const size_t sb = (size_t)nreads * (size_t)stride * sizeof(int16_t);
+    if ((rc = sk_reserve(c, &c->comp, sb))) return rc;
+    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
+    if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * 2 * sizeof(uint64_t)))) return rc;
+    // prefix sums of the filtered samples: 4 bytes each when every window sum fits 31 bits (sk_launch_roll_stats)
+    const size_t pbytes = (p->w < 65536 && sk_tune("SK_DRNA_STEP") == nullptr) ? sizeof(uint32_t) : sizeof(int64_t);
+    if ((rc = sk_reserve(c, &c->misc, (size_t)nreads * (size_t)(stride + 1) * pbytes))) return rc;
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    // filter + order-preserving compaction (the medmad kernel: its statistics are not used here)
+    rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nreads, lo, hi,
+                            SK_PREP_MEDMAD, 0.0, (int16_t *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
+    if (rc) return rc;
+    uint64_t *below = (uint64_t *)c->mask.p, *above = below + (size_t)nreads * (size_t)words;
+    rc = sk_launch_roll_stats(c, (const int16_t *)c->comp.p, stride, (sk_prep *)c->prep.p, nreads, p->w,
+                              p->std_scale, (int64_t *)c->misc.p, below, above);
+    if (rc) return rc;
+    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+    rc = sk_launch_roll_walk(c, below, above, (const sk_prep *)c->prep.p, nreads, p, d_xy, d_found);
+    if (rc) return rc;
+    c->ev_valid = true;
+    return SK_OK;
+}
+
+static int drna_segment_dev(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                            const sk_drna_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs)
+{
+    int rc;
+    int32_t lo = p->lim_low, hi = p->lim_hi;
+    clamp_limits(&lo, &hi);
+    const int64_t words = (stride + 63) / 64;
+    const size_t sb = (size_t)nreads * (size_t)stride * sizeof(int16_t);
+    const size_t gb = (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t);
+    if ((rc = sk_reserve(c, &c->comp, sb))) return rc;
+    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
+    if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * sizeof(uint64_t)))) return rc;
+    SK_HIP(hipMemsetAsync(d_segs, 0, gb, c->stream));
+    SK_HIP(hipEventRecord(c->ev[0], c->stream));
+    rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nreads, lo, hi,
+                            SK_PREP_DRNA, p->std_scale, (int16_t *)c->comp.p, (sk_prep *)c->prep.p,
+                            (uint64_t *)c->mask.p, nreads, p->t_start, p->t_end);
+    if (rc) return rc;
+    SK_HIP(hipEventRecord(c->ev[1], c->stream));
+    rc = sk_launch_drna_walk(c, (const uint64_t *)c->mask.p, nreads, (const sk_prep *)c->prep.p, nreads, p,
+                             d_segs, d_nsegs, max_segs);
+    if (rc) return rc;
+    c->ev_valid = true;
+    return SK_OK;
+}
+
+static int check_roll(const sk_roll_params *p)
+{
+    if (!p) return sk_fail(SK_ERR_INVALID, "NULL sk_roll_params");
+    if (p->w <= 0) return sk_fail(SK_ERR_INVALID, "the rolling window w must be positive");
+    return SK_OK;
+}
+
+static int check_drna(const sk_drna_params *p, int32_t max_segs)
+{
+    if (!p) return sk_fail(SK_ERR_INVALID, "NULL sk_drna_params");
+    if (p->w <= 0) return sk_fail(SK_ERR_INVALID, "w must be positive (the scan takes c %% w)");
+    if (p->t_start < 0 || p->t_end < p->t_start) return sk_fail(SK_ERR_INVALID, "bad statistics window");
+    if (max_segs <= 0) return sk_fail(SK_ERR_INVALID, "max_segs must be positive");
+    return SK_OK;
+}
+
+int sk_drna_roll_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                         const sk_roll_params *p, int32_t *d_xy, int32_t *d_found)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    int rc = check_i16(d_sig, stride, d_len, nreads);
+    if (rc) return rc;
+    if ((rc = check_roll(p))) return rc;
+    if (nreads == 0) return SK_OK;
+    if (!d_xy || !d_found) return sk_fail(SK_ERR_INVALID, "NULL xy/found");
+    return drna_roll_dev(c, d_sig, stride, d_len, nreads, p, d_xy, d_found);
+}
+
+int sk_drna_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                            const sk_drna_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    int rc = check_i16(d_sig, stride, d_len, nreads);
+    if (rc) return rc;
+    if ((rc = check_drna(p, max_segs))) return rc;
+    if (nreads == 0) return SK_OK;
+    if (!d_segs || !d_nsegs) return sk_fail(SK_ERR_INVALID, "NULL segs/nsegs");
+    return drna_segment_dev(c, d_sig, stride, d_len, nreads, p, d_segs, d_nsegs, max_segs);
+}
+
 int sk_drna_roll_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads,
                            const sk_roll_params *p, int32_t *xy, int32_t *found)
 {
@@ -913,38 +1012,18 @@ int sk_drna_roll_batch_i16(const int16_t *sig, int64_t stride, const int32_t *le
     int rc = check_i16(sig, stride, len, nreads);
     if (rc) return rc;
     if ((rc = check_len_host(len, nreads, stride))) return rc;
-    if (!p) return sk_fail(SK_ERR_INVALID, "NULL sk_roll_params");
-    if (p->w <= 0) return sk_fail(SK_ERR_INVALID, "the rolling window w must be positive");
+    if ((rc = check_roll(p))) return rc;
     if (nreads == 0) return SK_OK;
     if (!xy || !found) return sk_fail(SK_ERR_INVALID, "NULL xy/found");
-    int32_t lo = p->lim_low, hi = p->lim_hi;
-    clamp_limits(&lo, &hi);
-    const int64_t words = (stride + 63) / 64;
     const size_t sb = (size_t)nreads * (size_t)stride * sizeof(int16_t);
     if ((rc = sk_reserve(c, &c->sig, sb))) return rc;
     if ((rc = sk_reserve(c, &c->len, (size_t)nreads * sizeof(int32_t)))) return rc;
-    if ((rc = sk_reserve(c, &c->comp, sb))) return rc;
-    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
-    if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * 2 * sizeof(uint64_t)))) return rc;
-    if ((rc = sk_reserve(c, &c->misc, (size_t)nreads * (size_t)(stride + 1) * sizeof(int64_t)))) return rc;
     if ((rc = sk_reserve(c, &c->out, (size_t)nreads * 2 * sizeof(int32_t)))) return rc;
     if ((rc = sk_reserve(c, &c->out2, (size_t)nreads * sizeof(int32_t)))) return rc;
     SK_HIP(hipMemcpyAsync(c->sig.p, sig, sb, hipMemcpyHostToDevice, c->stream));
     SK_HIP(hipMemcpyAsync(c->len.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    SK_HIP(hipEventRecord(c->ev[0], c->stream));
-    // filter + order-preserving compaction (the medmad kernel: its statistics are not used here)
-    rc = sk_launch_prep_i16(c, (const int16_t *)c->sig.p, stride, (const int32_t *)c->len.p, nreads, lo, hi,
-                            SK_PREP_MEDMAD, 0.0, (int16_t *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
-    if (rc) return rc;
-    uint64_t *below = (uint64_t *)c->mask.p, *above = below + (size_t)nreads * (size_t)words;
-    rc = sk_launch_roll_stats(c, (const int16_t *)c->comp.p, stride, (sk_prep *)c->prep.p, nreads, p->w,
-                              p->std_scale, (int64_t *)c->misc.p, below, above);
-    if (rc) return rc;
-    SK_HIP(hipEventRecord(c->ev[1], c->stream));
-    rc = sk_launch_roll_walk(c, below, above, (const sk_prep *)c->prep.p, nreads, p, (int32_t *)c->out.p,
-                             (int32_t *)c->out2.p);
-    if (rc) return rc;
-    c->ev_valid = true;
+    if ((rc = drna_roll_dev(c, (const int16_t *)c->sig.p, stride, (const int32_t *)c->len.p, nreads, p,
+                            (int32_t *)c->out.p, (int32_t *)c->out2.p))) return rc;
     SK_HIP(hipMemcpyAsync(xy, c->out.p, (size_t)nreads * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     SK_HIP(hipMemcpyAsync(found, c->out2.p, (size_t)nreads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     SK_HIP(hipStreamSynchronize(c->stream));
@@ -959,37 +1038,19 @@ int sk_drna_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t 
     int rc = check_i16(sig, stride, len, nreads);
     if (rc) return rc;
     if ((rc = check_len_host(len, nreads, stride))) return rc;
-    if (!p) return sk_fail(SK_ERR_INVALID, "NULL sk_drna_params");
-    if (p->w <= 0) return sk_fail(SK_ERR_INVALID, "w must be positive (the scan takes c %% w)");
-    if (p->t_start < 0 || p->t_end < p->t_start) return sk_fail(SK_ERR_INVALID, "bad statistics window");
-    if (max_segs <= 0) return sk_fail(SK_ERR_INVALID, "max_segs must be positive");
+    if ((rc = check_drna(p, max_segs))) return rc;
     if (nreads == 0) return SK_OK;
     if (!segs || !nsegs) return sk_fail(SK_ERR_INVALID, "NULL segs/nsegs");
-    int32_t lo = p->lim_low, hi = p->lim_hi;
-    clamp_limits(&lo, &hi);
-    const int64_t words = (stride + 63) / 64;
     const size_t sb = (size_t)nreads * (size_t)stride * sizeof(int16_t);
     const size_t gb = (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t);
     if ((rc = sk_reserve(c, &c->sig, sb))) return rc;
     if ((rc = sk_reserve(c, &c->len, (size_t)nreads * sizeof(int32_t)))) return rc;
-    if ((rc = sk_reserve(c, &c->comp, sb))) return rc;
-    if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
-    if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * sizeof(uint64_t)))) return rc;
     if ((rc = sk_reserve(c, &c->out, gb))) return rc;
     if ((rc = sk_reserve(c, &c->out2, (size_t)nreads * sizeof(int32_t)))) return rc;
     SK_HIP(hipMemcpyAsync(c->sig.p, sig, sb, hipMemcpyHostToDevice, c->stream));
     SK_HIP(hipMemcpyAsync(c->len.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    SK_HIP(hipMemsetAsync(c->out.p, 0, gb, c->stream));
-    SK_HIP(hipEventRecord(c->ev[0], c->stream));
-    rc = sk_launch_prep_i16(c, (const int16_t *)c->sig.p, stride, (const int32_t *)c->len.p, nreads, lo, hi,
-                            SK_PREP_DRNA, p->std_scale, (int16_t *)c->comp.p, (sk_prep *)c->prep.p,
-                            (uint64_t *)c->mask.p, nreads, p->t_start, p->t_end);
-    if (rc) return rc;
-    SK_HIP(hipEventRecord(c->ev[1], c->stream));
-    rc = sk_launch_drna_walk(c, (const uint64_t *)c->mask.p, nreads, (const sk_prep *)c->prep.p, nreads, p,
-                             (int32_t *)c->out.p, (int32_t *)c->out2.p, max_segs);
-    if (rc) return rc;
-    c->ev_valid = true;
+    if ((rc = drna_segment_dev(c, (const int16_t *)c->sig.p, stride, (const int32_t *)c->len.p, nreads, p,
+                               (int32_t *)c->out.p, (int32_t *)c->out2.p, max_segs))) return rc;
     SK_HIP(hipMemcpyAsync(segs, c->out.p, gb, hipMemcpyDeviceToHost, c->stream));
     SK_HIP(hipMemcpyAsync(nsegs, c->out2.p, (size_t)nreads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     SK_HIP(hipStreamSynchronize(c->stream));

@@ -492,20 +492,65 @@ def close_groups():
         _groups.clear()
 
 
-def run_sharded(devices, total, fn, rccl=False):
+_fault_hook = None          # tests: callable(rank) run at the start of a rank's shard (raises to play a failing device)
+
+
+def run_sharded(devices, total, fn, rccl=False, reshard=None):
     """fn(lo, hi, comm) on one thread per device, over the block split of `total` reads.  Results are written
-    by fn into views of caller-owned host arrays (that IS the host-side gather).  Returns the group."""
+    by fn into views of caller-owned host arrays (that IS the host-side gather).  Returns the group.
+
+    A rank whose shard fails with a library error (a device that dropped out, ran out of memory, ...) does not take the
+    job down while other devices are healthy ("never abort the stream of reads"): its block is cut up
+    over the surviving devices and run again there, with one line on stderr.  Only for shards that do not talk to each
+    other (reshard defaults to `not rccl`); invalid arguments (SK_ERR_INVALID) fail on every device alike and are raised.
+    If every rank failed, or the second attempt fails too, the first error is raised."""
+    import sys
     g = group_for(devices, rccl=rccl)
+    reshard = (not rccl) if reshard is None else reshard
+    failed = []                                                      # (rank, lo, hi, error)
+    mu = threading.Lock()
 
     def body(comm):
         lo, hi = sharding.shard_bounds(total, comm.rank, comm.world)
-        return fn(lo, hi, comm)
+        try:
+            if _fault_hook is not None:
+                _fault_hook(comm.rank)
+            return fn(lo, hi, comm)
+        except _lib.SquiggleKitError as e:
+            if not reshard or e.code == -2:                          # SK_ERR_INVALID: the caller's arguments
+                raise
+            with mu:
+                failed.append((comm.rank, lo, hi, e))
+            return None
 
     try:
         g.run(body)
     except BaseException:
         drop_group(g)
         raise
+    if failed:
+        bad = {r for r, _, _, _ in failed}
+        good = [d for k, d in enumerate(g.devices) if k not in bad]
+        drop_group(g)                                                # (a context that failed is not reused)
+        if not good:
+            raise failed[0][3]
+        for r, lo, hi, e in sorted(failed):
+            sys.stderr.write("squigglekit: device %d (rank %d) failed on reads %d..%d (%s); re-running them on device(s) %s\n"
+                             % (g.devices[r], r, lo, hi - 1, e, ", ".join(str(d) for d in good)))
+            n = hi - lo
+            if n <= 0:
+                continue
+            g2 = group_for(good, rccl=False)
+
+            def again(comm, lo=lo, n=n):
+                a, b = sharding.shard_bounds(n, comm.rank, comm.world)
+                return fn(lo + a, lo + b, comm) if b > a else None
+            try:
+                g2.run(again)
+            except BaseException:
+                drop_group(g2)
+                raise
+        return group_for(good, rccl=False)
     return g
 
 

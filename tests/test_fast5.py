@@ -88,3 +88,44 @@ def test_fast5_cli_branches_cpu(oracle_backend, scrappy_stub, tmp_path):    # no
 @pytest.mark.gpu
 def test_fast5_cli_branches_gpu(gpu, scrappy_stub, tmp_path):               # noqa: F811
     _replay(tmp_path)
+
+
+def _replay_multi():
+    """The multi-read branch (segmenter.py:233-260, 358-396; tsvio.read_multi_fast5 -> segmenter_cli): the reference's
+    main() on tests/golden/multi_two_reads.fast5 (two reads with different channel constants, deflate-compressed
+    signals; laid out by tools/hdf5_write_min.py, goldens by tools/gen_golden_fast5.py:multi_read)."""
+    from squigglekit_amd.segmenter_cli import main as seg_main
+    path = os.path.join(GOLD, "multi_two_reads.fast5")
+    gold = load_golden("fast5_multi_cli.json.gz")
+    for run in gold["runs"]:
+        so, se, code = run_cli(seg_main, [a.replace("<F5>", path) for a in run["argv"]])
+        assert so.replace(path, "<F5>") == run["stdout"], (run["argv"], so[-300:], run["stdout"][-300:])
+        assert code == run["exit"] and _no_traceback(se.replace(path, "<F5>")) == _no_traceback(run["stderr"]), run["argv"]
+    assert len(gold["runs"]) == 5 and gold["runs"][0]["stdout"].count("\n") == 2
+
+
+def test_multi_read_fast5_reader():
+    """hdf5min on the multi-read fixture: both groups, their attributes, the signals byte-equal to the stretches of the
+    example read they were cut from."""
+    from squigglekit_amd import hdf5min, tsvio
+    with hdf5min.File(os.path.join(GOLD, "example_test.fast5")) as f:
+        name = list(f["Raw/Reads"].keys())[0]
+        sig = f["Raw/Reads"][name]["Signal"][()]
+    with hdf5min.File(os.path.join(GOLD, "multi_two_reads.fast5")) as f:
+        keys = list(f.keys())
+        assert keys == ["read_0a1b2c3d-aaaa-4bbb-8ccc-000000000001", "read_0a1b2c3d-aaaa-4bbb-8ccc-000000000002"]
+        assert np.array_equal(f[keys[0]]["Raw/Signal"][()], sig[:9000])
+        assert np.array_equal(f[keys[1]]["Raw/Signal"][()], sig[14000:26000])
+        assert f[keys[1]]["Raw"].attrs["read_id"].decode() == keys[1][5:]
+        assert f[keys[1]]["channel_id"].attrs["offset"] == f[keys[0]]["channel_id"].attrs["offset"] + 7.0
+    raw = tsvio.read_multi_fast5(os.path.join(GOLD, "multi_two_reads.fast5"), True)
+    assert list(raw) == keys and np.array_equal(raw[keys[0]], sig[:9000])
+
+
+def test_multi_read_fast5_cli_cpu(oracle_backend):                          # noqa: F811
+    _replay_multi()
+
+
+@pytest.mark.gpu
+def test_multi_read_fast5_cli_gpu(gpu):
+    _replay_multi()

@@ -191,6 +191,14 @@ def test_product_api_two_ranks_on_one_device(gpu, ora, monkeypatch):
     one = api.motifseq_multi_ragged_f64(flat, off, motifs)
     two = api.motifseq_multi_ragged_f64(flat, off, motifs, devices=[0, 0])
     assert [h.tobytes() for h in one] == [h.tobytes() for h in two]
+    # a rank that fails is not the end of the job (round 5): its block is re-run on the surviving device(s)
+    def fault(rank):
+        if rank == 1:
+            raise gpu.SquiggleKitError(-3, "device lost (injected)")
+    monkeypatch.setattr(multigpu, "_fault_hook", fault)
+    got = api.motifseq_batch(sig, lens, motif, devices=[0, 0, 0])
+    monkeypatch.setattr(multigpu, "_fault_hook", None)
+    assert got.tobytes() == plain.tobytes()
     multigpu.close_groups()
     gpu.init(0)                                                       # back to the plain binding for later tests
 

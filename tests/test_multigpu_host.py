@@ -118,6 +118,45 @@ def test_sharded_host_gather_equals_unsharded(ora):
     assert sorted(seen) == [(0, 8), (8, 16), (16, 23)]
 
 
+def test_run_sharded_reruns_a_failed_ranks_block_on_the_survivors(ora, monkeypatch, capsys):
+    """A rank whose shard raises a library error (a device that dropped out) does not abort the job: its block is cut up
+    over the surviving devices and run again; invalid arguments and an all-ranks failure are still raised."""
+    from squigglekit_amd import _lib, multigpu, synth
+    motif = synth.synthetic_motif(40)
+    sig = synth.squiggle_batch(23, 600, 99, motif=motif)
+    lens = np.full(23, 600, dtype=np.int32)
+    want = ora.motifseq_batch_i16(sig, lens, motif)
+    out = np.zeros_like(want)
+    for key in ((0, 1, 2), (0, 2), (1,)):                        # (host-logic groups: no device to bind here)
+        multigpu._groups[key] = multigpu.ThreadGroup(key, rccl=False, bind=False)
+    calls = []
+
+    def shard(lo, hi, comm):
+        calls.append((lo, hi))
+        out[lo:hi] = ora.motifseq_batch_i16(sig[lo:hi], lens[lo:hi], motif)
+
+    def fault(rank):
+        if rank == 1:
+            raise _lib.SquiggleKitError(-3, "hipStreamSynchronize failed: device lost (injected)")
+    monkeypatch.setattr(multigpu, "_fault_hook", fault)
+    g = multigpu.run_sharded([0, 1, 2], 23, shard)
+    monkeypatch.setattr(multigpu, "_fault_hook", None)
+    assert out.tobytes() == want.tobytes()
+    assert sorted(calls) == [(0, 8), (8, 12), (12, 16), (16, 23)]      # rank 1's block 8..15 redone by devices 0 and 2
+    assert g.devices == [0, 2] and (0, 1, 2) not in multigpu._groups
+    assert "device 1 (rank 1) failed on reads 8..15" in capsys.readouterr().err
+    # every rank failing, or the caller's arguments being wrong: raised
+    multigpu._groups[(0, 2)] = multigpu.ThreadGroup((0, 2), rccl=False, bind=False)
+    monkeypatch.setattr(multigpu, "_fault_hook", lambda rank: (_ for _ in ()).throw(_lib.SquiggleKitError(-3, "all gone")))
+    with pytest.raises(_lib.SquiggleKitError):
+        multigpu.run_sharded([0, 2], 23, shard)
+    multigpu._groups[(0, 2)] = multigpu.ThreadGroup((0, 2), rccl=False, bind=False)
+    monkeypatch.setattr(multigpu, "_fault_hook", lambda rank: (_ for _ in ()).throw(_lib.SquiggleKitError(-2, "bad argument")))
+    with pytest.raises(_lib.SquiggleKitError):
+        multigpu.run_sharded([0, 2], 23, shard)
+    multigpu._groups.clear()
+
+
 _WORKER = r"""
 import os, sys
 import numpy as np

@@ -18,6 +18,8 @@ import sys
 import tempfile
 import types
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -68,6 +70,41 @@ def main():
     shutil.rmtree(tmp)
     for r in runs:
         print(r["tool"], r["argv"], "->", repr(r["stdout"][:90]), "| stderr tail:", repr(r["stderr"][-90:]))
+    multi_read(seg)
+
+
+def multi_read(seg):
+    """The multi-read branch (segmenter.py:233-260, 358-396: no --single): the reference ships no multi-read file, so a
+    fixture is LAID OUT here (tools/hdf5_write_min.py: classic HDF5, deflate-compressed Signal datasets, the attributes
+    the reference reads) from two stretches of the reference's own example read with its channel constants, and the
+    reference's main() is run on it."""
+    from hdf5_write_min import write_hdf5
+    with hdf5min.File(os.path.join(GOLD, "example_test.fast5")) as f:
+        name = list(f["Raw/Reads"].keys())[0]
+        sig = f["Raw/Reads"][name]["Signal"][()]
+        ch = {k: float(v) for k, v in f["UniqueGlobalKey/channel_id"].attrs.items()
+              if k in ("digitisation", "offset", "range", "sampling_rate")}
+    chan = {"@" + k: v for k, v in ch.items()}
+    chan2 = dict(chan, **{"@offset": ch["offset"] + 7.0, "@range": ch["range"] * 1.015})     # (per-read constants differ)
+    tree = {"read_0a1b2c3d-aaaa-4bbb-8ccc-000000000001": {"Raw": {"@read_id": b"0a1b2c3d-aaaa-4bbb-8ccc-000000000001",
+                                                                  "Signal": np.ascontiguousarray(sig[:9000])},
+                                                          "channel_id": chan},
+            "read_0a1b2c3d-aaaa-4bbb-8ccc-000000000002": {"Raw": {"@read_id": b"0a1b2c3d-aaaa-4bbb-8ccc-000000000002",
+                                                                  "Signal": np.ascontiguousarray(sig[14000:26000])},
+                                                          "channel_id": chan2}}
+    path = os.path.join(GOLD, "multi_two_reads.fast5")
+    write_hdf5(path, tree)
+    runs = []
+    for argv in (["-i", path], ["-i", path, "--raw_signal"], ["-i", path, "-n", "6000"], ["-i", path, "-ku", "-j", "100"],
+                 ["-i", path, "-w", "60", "-e", "9"]):
+        so, se, code = gg.run_main(seg, ["segmenter.py"] + argv)
+        runs.append({"tool": "segmenter", "argv": [a.replace(path, "<F5>") for a in argv], "stdout": so.replace(path, "<F5>"),
+                     "stderr": se.replace(path, "<F5>"), "exit": code})
+        print("multi", argv[1:], "->", repr(so[:120]), "| stderr tail:", repr(se[-80:]))
+    with gzip.open(os.path.join(GOLD, "fast5_multi_cli.json.gz"), "wt") as fh:
+        json.dump({"generator": "tools/gen_golden_fast5.py:multi_read -- /root/reference segmenter.py main() (multi-read branch) on "
+                                "tests/golden/multi_two_reads.fast5 (two stretches of example/test.fast5's signal, laid out by "
+                                "tools/hdf5_write_min.py); h5py stood in by squigglekit_amd.hdf5min", "runs": runs}, fh, indent=1)
 
 
 if __name__ == "__main__":
