@@ -78,7 +78,7 @@ struct sdtw_kargs {
     int32_t       *retry_cnt;
     // fixed-point screening scheme
     const unsigned *xlayq;      // motif, quantised + biased, laid out per lane [L][R]
-    unsigned      *ckq;         // [slot][nck][L][R+2] unsigned
+    unsigned      *ckq;         // [slot][nck][L][(R+3)/2]: the high halves of the R + 2 state words, two to a dword
     unsigned      *lastq;       // [slot][lq_stride]: screening cost of the last row per column
     int64_t        lq_stride;
     int32_t       *qflag;       // [slot]: screening minimum of the read; QINF = a sample left the fixed-point range
@@ -93,6 +93,7 @@ struct sdtw_kargs {
     const int16_t *fz_raw;      // raw rows (same stride), or nullptr: prep / samples were filled by an earlier kernel
     const int32_t *fz_len;
     int            fz_lo, fz_hi, fz_vec;
+    int            lds_wave_words; // pass Q: words of dynamic LDS per wavefront (the prologue's histogram, then the interval's last-row values)
     int32_t       *early;       // reads pass Q already knows cannot be screened (candidate range too wide, samples out of
     int32_t       *early_cnt;   // range): their exact retry starts right behind pass Q, beside the window passes
     unsigned long long *clk;    // pass Q: {shader cycles, 100 MHz reference ticks} of the first wave's sweep, or nullptr

@@ -152,7 +152,7 @@ __device__ __forceinline__ void candidate_columns(const sdtw_kargs &a, int r, in
 // pass Q
 // ---------------------------------------------------------------------------------------------
 #ifndef SK_Q_WAVES
-#define SK_Q_WAVES(R) 1
+#define SK_Q_WAVES(R) 4    /* four waves per SIMD (128 VGPRs): R <= 32 rows of 3 words + the feed; the little that does not fit is spilled from the cold ends of the kernel */
 #endif
 // P0: every lane owns R rows (the motif fills L x R slots exactly): no short-lane select after the column
 template <int L, int R, int FEED, bool P0>
@@ -161,7 +161,7 @@ void k_sdtw_q(const sdtw_kargs a)
 {
     static_assert(L == 8 || L == 16 || L == 64, "lanes per read");
     constexpr int G = 64 / L;
-    constexpr int CKW = R + 2;
+    constexpr int CKH = (R + 3) / 2;                // dwords per lane and checkpoint: R + 2 state words, their high halves
     constexpr int U = (L < 16) ? L : 16;            // steps per unrolled run (y values prefetched from LDS)
 
     const int lane = threadIdx.x & 63;
@@ -177,6 +177,9 @@ void k_sdtw_q(const sdtw_kargs a)
     unsigned long long tc0 = 0, tr0 = 0;
     if (timer) { tc0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
 
+    // per wave: lds_wave_words words of dynamic LDS -- the prologue's value histogram, then (the prologue is over by then)
+    // the last-row values of the checkpoint interval in progress, ck words per read group
+    extern __shared__ __align__(16) unsigned char lds_dyn[];
     int n;
     double center = 0.0, scale = 1.0;
     const int16_t *s16 = nullptr;
@@ -187,10 +190,10 @@ void k_sdtw_q(const sdtw_kargs a)
             // (sk_prepw_dev.h: compacted samples -> a.samples, statistics -> a.prep, both also read by the later
             // passes).  Latency-bound work that the sweeps of the SIMD's other waves hide; as a kernel of its own it
             // cost 4 ms per 1 M reads.
-            extern __shared__ __align__(16) unsigned char lds_dyn[];
             const int nb4 = ((a.fz_hi - a.fz_lo - 1) + 3) & ~3;
-            const prepw_env E = prepw_setup<5>((unsigned *)lds_dyn + (size_t)(threadIdx.x >> 6) * nb4, lane,
+            const prepw_env E = prepw_setup<5>((unsigned *)lds_dyn + (size_t)(threadIdx.x >> 6) * a.lds_wave_words, lane,
                                                a.fz_lo, a.fz_hi, a.fz_vec);
+            (void)nb4;
             n = 0;
             for (int gg = 0; gg < G; gg++) {
                 if (wave * G + gg >= a.nreads) break;           // (wave-uniform)
@@ -298,8 +301,16 @@ void k_sdtw_q(const sdtw_kargs a)
     // so that sample t0 + q - l of an even block is ybuf[2L + q - l] and of an odd one ybuf[L + q - l].
     __shared__ unsigned lds_all[4][5 * 64];
     unsigned *ybuf = lds_all[threadIdx.x >> 6] + g * 5 * L;
-    unsigned *hbuf = ybuf + 3 * L;
-    unsigned *hw = (l == L - 1) ? hbuf : hbuf + L;  // every other lane writes to a dump row
+    unsigned *dump = ybuf + 3 * L;                  // 2 L words: where the lanes that do not hold the last row write
+    // The last row is kept per CHECKPOINT INTERVAL in LDS and goes to memory only when the interval can hold a candidate
+    // column (round 5).  A column is a candidate when its cost is within 2 E of the read's FINAL minimum b; the minimum so
+    // far, m, is >= b, so an interval whose smallest value exceeds m + 2 E holds none -- and every later look at the row
+    // (this kernel's epilogue, pass P's second tier, pass W's premise test) only visits intervals whose per-lane
+    // summaries are <= b + 2 E, i.e. intervals that WERE stored.  On the C4 batch about one interval in eight goes out:
+    // 16 KB of last row per read became 2-3.
+    unsigned *ibuf = (unsigned *)lds_dyn + (size_t)(threadIdx.x >> 6) * a.lds_wave_words + g * a.ck;
+    int ioff = 0;                                   // steps of the current interval done
+    unsigned gmin = QINF;                           // minimum of the read's last row over the intervals already closed
     ybuf[L + l] = QINF;                             // columns before the read
     unsigned F = toq(loadraw(l), l);
     // one step: lane l-1's bottom row comes in by DPP, run the column old -> nw
@@ -311,22 +322,50 @@ void k_sdtw_q(const sdtw_kargs a)
         if constexpr (P0)          botq = nw[R - 1];
         else if constexpr (R >= 2) asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(botq) : "v"(nw[R - 2]), "v"(nw[R - 1]), "v"(smask));
         else                       asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(botq) : "v"(upq), "v"(nw[0]), "v"(smask));
-        *hslot = nw[R - 1];                         // (only lane L-1's lands in hbuf)
+        *hslot = nw[R - 1];                         // (only lane L-1's lands in the interval buffer)
+    };
+    // close interval c (nb blocks of it are in ibuf): store it if it can hold a candidate
+    auto flush = [&](int c, int nb) {
+        unsigned im = smin;
+#pragma unroll
+        for (int d = 1; d < L; d <<= 1) im = min(im, (unsigned)__shfl_xor((int)im, d));
+        const unsigned lim = (gmin > QINF - 2u * a.qerr) ? QINF : gmin + 2u * a.qerr;
+        const bool keep = live && im <= lim;
+        gmin = min(gmin, im);
+        if (keep) {
+            unsigned *dst = lastq + (int64_t)c * a.ck + l + 1;        // (rows start L early: see below)
+            for (int q = 0; q < nb; q++) dst[q * L] = ibuf[q * L + l];
+        }
     };
     for (int blk = 0; blk < nblk; blk++) {
         const auto rawnext = loadraw((blk + 1) * L + l);
         const int t0 = blk * L;
-        if (t0 > 0 && (t0 % a.ck) == 0 && t0 / a.ck <= a.nck && live) {
-            unsigned *cp = a.ckq + (((int64_t)(r - a.read0) * a.nck + (t0 / a.ck - 1)) * L + l) * CKW;
+        if (t0 > 0 && (t0 % a.ck) == 0) {                    // (wave-uniform) a checkpoint interval ends here
+          if (t0 / a.ck <= a.nck && live) {
+            // Checkpoints go out as the HIGH HALVES of the state words, two to a dword (round 5: 27 -> 14 dwords per lane
+            // and checkpoint, 27 KB -> 14 KB per read; pass Q 48.5 -> 47.4 ms).  What is dropped is less than 2^16 units =
+            // 0.016 signal units, and it is dropped DOWNWARDS: a restored state is cell by cell <= the screening state and
+            // >= it minus 2^16, the recurrence is monotone and non-expanding (min and saturating add), so everything the
+            // pre-roll computes from it keeps that property -- and the window pass only ever uses restored cells as lower
+            // bounds (Dq - E) of exact values (file header), which they still are.
+            unsigned *cp = a.ckq + (((int64_t)(r - a.read0) * a.nck + (t0 / a.ck - 1)) * L + l) * CKH;
+            auto hi2 = [](unsigned lo_word, unsigned hi_word) -> unsigned {   // {lo_word >> 16, hi_word >> 16} in one v_perm_b32
+                return __builtin_amdgcn_perm(hi_word, lo_word, 0x07060302u);
+            };
 #pragma unroll
-            for (int k = 0; k < R; k++) cp[k] = Da[k];
-            cp[R] = botq; cp[R + 1] = diagq;
+            for (int k = 0; k + 1 < R; k += 2) cp[k / 2] = hi2(Da[k], Da[k + 1]);
+            if constexpr (R % 2) { cp[R / 2] = hi2(Da[R - 1], botq); cp[R / 2 + 1] = hi2(diagq, 0u); }
+            else                 { cp[R / 2] = hi2(botq, diagq); }
             // summary of the last row: the minimum over the columns this lane handed to lastq during the ck steps
             // before this one (columns == l + 1 mod L of one window of ck columns) -- pass P looks at the
             // (nck + 1) * L summaries of a read instead of all its columns
             a.lsum[((int64_t)(r - a.read0) * (a.nck + 1) + (t0 / a.ck - 1)) * L + l] = smin;
+          }
+            flush(t0 / a.ck - 1, a.ck / L);
             smin = QINF;
+            ioff = 0;
         }
+        unsigned *hw = (l == L - 1) ? ibuf + ioff : dump;             // every other lane writes to a dump row
         const unsigned *yr;
         if (blk & 1) { ybuf[L + l] = F; yr = ybuf + L - l; }
         else         { ybuf[l] = F; ybuf[2 * L + l] = F; yr = ybuf + 2 * L - l; }
@@ -345,12 +384,14 @@ void k_sdtw_q(const sdtw_kargs a)
         // lane L-1's column at step t0 + l is t0 + l - (L - 1).  Rows of lastq carry L columns of padding in front and
         // 2 L behind, so every lane stores without a range test; columns outside the read hold costs of 2^30 units
         // and more (their sample is "infinite"), which neither the summaries nor pass P's column test (j < n) mind.
-        { const unsigned hv = hbuf[l]; lastq[t0 + l + 1] = hv; smin = min(smin, hv); }
+        { const unsigned hv = ibuf[ioff + l]; smin = min(smin, hv); }
+        ioff += L;
     }
     // the columns after the last checkpoint
     {
         const int cl = nblk > 0 ? min((nblk * L - 1) / a.ck, a.nck) : 0;   // checkpoints this wave passed (wave-uniform)
         if (live) a.lsum[((int64_t)(r - a.read0) * (a.nck + 1) + cl) * L + l] = smin;
+        if (nblk > 0) flush(cl, ioff / L);
         // (summaries of intervals the read never reached)
         for (int cc = cl + 1; cc <= a.nck; cc++)
             if (live) a.lsum[((int64_t)(r - a.read0) * (a.nck + 1) + cc) * L + l] = QINF;
@@ -462,11 +503,13 @@ void k_sdtw_p(const sdtw_kargs a)
     unsigned botq = QINF, diagq = QINF;
 #pragma unroll
     for (int k = 0; k < R; k++) Qs[k] = QINF;
-    const unsigned *cp = a.ckq + (((int64_t)(r - a.read0) * a.nck + (c0 > 0 ? c0 - 1 : 0)) * L + l) * CKW;
+    constexpr int CKH = (R + 3) / 2;                // (pass Q stores the high halves of the R + 2 state words, two to a dword)
+    const unsigned *cp = a.ckq + (((int64_t)(r - a.read0) * a.nck + (c0 > 0 ? c0 - 1 : 0)) * L + l) * CKH;
     auto load_ckpt = [&]() {
+        auto word = [&](int k) -> unsigned { const unsigned w2 = cp[k / 2]; return (k & 1) ? (w2 & 0xffff0000u) : (w2 << 16); };
 #pragma unroll
-        for (int k = 0; k < R; k++) Qs[k] = cp[k];
-        botq = cp[R]; diagq = cp[R + 1];
+        for (int k = 0; k < R; k++) Qs[k] = word(k);
+        botq = word(R); diagq = word(R + 1);
     };
     int maxpre = npre;
 #pragma unroll
@@ -970,12 +1013,13 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
     const int nck = (int)((maxlen + L - 1) / ck);
     const size_t lq_stride = (size_t)((maxlen + 3 * L + 7) & ~(int64_t)3);      // L columns of padding in front, 2 L behind
     const size_t state_bytes = (size_t)L * (R + 2) * sizeof(unsigned);
-    const size_t per_read = (size_t)(nck > 0 ? nck : 1) * state_bytes + lq_stride * sizeof(unsigned) + state_bytes +
+    const size_t ck_bytes = (size_t)L * ((R + 3) / 2) * sizeof(unsigned);          // a checkpoint: the state's high halves
+    const size_t per_read = (size_t)(nck > 0 ? nck : 1) * ck_bytes + lq_stride * sizeof(unsigned) + state_bytes +
                             (size_t)(nck + 1) * L * sizeof(unsigned) + 64;
     int64_t chunk;
     while (true) {                                      // (a device short of memory: halve the budget and try again)
         chunk = sk_dtw_chunk_reads(per_read, a->nreads);
-        rc = sk_reserve(c, &c->ckpt, (size_t)chunk * (size_t)(nck > 0 ? nck : 1) * state_bytes);
+        rc = sk_reserve(c, &c->ckpt, (size_t)chunk * (size_t)(nck > 0 ? nck : 1) * ck_bytes);
         if (!rc) rc = sk_reserve(c, &c->lastq, (size_t)chunk * lq_stride * sizeof(unsigned));
         if (!rc) rc = sk_reserve(c, &c->wstate, (size_t)chunk * state_bytes);
         if (!rc) rc = sk_reserve(c, &c->lsum, (size_t)chunk * (size_t)(nck + 1) * L * sizeof(unsigned));
@@ -1011,6 +1055,7 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
     k.early_cnt = d_early_cnt; k.early = d_early;
     k.qerr = (unsigned)(N + maxlen + 2);
     k.wmax = 4 * ck;
+    k.lds_wave_words = (64 / L) * ck;                   // pass Q, per wave: the interval's last-row values of its read groups
     k.guard = sk_tune("SK_DTW_NOGUARD") ? nullptr : (int32_t *)c->dtwcnt.p + 8;
     if (const char *e = sk_tune("SK_DTW_HOLE")) {                 // tests: a known hole back in, for the guard to find
         k.hole = strcmp(e, "qerr1") == 0 ? SK_HOLE_QERR1 : strcmp(e, "fma64") == 0 ? SK_HOLE_FMA64
@@ -1025,7 +1070,8 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
     // filter + medmad fused into pass Q (the caller checked the limits: sk_sdtw_fuse_ok)
     size_t fz_lds = 0;
     const sk_prep_fuse fz = a->fuse ? *a->fuse : sk_prep_fuse();
-    if (a->fuse) fz_lds = (size_t)4 * (size_t)(((fz.hi - fz.lo - 1) + 3) & ~3) * sizeof(unsigned);
+    if (a->fuse && (((fz.hi - fz.lo - 1) + 3) & ~3) > k.lds_wave_words) k.lds_wave_words = ((fz.hi - fz.lo - 1) + 3) & ~3;   // (or the prologue's histogram)
+    fz_lds = (size_t)4 * (size_t)k.lds_wave_words * sizeof(unsigned);
 
     const size_t nchunks = (size_t)((a->nreads + chunk - 1) / chunk);
     while (c->evpool.size() < 3 * nchunks) {
