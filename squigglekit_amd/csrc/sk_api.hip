@@ -211,7 +211,8 @@ int motifseq_dev(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t 
     // sk_launch_sdtw runs them as a kernel of their own when it does not take the screening scheme
     sk_prep_fuse fz;
     fz.raw = d_sig; fz.len = d_len; fz.lo = scale_low; fz.hi = scale_hi;
-    const bool fuse = scale_mode == SK_SCALE_MEDMAD && sk_sdtw_fuse_ok(scale_low, scale_hi);
+    fz.mode = scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE;
+    const bool fuse = sk_sdtw_fuse_ok(scale_low, scale_hi, fz.mode, stride);
     SK_HIP(hipEventRecord(c->ev[0], c->stream));
     if (!fuse) {
         rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nreads, scale_low, scale_hi,
@@ -286,9 +287,10 @@ static int motifseq_multi_dev(sk_ctx *c, const int16_t *d_sig, int64_t stride, c
                               sk_hit *d_out, int64_t out_stride, int later_batch)
 {
     int rc;
-    const bool fuse = scale_mode == SK_SCALE_MEDMAD && sk_sdtw_fuse_ok(scale_low, scale_hi);
     sk_prep_fuse fz;
     fz.raw = d_sig; fz.len = d_len; fz.lo = scale_low; fz.hi = scale_hi;
+    fz.mode = scale_mode == SK_SCALE_MEDMAD ? SK_PREP_MEDMAD : SK_PREP_ZSCALE;
+    const bool fuse = sk_sdtw_fuse_ok(scale_low, scale_hi, fz.mode, stride);
     SK_HIP(hipEventRecord(c->ev[0], c->stream));
     if (!fuse) {
         rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nr, scale_low, scale_hi,

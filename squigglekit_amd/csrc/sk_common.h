@@ -155,8 +155,11 @@ struct sk_prep_fuse {
     const int16_t *raw = nullptr;   // device, rows of `stride` samples (sk_sdtw_args::stride)
     const int32_t *len = nullptr;   // device
     int32_t lo = 0, hi = 0;         // scale_outliers limits
+    int     mode = SK_PREP_MEDMAD;  // SK_PREP_MEDMAD or SK_PREP_ZSCALE (round 5: reads of up to 4 096 samples)
 };
-bool sk_sdtw_fuse_ok(int32_t lo, int32_t hi);   // limits inside the fused prologue's histogram range?
+// can filter + statistics of this call ride in the screening pass?  medmad: limits inside the prologue's histogram
+// range; zscale: rows of at most 4 096 samples (the wave keeps the compacted read in LDS)
+bool sk_sdtw_fuse_ok(int32_t lo, int32_t hi, int mode = SK_PREP_MEDMAD, int64_t stride = 0);
 
 struct sk_sdtw_args {
     int           feed;

@@ -259,4 +259,176 @@ __device__ __forceinline__ sk_prep prepw_read(const prepw_env &E, const int16_t 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// zscale on one wavefront (round 5; the fused prologue of the screening pass for `-l zscale`, reads of up to 4 096
+// samples).  sklearn.preprocessing.scale as MotifSeq.py:186-191 calls it: (x - np.mean(x)) / np.std(x).  The mean of
+// integer samples is an exact integer sum and one division; np.std's sum of (x - mean)^2 has to be added up in NUMPY'S
+// ORDER, because the value itself -- not a comparison against it -- goes into every normalised sample: the pairwise
+// tree of np.add.reduce (a node longer than 128 splits at (len / 2) rounded down to a multiple of 8; a leaf is eight
+// strided accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a serial tail), which the workgroup kernel
+// (sk_prep.hip pairwise_chunk) builds as a table.  Here: every leaf is at least 64 long and starts at a multiple of 8,
+// so lane l probes position 64 l, walks down from the root to the leaf that holds it (<= 6 steps of integer
+// arithmetic) and sums that leaf if it is the first probe inside it -- one leaf per lane, from the compacted samples
+// the wave keeps in LDS (16-byte reads); the leaf sums meet in a 128-entry heap in LDS, folded bottom-up level by level.
+// ------------------------------------------------------------------------------------------------------------------
+struct zs_env {
+    int16_t *lcomp;        // this wave's compacted samples in LDS (16-byte aligned, >= stride int16)
+    double  *nodes;        // 128 doubles of LDS: the pairwise tree's partial sums, heap order
+    int lo, hi;
+    bool in_vec, out_vec;
+    unsigned lo2, hi2;
+};
+
+__device__ __forceinline__ zs_env zs_setup(int16_t *lcomp, double *nodes, int lo, int hi, int vec_ok)
+{
+    zs_env e;
+    e.lcomp = lcomp; e.nodes = nodes; e.lo = lo; e.hi = hi;
+    e.in_vec = (vec_ok & 1) != 0; e.out_vec = (vec_ok & 2) != 0;
+    const int lo1 = max(lo + 1, -32768), hi1 = min(hi - 1, 32767);
+    e.lo2 = (unsigned)(lo1 & 0xffff) * 0x10001u; e.hi2 = (unsigned)(hi1 & 0xffff) * 0x10001u;
+    return e;
+}
+
+// sum over i < m of sq(lcomp[i]) in np.add.reduce's order, m <= 8192 (one reduction chunk); sq(v) >= 0
+template <typename Sq>
+__device__ __forceinline__ double wave_pairwise_sq(int m, const int16_t *lcomp, double *nodes, int lane, Sq sq)
+{
+    if (m < 8) {                                            // numpy: a plain serial loop
+        double res = 0.0;
+        for (int i = 0; i < m; i++) res += sq((int)lcomp[i]);
+        return res;
+    }
+    const int p = lane * 64;
+    int s = 0, len = m, id = 1;
+#pragma unroll 1
+    for (int it = 0; it < 7; it++) {
+        if (len > 128) {
+            int n2 = len / 2;
+            n2 -= n2 % 8;
+            if (p < s + n2) { len = n2; id = 2 * id; }
+            else            { s += n2; len -= n2; id = 2 * id + 1; }
+        }
+    }
+    const bool active = p < m && (lane == 0 || s > p - 64);     // the first probe inside its leaf
+    nodes[lane] = -1.0; nodes[lane + 64] = -1.0;                // "no such node" (the sums are >= 0)
+    __builtin_amdgcn_wave_barrier();
+    if (active) {
+        const int16_t *q = lcomp + s;                            // (s is a multiple of 8: 16-byte aligned)
+        double r[8];
+        {
+            const uint4 t = *(const uint4 *)q;
+            const unsigned w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = sq((j & 1) ? (int)w4[j >> 1] >> 16 : (int)(short)(w4[j >> 1] & 0xffffu));
+        }
+        const int full = len - (len % 8);
+        for (int i = 8; i < full; i += 8) {
+            const uint4 t = *(const uint4 *)(q + i);
+            const unsigned w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] += sq((j & 1) ? (int)w4[j >> 1] >> 16 : (int)(short)(w4[j >> 1] & 0xffffu));
+        }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (int i = full; i < len; i++) res += sq((int)q[i]);
+        nodes[id] = res;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int d = 6; d >= 1; d--) {                              // parents at depth d - 1 from their children at depth d
+        const int pid = (1 << (d - 1)) + lane;
+        if (lane < (1 << (d - 1))) {
+            const double a = nodes[2 * pid], b = nodes[2 * pid + 1];
+            if (a >= 0.0 && b >= 0.0) nodes[pid] = a + b;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return nodes[1];
+}
+
+// Read r: filter, compacted samples -> comp row (and LDS), mean / std -> prep[r] (lane 0 stores), returned in every lane.
+__device__ __forceinline__ sk_prep zs_read(const zs_env &E, const int16_t *__restrict__ sig, int64_t stride,
+                                           const int32_t *__restrict__ len, int r, int lane,
+                                           int16_t *__restrict__ comp, sk_prep *__restrict__ prep)
+{
+    const int lo = E.lo, hi = E.hi;
+    const unsigned lo2 = E.lo2, hi2 = E.hi2;
+    const int M = min(max(len[r], 0), (int)min(stride, (int64_t)0x7fffff00));
+    const int16_t *row = sig + (int64_t)r * stride;
+    int16_t *crow = comp + (int64_t)r * stride;
+    int16_t *lcomp = E.lcomp;
+    auto load8 = [&](int i0, unsigned (&q)[4]) {
+        if (E.in_vec && i0 + 8 <= M) {
+            const uint4 t = *(const uint4 *)(row + i0);
+            q[0] = t.x; q[1] = t.y; q[2] = t.z; q[3] = t.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned a = (i0 + 2 * k < M) ? (unsigned short)row[i0 + 2 * k] : 0u;
+                const unsigned b = (i0 + 2 * k + 1 < M) ? (unsigned short)row[i0 + 2 * k + 1] : 0u;
+                q[k] = a | (b << 16);
+            }
+        }
+    };
+    int run = 0, isum = 0;                                  // (|sum| <= 4 096 * 32 768 < 2^31)
+    unsigned v[4], vn[4];
+    load8(lane * 8, v);
+    for (int base = 0; base < M; base += 512) {
+        const int i0 = base + lane * 8;
+        if (base + 512 < M) load8(i0 + 512, vn);            // next tile in flight
+        unsigned changed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) changed |= clamp_pk_i16(v[k], lo2, hi2) ^ v[k];
+        if (__all(i0 + 8 <= M && changed == 0u)) {
+            put8(crow + run + lane * 8, v, E.out_vec ? (run & 7) : 1);
+            put8(lcomp + run + lane * 8, v, run & 7);
+#pragma unroll
+            for (int k = 0; k < 8; k++) isum += sample_of(v, k);
+            run += 512;
+        } else {
+            unsigned keep = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int x = sample_of(v, k);
+                if (i0 + k < M && x > lo && x < hi) keep |= 1u << k;
+            }
+            const int cnt = __popc(keep);
+            const int inc = wave_incl_scan(cnt);
+            int o = run + inc - cnt;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (keep & (1u << k)) {
+                    const int x = sample_of(v, k);
+                    crow[o] = (int16_t)x;
+                    lcomp[o] = (int16_t)x;
+                    isum += x;
+                    o++;
+                }
+            }
+            run += bcast_from(inc, 63);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = vn[k];
+    }
+    const int n = run;
+    sk_prep pr;
+    pr.n = n; pr.flags = 0; pr.center = 0.0; pr.scale = 1.0; pr.top = 0.0; pr.bot = 0.0;
+    if (n == 0) {
+        pr.flags = SK_FLAG_EMPTY;
+        const double qnan = __builtin_nan("");
+        pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
+        if (lane == 0) prep[r] = pr;
+        return pr;
+    }
+    const int S = bcast_from(wave_incl_scan(isum), 63);
+    const double mean = (double)S / (double)n;
+    __builtin_amdgcn_wave_barrier();                        // (the LDS copy is complete: LDS operations of a wave are in order)
+    const double ssq = wave_pairwise_sq(n, lcomp, E.nodes, lane, [&](int x) { const double d = (double)x - mean; return d * d; });
+    const double sd = sqrt(ssq / (double)n);
+    pr.center = mean;
+    pr.scale = (sd == 0.0) ? 1.0 : sd;                      // sklearn _handle_zeros_in_scale
+    if (lane == 0) prep[r] = pr;
+    return pr;
+}
+
 } // namespace

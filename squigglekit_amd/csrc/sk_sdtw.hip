@@ -460,10 +460,12 @@ static int launch_chained(sk_ctx *c, const sk_sdtw_args *a)
 
 // Host side: lay the motif out per lane, pick (L, R), choose one or two passes, launch.
 // (the fused prologue is instantiated for histograms of 1 025 .. 1 280 bins: the default limits 0 / 1 200)
-bool sk_sdtw_fuse_ok(int32_t lo, int32_t hi)
+bool sk_sdtw_fuse_ok(int32_t lo, int32_t hi, int mode, int64_t stride)
 {
+    if (sk_tune("SK_PREP_BLOCK") || sk_tune("SK_DTW_NOFUSE")) return false;
+    if (mode == SK_PREP_ZSCALE) return stride > 0 && stride <= 4096 && hi > lo;
     const int64_t nbins = (int64_t)hi - lo - 1;
-    return nbins > 1024 && nbins <= 1280 && !sk_tune("SK_PREP_BLOCK") && !sk_tune("SK_DTW_NOFUSE");
+    return nbins > 1024 && nbins <= 1280;
 }
 
 // will this call take the screening scheme (sk_sdtwq.hip)?  (the look-back / checkpoint numbers as in sk_launch_sdtw)
@@ -488,11 +490,11 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
         int ck0 = 128, span0 = N + N / 8 + 8;
         if (const char *e = sk_tune("SK_DTW_CK")) { int v = atoi(e); if (v >= 64 && v % 64 == 0) ck0 = v; }
         if (const char *e = sk_tune("SK_DTW_SPAN")) { int v = atoi(e); if (v > 0) span0 = v; }
-        if (!screens(a, span0, ck0) || !sk_sdtw_fuse_ok(a->fuse->lo, a->fuse->hi)) {
+        if (!screens(a, span0, ck0) || !sk_sdtw_fuse_ok(a->fuse->lo, a->fuse->hi, a->fuse->mode, a->stride)) {
             // no screening pass to carry the prologue: filter + statistics as their own kernel, now
             SK_HIP(hipEventRecord(c->ev[0], c->stream));
             int rc0 = sk_launch_prep_i16(c, a->fuse->raw, a->stride, a->fuse->len, a->nreads, a->fuse->lo, a->fuse->hi,
-                                         SK_PREP_MEDMAD, 0.0, (int16_t *)a->samples, (sk_prep *)a->prep, nullptr, 0);
+                                         a->fuse->mode, 0.0, (int16_t *)a->samples, (sk_prep *)a->prep, nullptr, 0);
             if (rc0) return rc0;
             SK_HIP(hipEventRecord(c->ev[1], c->stream));
             a_unfused = *a;

@@ -93,6 +93,7 @@ struct sdtw_kargs {
     const int16_t *fz_raw;      // raw rows (same stride), or nullptr: prep / samples were filled by an earlier kernel
     const int32_t *fz_len;
     int            fz_lo, fz_hi, fz_vec;
+    int            fz_mode;     // 0: medmad (histogram median + MAD), 1: zscale (numpy-order mean / std; rows <= 4 096 samples)
     int            lds_wave_words; // pass Q: words of dynamic LDS per wavefront (the prologue's histogram, then the interval's last-row values)
     int32_t       *early;       // reads pass Q already knows cannot be screened (candidate range too wide, samples out of
     int32_t       *early_cnt;   // range): their exact retry starts right behind pass Q, beside the window passes

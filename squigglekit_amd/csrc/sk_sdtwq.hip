@@ -180,6 +180,8 @@ void k_sdtw_q(const sdtw_kargs a)
     // per wave: lds_wave_words words of dynamic LDS -- the prologue's value histogram, then (the prologue is over by then)
     // the last-row values of the checkpoint interval in progress, ck words per read group
     extern __shared__ __align__(16) unsigned char lds_dyn[];
+    __shared__ __align__(16) unsigned lds_all[4][5 * 64];   // per wave: the sample ring + dump rows of its read groups (the sweep);
+                                                            // before that, 128 doubles of the zscale prologue's pairwise tree
     int n;
     double center = 0.0, scale = 1.0;
     const int16_t *s16 = nullptr;
@@ -190,16 +192,28 @@ void k_sdtw_q(const sdtw_kargs a)
             // (sk_prepw_dev.h: compacted samples -> a.samples, statistics -> a.prep, both also read by the later
             // passes).  Latency-bound work that the sweeps of the SIMD's other waves hide; as a kernel of its own it
             // cost 4 ms per 1 M reads.
-            const int nb4 = ((a.fz_hi - a.fz_lo - 1) + 3) & ~3;
-            const prepw_env E = prepw_setup<5>((unsigned *)lds_dyn + (size_t)(threadIdx.x >> 6) * a.lds_wave_words, lane,
-                                               a.fz_lo, a.fz_hi, a.fz_vec);
-            (void)nb4;
+            unsigned *wlds = (unsigned *)lds_dyn + (size_t)(threadIdx.x >> 6) * a.lds_wave_words;
             n = 0;
-            for (int gg = 0; gg < G; gg++) {
-                if (wave * G + gg >= a.nreads) break;           // (wave-uniform)
-                const sk_prep pr = prepw_read<5>(E, a.fz_raw, a.stride, a.fz_len, a.read0 + wave * G + gg, lane,
-                                                 (int16_t *)a.samples, (sk_prep *)a.prep);
-                if (g == gg) { n = pr.n; center = pr.center; scale = pr.scale; }
+            if (a.fz_mode == 0) {
+                const prepw_env E = prepw_setup<5>(wlds, lane, a.fz_lo, a.fz_hi, a.fz_vec);
+                for (int gg = 0; gg < G; gg++) {
+                    if (wave * G + gg >= a.nreads) break;       // (wave-uniform)
+                    const sk_prep pr = prepw_read<5>(E, a.fz_raw, a.stride, a.fz_len, a.read0 + wave * G + gg, lane,
+                                                     (int16_t *)a.samples, (sk_prep *)a.prep);
+                    if (g == gg) { n = pr.n; center = pr.center; scale = pr.scale; }
+                }
+            } else {
+                // zscale (round 5): numpy-order mean / std by this wave, the compacted read in its share of the dynamic
+                // LDS, the pairwise tree's partial sums in the (not yet used) static sample ring
+                const zs_env E = zs_setup((int16_t *)wlds, (double *)lds_all[threadIdx.x >> 6], a.fz_lo, a.fz_hi, a.fz_vec);
+#pragma unroll 1
+                for (int gg = 0; gg < G; gg++) {
+                    if (wave * G + gg >= a.nreads) break;
+                    const sk_prep pr = zs_read(E, a.fz_raw, a.stride, a.fz_len, a.read0 + wave * G + gg, lane,
+                                               (int16_t *)a.samples, (sk_prep *)a.prep);
+                    if (g == gg) { n = pr.n; center = pr.center; scale = pr.scale; }
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
             // the sweep below reads what other lanes of this wave just stored
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -299,7 +313,6 @@ void k_sdtw_q(const sdtw_kargs a)
     // chain on the vector ALU, which is the bottleneck), and the last-row values lane L-1 produces.
     //   ybuf[0,L) even blocks | ybuf[L,2L) odd blocks | ybuf[2L,3L) copy of [0,L)
     // so that sample t0 + q - l of an even block is ybuf[2L + q - l] and of an odd one ybuf[L + q - l].
-    __shared__ unsigned lds_all[4][5 * 64];
     unsigned *ybuf = lds_all[threadIdx.x >> 6] + g * 5 * L;
     unsigned *dump = ybuf + 3 * L;                  // 2 L words: where the lanes that do not hold the last row write
     // The last row is kept per CHECKPOINT INTERVAL in LDS and goes to memory only when the interval can hold a candidate
@@ -1070,7 +1083,10 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
     // filter + medmad fused into pass Q (the caller checked the limits: sk_sdtw_fuse_ok)
     size_t fz_lds = 0;
     const sk_prep_fuse fz = a->fuse ? *a->fuse : sk_prep_fuse();
-    if (a->fuse && (((fz.hi - fz.lo - 1) + 3) & ~3) > k.lds_wave_words) k.lds_wave_words = ((fz.hi - fz.lo - 1) + 3) & ~3;   // (or the prologue's histogram)
+    if (a->fuse) {                                      // (or the prologue's histogram / its LDS copy of the compacted read)
+        const int need = fz.mode == SK_PREP_ZSCALE ? (int)((a->stride * 2 + 15) / 16 * 4) : (((fz.hi - fz.lo - 1) + 3) & ~3);
+        if (need > k.lds_wave_words) k.lds_wave_words = need;
+    }
     fz_lds = (size_t)4 * (size_t)k.lds_wave_words * sizeof(unsigned);
 
     const size_t nchunks = (size_t)((a->nreads + chunk - 1) / chunk);
@@ -1087,6 +1103,7 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
         const int grid = (k.nreads + reads_per_block - 1) / reads_per_block;
         if (a->fuse) {
             k.fz_raw = fz.raw; k.fz_len = fz.len; k.fz_lo = fz.lo; k.fz_hi = fz.hi;
+            k.fz_mode = fz.mode == SK_PREP_ZSCALE ? 1 : 0;
             k.fz_vec = ((((uintptr_t)fz.raw & 15) == 0 && (a->stride % 8) == 0) ? 1 : 0) |
                        ((((uintptr_t)a->samples & 15) == 0 && (a->stride % 8) == 0) ? 2 : 0);
         }

@@ -2,6 +2,8 @@
 a multiple of 8 samples (scalar loads, 2-byte stores), reads without a single outlier (every
 wavefront takes the packed all-survive path, 16-byte stores), and outliers placed on the tile /
 wavefront / vector boundaries so that each store alignment (16, 4, 2 bytes) is exercised."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -141,3 +143,37 @@ def test_pipelined_ingest_sub_batches_and_pinned_buffers(gpu, ora, monkeypatch):
     want = ora.motifseq_batch_i16(sig[8990:], lens[8990:], motif)
     assert np.array_equal(got["dist"][8990:], want["dist"]) and np.array_equal(got["start"][8990:], want["start"])
     del pin
+
+
+@pytest.mark.parametrize("stride", [4096, 4000, 3001])
+def test_fused_zscale_prologue_numpy_order(gpu, ora, monkeypatch, stride):
+    """`-l zscale` on reads of up to 4 096 samples: mean / std are computed by the screening pass's own wavefront (round 5;
+    csrc/sk_prepw_dev.h zs_read: numpy's pairwise tree walked per lane) instead of by the workgroup kernel.  Lengths
+    around every split of np.add.reduce's tree (< 8: serial; <= 128: one leaf; 129 .. 143: the 64 + rest split; powers
+    of two; the full row), reads with and without dropped samples, an aligned and two unaligned strides (3001: the
+    element-by-element loads) -- records equal to the unfused path byte for byte, and to the oracle."""
+    from squigglekit_amd import api, synth
+    motif = synth.synthetic_motif(40, seed=8)
+    R = 700
+    sig = synth.squiggle_batch(R, stride, 60606 + stride, motif=motif)
+    rng = np.random.default_rng(stride)
+    lens = rng.integers(200, stride + 1, R).astype(np.int32)
+    corner = [0, 1, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 128, 129, 130, 136, 137, 143, 144, 145, 255, 256, 257, 511, 512,
+              1023, 1024, 1025, 2047, 2048, 2049, stride - 1, stride]
+    lens[:len(corner)] = [min(c, stride) for c in corner]
+    sig[40:80] = np.clip(sig[40:80], 1, 1199)                       # nothing dropped: the all-kept fast path throughout
+    sig[80:90, ::3] = 0                                              # a third of the samples dropped
+    sig[90] = 500                                                    # std = 0 -> scale 1
+    got = api.motifseq_batch(sig, lens, motif, scale="zscale")
+    launches = C.c_int32()
+    gpu.load().sk_last_dtw_profile(None, C.byref(launches), None, None, None)
+    assert launches.value >= 1, "the batch did not take the screening scheme"
+    monkeypatch.setenv("SK_DTW_NOFUSE", "1")
+    plain = api.motifseq_batch(sig, lens, motif, scale="zscale")
+    monkeypatch.delenv("SK_DTW_NOFUSE")
+    assert got.tobytes() == plain.tobytes()
+    want = ora.motifseq_batch_i16(sig, lens, motif, scale_mode=1)
+    ok = got["n"] > 0
+    assert np.array_equal(got["n"], want["n"])
+    assert np.array_equal(got["dist"][ok], want["dist"][ok]) and np.array_equal(got["start"][ok], want["start"][ok]) \
+        and np.array_equal(got["end"][ok], want["end"][ok])
