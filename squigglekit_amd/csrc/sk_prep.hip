@@ -625,6 +625,193 @@ void k_prep_i16(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
 
 
 // ------------------------------------------------------------------------------------------
+// dRNA_segmenter.py, slow5 branch (:85-176): statistics window + one-sided band, ONE look at the read (round 5)
+// ------------------------------------------------------------------------------------------
+// The branch takes median and std from the filtered samples [t_start, t_end) = [1 000, 5 000) and then tests `a < top`
+// over the whole read (:109-114).  k_prep_i16<WINDOWED> does that as the general kernel does everything: compact the
+// read to memory, statistics, then read the compacted samples back for the band test -- 6 bytes of traffic per sample
+// for 2 bytes of input (10.2 ms per 250 000 reads of 17 300 samples, 0.10 of HBM).  But the statistics are complete as
+// soon as t_end samples have survived the filter: this kernel collects those in LDS (they are needed there for numpy's
+// summation order anyway), computes top, classifies what it has collected from LDS and every later tile straight from
+// the registers it was loaded into.  The band bits are compacted into an LDS bit row (one atomic OR per thread and tile)
+// and leave as the transposed words the scan reads.  Nothing is written but the mask and the 48-byte record.
+// LDS: Scratch | hist[nb4] | lbits[ceil(stride / 64) * 2] | lcomp[t_end + 8 TPB] int16.
+__global__ __launch_bounds__(TPB, 5)
+void k_drna_stats(const int16_t *__restrict__ sig, int64_t stride, const int32_t *__restrict__ len, int nreads,
+                  int lo, int hi, double std_scale, int vec_ok, int t0, int t1, int lbits_words,
+                  sk_prep *__restrict__ prep, uint64_t *__restrict__ maskT, int64_t mask_rows)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    Scratch *sc = (Scratch *)lds_raw;
+    unsigned *hist = (unsigned *)(lds_raw + sizeof(Scratch));
+    const int nbins = max(0, hi - lo - 1);
+    const int nb4 = (nbins + 3) & ~3;
+    unsigned *lbits = hist + nb4;                           // the read's band bits, filtered coordinates
+    int16_t *lcomp = (int16_t *)(lbits + lbits_words);      // the first t1 (+ one tile) filtered samples
+    unsigned *hist_v = hist - (lo + 1);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool in_vec = (vec_ok & 1) != 0;
+    const int lo1 = max(lo + 1, -32768), hi1 = min(hi - 1, 32767);
+    const bool range_ok = lo1 <= hi1;
+    const unsigned lo2 = (unsigned)(lo1 & 0xffff) * 0x10001u, hi2 = (unsigned)(hi1 & 0xffff) * 0x10001u;
+    auto load8 = [&](const int16_t *row, int M, int i0, unsigned (&q)[4]) {
+        if (in_vec && i0 + 8 <= M) {
+            const uint4 t = *(const uint4 *)(row + i0);
+            q[0] = t.x; q[1] = t.y; q[2] = t.z; q[3] = t.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned a = (i0 + 2 * k < M) ? (unsigned short)row[i0 + 2 * k] : 0u;
+                const unsigned b = (i0 + 2 * k + 1 < M) ? (unsigned short)row[i0 + 2 * k + 1] : 0u;
+                q[k] = a | (b << 16);
+            }
+        }
+    };
+    auto sample = [](const unsigned (&q)[4], int k) -> int {
+        return (k & 1) ? (int)q[k >> 1] >> 16 : (int)(short)(q[k >> 1] & 0xffffu);
+    };
+    if (tid == 0) sc->tree_m = -1;
+    for (int b = tid; b < nb4; b += TPB) hist[b] = 0u;
+    const int maxM = (int)min(stride, (int64_t)0x7fffff00);
+
+    for (int r = blockIdx.x; r < nreads; r += gridDim.x) {
+        const int M = min(max(len[r], 0), maxM);
+        const int16_t *row = sig + (int64_t)r * stride;
+        for (int i = tid; i < lbits_words; i += TPB) lbits[i] = 0u;
+        if (tid < 4) sc->sel[tid] = 0;
+        lds_barrier();
+
+        sk_prep pr;
+        pr.n = 0; pr.flags = 0; pr.center = 0.0; pr.scale = 1.0; pr.top = 0.0; pr.bot = 0.0;
+        int run = 0, parity = 0;
+        bool have = false;                                  // the statistics exist
+        int itop = -32768;                                  // in band <=> x < itop
+        unsigned v[4], vn[4];
+        load8(row, M, tid * 8, v);
+        // statistics + the band bits of everything collected so far (block-uniform call)
+        auto finish_stats = [&](int nsofar) {
+            __syncthreads();                                // histogram + collected samples complete
+            const int w0 = min(nsofar, t0);
+            const int ns = min(nsofar, t1) - w0;
+            const double qnan = __builtin_nan("");
+            if (ns <= 0) {                                  // empty slice: numpy gives NaN, the band is empty
+                pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
+                itop = -32768;
+            } else {
+                long long wsum;
+                unsigned cnt[8];
+                rank_select2_regs<2>(hist, nb4, (ns - 1) / 2, ns / 2, sc, 0, true, &wsum, cnt);
+                const long long S = wsum + (long long)ns * (lo + 1);
+                const int hb0 = tid * 8;
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    if (hb0 + 4 * j < nb4) *(uint4 *)(hist + hb0 + 4 * j) = make_uint4(0u, 0u, 0u, 0u);
+                const int med2 = (sc->sel[0] + lo + 1) + (sc->sel[1] + lo + 1);
+                const double median = (double)med2 * 0.5;
+                const double mean = (double)S / (double)ns;
+                const double ssq = numpy_sum<false>(ns, sc, [&](int i) {
+                    const double d = (double)lcomp[w0 + i] - mean;
+                    return d * d;
+                });
+                if (tid == 0) {
+                    const double sd = sqrt(ssq / (double)ns);
+                    const double top = median + sd * std_scale;          // dRNA_segmenter.py:111
+                    sc->bcast[0] = median; sc->bcast[1] = sd;
+                    const double ct = ceil(top);
+                    sc->sel[2] = (top == top) ? (ct > 32768.0 ? 32768 : (ct < -32768.0 ? -32768 : (int)ct)) : -32768;
+                }
+                lds_barrier();
+                itop = sc->sel[2];
+                const double median_b = sc->bcast[0], sd_b = sc->bcast[1];
+                pr.center = median_b; pr.scale = sd_b; pr.top = median_b + sd_b * std_scale; pr.bot = -__builtin_huge_val();
+            }
+            // the samples collected so far, from LDS: 64 consecutive ones per wavefront and ballot
+            for (int base = 0; base < nsofar; base += TPB) {
+                const int i = base + tid;
+                const bool in = i < nsofar && (int)lcomp[i] < itop;
+                const unsigned long long bits = __ballot(in);
+                if (lane == 0) { lbits[2 * (i >> 6)] = (unsigned)bits; lbits[2 * (i >> 6) + 1] = (unsigned)(bits >> 32); }
+            }
+            have = true;
+        };
+        for (int base = 0; base < M; base += TPB * 8, parity ^= 1) {
+            const int i0 = base + tid * 8;
+            if (base + TPB * 8 < M) load8(row, M, i0 + TPB * 8, vn);
+            unsigned changed = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) changed |= clamp_pk_i16(v[k], lo2, hi2) ^ v[k];
+            const bool wave_all = __all(range_ok && i0 + 8 <= M && changed == 0u);
+            unsigned keep = 0xffu;
+            int cnt = 8, inc = 8 * (lane + 1);
+            if (!wave_all) {
+                keep = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int x = sample(v, k);
+                    if (i0 + k < M && x > lo && x < hi) keep |= 1u << k;
+                }
+                cnt = __popc(keep);
+                inc = wave_incl_scan(cnt, lane);
+            }
+            if (lane == 63) sc->wsum[parity][w] = inc;
+            lds_barrier();
+            int wbase = 0, tot = 0;
+#pragma unroll
+            for (int i = 0; i < NWAVE; i++) {
+                const int s2 = sc->wsum[parity][i];
+                if (i < w) wbase += s2;
+                tot += s2;
+            }
+            int o = run + wbase + inc - cnt;
+            if (!have) {                                    // collecting: samples to LDS, window samples into the histogram
+                int oo = o;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (keep & (1u << k)) {
+                        const int x = sample(v, k);
+                        lcomp[oo] = (int16_t)x;
+                        if (oo >= t0 && oo < t1) atomicAdd(&hist_v[x], 1u);
+                        oo++;
+                    }
+                }
+                run += tot;
+                if (run >= t1 || base + TPB * 8 >= M) finish_stats(run);     // (block-uniform)
+            } else {                                        // classifying: this tile's kept samples, straight from registers
+                unsigned bits = 0;
+                int nb = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (keep & (1u << k)) {
+                        bits |= ((sample(v, k) < itop) ? 1u : 0u) << nb;
+                        nb++;
+                    }
+                }
+                if (bits) {
+                    const int sh = o & 31;
+                    atomicOr(&lbits[o >> 5], bits << sh);
+                    if (sh + nb > 32) atomicOr(&lbits[(o >> 5) + 1], bits >> (32 - sh));
+                }
+                run += tot;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = vn[k];
+        }
+        const int n = run;
+        pr.n = n;
+        if (n == 0) {
+            pr.flags = SK_FLAG_EMPTY;
+            const double qnan = __builtin_nan("");
+            pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
+        }
+        lds_barrier();                                      // every OR into the bit row has landed
+        if (tid == 0) prep[r] = pr;
+        for (int wi = tid; wi * 64 < n; wi += TPB)
+            maskT[(int64_t)wi * mask_rows + r] = (unsigned long long)lbits[2 * wi] | ((unsigned long long)lbits[2 * wi + 1] << 32);
+        lds_barrier();                                      // LDS is reused by the next read
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // float64 reads (pA TSVs, segmenter.py:198-199 / MotifSeq.py:270; fast5 input converted to pA)
 // ------------------------------------------------------------------------------------------
 // Values are arbitrary doubles, so the median is found by an MSD radix select over the
@@ -1048,6 +1235,23 @@ int sk_launch_prep_i16(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
     }
     const int64_t nbins = (int64_t)hi - (int64_t)lo - 1 > 0 ? (int64_t)hi - lo - 1 : 0;
     const int64_t nb4 = (nbins + 3) & ~(int64_t)3;
+    if (mode == SK_PREP_DRNA && !listed && d_mask != nullptr && nbins >= 1 && nbins <= 2048 && t0 >= 0 && t1 > t0 &&
+        t1 <= 16384 && stride < (1 << 19) && sk_tune("SK_DRNA_STEP") == nullptr && sk_tune("SK_PREP_BLOCK") == nullptr) {
+        // one look at the read: the statistics window collected in LDS, every later tile classified from registers
+        const int lbits_words = (int)(((stride + 63) / 64) * 2 + 2);
+        const size_t dl = sizeof(Scratch) + (size_t)nb4 * 4 + (size_t)lbits_words * 4 + (size_t)(t1 + 8 * TPB + 8) * sizeof(int16_t);
+        if (dl <= 60 * 1024) {
+            const int vec_ok1 = (((uintptr_t)d_sig & 15) == 0 && (stride % 8) == 0) ? 1 : 0;
+            int per_cu = (int)((160 * 1024) / (dl + 512));
+            if (per_cu > 5) per_cu = 5;
+            long long g = (long long)c->num_cu * per_cu * 4;
+            const int grid = g > nreads ? nreads : (int)g;
+            hipLaunchKernelGGL(k_drna_stats, dim3(grid), dim3(TPB), dl, c->stream, d_sig, stride, d_len, nreads, lo, hi,
+                               std_scale, vec_ok1, t0, t1, lbits_words, d_prep, d_mask, mask_stride);
+            SK_HIP(hipGetLastError());
+            return SK_OK;
+        }
+    }
     size_t lds = sizeof(Scratch) + (size_t)nb4 * 4;
     if (lds > 160 * 1024)
         return sk_fail(SK_ERR_UNSUPPORTED,

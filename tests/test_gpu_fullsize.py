@@ -26,7 +26,12 @@ def test_c3_motifseq_full_size_properties(gpu, ora, example_model):
     sub = rng.choice(R, 200, replace=False)
     small = api.motifseq_batch(sig[sub], lens[:200], example_model)
     assert np.array_equal(small, hits[sub])
-    # oracle on the subset: bit-identical
+    # oracle on a tenth of the batch: bit-identical
+    from conftest import oracle_motifseq_threaded
+    big = rng.choice(R, 1000, replace=False)
+    wbig = oracle_motifseq_threaded(ora, sig[big], lens[:1000], example_model)
+    for f in ("dist", "start", "end", "n"):
+        assert np.array_equal(hits[f][big], wbig[f]), f
     want = ora.motifseq_batch_i16(sig[sub], lens[:200], example_model)
     assert np.array_equal(hits["start"][sub], want["start"]) and np.array_equal(hits["end"][sub], want["end"])
     assert np.array_equal(hits["dist"][sub], want["dist"])
@@ -58,8 +63,8 @@ def test_c2_segmenter_full_size_properties(gpu, ora):
     perm = rng.permutation(R)
     segs_p, nsegs_p = api.segment_batch(sig[perm], lens)
     assert np.array_equal(nsegs_p, nsegs[perm]) and np.array_equal(segs_p, segs[perm])
-    sub = rng.choice(R, 400, replace=False)
-    osegs, onsegs = ora.segment_batch_i16(sig[sub], lens[:400], max_segs=segs.shape[1])
+    sub = rng.choice(R, 2000, replace=False)
+    osegs, onsegs = ora.segment_batch_i16(sig[sub], lens[:2000], max_segs=segs.shape[1])
     assert np.array_equal(onsegs, nsegs[sub])
     for k, r in enumerate(sub):
         assert np.array_equal(osegs[k, :onsegs[k]], segs[r, :nsegs[r]])
@@ -129,7 +134,7 @@ def test_f64_route_full_size_250k_pa_reads(gpu, ora):
         check(L.sk_motifseq_dev_f64(d_f, d_off, R, R * Mf, Mf, ptr(motif), N, 0, 0, 1200, d_h2))
         check(L.sk_sync())
         ns2, segs2, h2 = fetch(d_ns2, R, np.int32), fetch(d_segs2, (R, MAXS, 2), np.int32), fetch(d_h2, R, HIT_DTYPE)
-        rows = strided_rows(R, 384)
+        rows = strided_rows(R, 1024)
         pa = download_rows(L, d_f, Mf * 8, rows, np.float64, Mf)
         op = ora.SegParams(sp.error, sp.corrector, sp.window, sp.seg_dist, sp.std_scale, sp.stall_len)
 

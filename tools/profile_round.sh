@@ -57,8 +57,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_other" -- \
         python "$R/bench.py" --only-other-paths --steps 1 --warmup 0 --cpu-seconds 0 > "$OUT/pmc_${C}_other.log" 2>&1
 done
-python "$R/tools/pmc_traffic.py" 250000 1 "$OUT/pmc_FETCH_SIZE_other" "$OUT/pmc_WRITE_SIZE_other" \
-    "bench.py --only-other-paths --steps 1 --warmup 0 ($TAG; per-launch bytes: the float64 kernels run on 250 000 reads x 3 999 samples and 50 000 x 19 999, 4 launches each)" > "$OUT/traffic_other_paths.json"
+python "$R/tools/pmc_traffic.py" 500000 1 "$OUT/pmc_FETCH_SIZE_other" "$OUT/pmc_WRITE_SIZE_other" \
+    "bench.py --only-other-paths --steps 1 --warmup 0 ($TAG; per-launch bytes; the float64 kernels run on 500 000 reads x 3 999 samples, 50 000 x 19 999 and 25 000 x 36 977, the dRNA ones on 250 000 reads, 4 launches each)" > "$OUT/traffic_other_paths.json"
 rm -rf "$OUT/kt_other" "$OUT/pmc_FETCH_SIZE_other" "$OUT/pmc_WRITE_SIZE_other"
 python "$R/tools/cli_throughput.py" 200000 1000000 > "$OUT/cli_throughput.txt" 2>&1
 (cd "$R" && python tools/parity_at_scale.py 400000 128 && python tools/parity_at_scale.py segmenter 1000000 128) > "$OUT/parity_at_scale.txt" 2>&1
