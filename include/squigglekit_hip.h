@@ -203,6 +203,12 @@ int sk_motifseq_multi_batch_i16(const int16_t *sig, int64_t stride, const int32_
 int sk_motifseq_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
                           const double *motif, int32_t nmotif, int32_t scale_mode,
                           int32_t scale_low, int32_t scale_hi, sk_hit *out);
+/* Several motifs against the same ragged float64 batch -- the `for name in m_order` loop of MotifSeq.py:436 on pA
+ * input: the batch is staged and filtered once, one DTW launch set per motif.  motif k = motifs[motif_off[k] ..
+ * motif_off[k+1]); out is [nmotifs][nreads]. */
+int sk_motifseq_multi_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
+                                const double *motifs, const int32_t *motif_off, int32_t nmotifs,
+                                int32_t scale_mode, int32_t scale_low, int32_t scale_hi, sk_hit *out);
 /* device-resident form (d_sig, d_len, d_out device; motif host). */
 int sk_motifseq_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
                         const double *motif, int32_t nmotif, int32_t scale_mode,

@@ -124,6 +124,7 @@ ABI = {
                                               C.c_int32, C.c_int32, _vp]),
     "sk_motifseq_batch_f64": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, _vp]),
+    "sk_motifseq_multi_batch_f64": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "sk_motifseq_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, _vp]),
     "sk_motifseq_multi_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,

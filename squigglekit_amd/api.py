@@ -289,15 +289,19 @@ def motifseq_multi_ragged_f64(values, off, motifs, scale="medmad", scale_low=0, 
     R = off.size - 1
     ms = [np.ascontiguousarray(m, dtype=np.float64) for m in motifs]
     out = [np.zeros(max(R, 1), dtype=HIT_DTYPE) for _ in ms]
+    flat = np.ascontiguousarray(np.concatenate(ms)) if ms else np.zeros(0)
+    moff = np.concatenate([[0], np.cumsum([m.size for m in ms])]).astype(np.int32)
 
     def call(lo, hi):
-        for m, hits in zip(ms, out):
-            rc = L.sk_motifseq_batch_f64(ptr(values), ptr(off[lo:hi + 1]), hi - lo, ptr(m), m.size, _lib.SK_SCALE[scale],
-                                         int(scale_low), int(scale_hi), ptr(hits[lo:hi]))
-            if rc:
-                return rc
-        return 0
-    if R:
+        # the shard is staged and filtered ONCE, every motif runs against it on the device (sk_motifseq_multi_batch_f64)
+        part = np.zeros((len(ms), hi - lo), dtype=HIT_DTYPE)
+        rc = L.sk_motifseq_multi_batch_f64(ptr(values), ptr(off[lo:hi + 1]), hi - lo, ptr(flat), ptr(moff), len(ms),
+                                           _lib.SK_SCALE[scale], int(scale_low), int(scale_hi), ptr(part))
+        if rc == 0:
+            for k, hits in enumerate(out):
+                hits[lo:hi] = part[k]
+        return rc
+    if R and ms:
         _over_devices(devices, R, call)
     return [h[:R] for h in out]
 

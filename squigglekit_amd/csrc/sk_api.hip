@@ -422,10 +422,12 @@ static int stage_ragged_f64(sk_ctx *c, const double *sig, const int64_t *off, in
     return SK_OK;
 }
 
-// device-resident core of the float64 MotifSeq path: d_sig / d_off (zero based, nreads + 1) are device pointers
-static int motifseq_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t total,
-                            int64_t maxlen, const double *motif, int32_t nmotif, int32_t scale_mode,
-                            int32_t scale_low, int32_t scale_hi, sk_hit *d_out)
+// device-resident core of the float64 MotifSeq path: d_sig / d_off (zero based, nreads + 1) are device pointers.
+// Filter + statistics once, then one DTW launch set per motif (nmotifs >= 1; motif k = motifs + motif_off[k], its records
+// go to d_out + k * out_stride).
+static int motifseq_multi_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t total,
+                                  int64_t maxlen, const double *motifs, const int32_t *motif_off, int32_t nmotifs,
+                                  int32_t scale_mode, int32_t scale_low, int32_t scale_hi, sk_hit *d_out, int64_t out_stride)
 {
     int rc;
     if ((rc = sk_reserve(c, &c->comp, (size_t)(total > 0 ? total : 1) * sizeof(double)))) return rc;
@@ -451,14 +453,27 @@ static int motifseq_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off
     }
     if (rc) return rc;
     SK_HIP(hipEventRecord(c->ev[1], c->stream));
-    sk_sdtw_args a;
-    a.feed = SK_FEED_F64_NORM; a.samples = c->comp.p; a.stride = 0; a.off = d_off;
-    a.samples_raw = d_sig;                              // (reads the filter left whole are not copied: SK_IFLAG_INPLACE)
-    a.prep = (const sk_prep *)c->prep.p; a.nreads = nreads; a.motif = motif; a.nmotif = nmotif;
-    a.out = d_out; a.last_row = nullptr; a.max_len = maxlen; a.force_single = 0;
-    if ((rc = sk_launch_sdtw(c, &a))) return rc;
+    for (int32_t k = 0; k < nmotifs; k++) {
+        sk_sdtw_args a;
+        a.feed = SK_FEED_F64_NORM; a.samples = c->comp.p; a.stride = 0; a.off = d_off;
+        a.samples_raw = d_sig;                          // (reads the filter left whole are not copied: SK_IFLAG_INPLACE)
+        a.prep = (const sk_prep *)c->prep.p; a.nreads = nreads; a.motif = motifs + motif_off[k];
+        a.nmotif = motif_off[k + 1] - motif_off[k];
+        a.out = d_out + (size_t)k * (size_t)out_stride; a.last_row = nullptr; a.max_len = maxlen; a.force_single = 0;
+        a.accumulate = k > 0 ? 1 : 0;
+        if ((rc = sk_launch_sdtw(c, &a))) return rc;
+    }
     c->ev_valid = true;
     return SK_OK;
+}
+
+static int motifseq_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int32_t nreads, int64_t total,
+                            int64_t maxlen, const double *motif, int32_t nmotif, int32_t scale_mode,
+                            int32_t scale_low, int32_t scale_hi, sk_hit *d_out)
+{
+    const int32_t moff[2] = {0, nmotif};
+    return motifseq_multi_dev_f64(c, d_sig, d_off, nreads, total, maxlen, motif, moff, 1, scale_mode, scale_low, scale_hi,
+                                  d_out, nreads);
 }
 
 int sk_motifseq_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
@@ -481,6 +496,31 @@ int sk_motifseq_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
                           scale_mode, scale_low, scale_hi, (sk_hit *)c->out.p);
     if (rc) return rc;
     SK_HIP(hipMemcpyAsync(out, c->out.p, (size_t)nreads * sizeof(sk_hit), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = finish_dtw_host(c))) return rc;
+    return SK_OK;
+}
+
+// Several motifs against the same ragged float64 batch (the `for name in m_order` loop of MotifSeq.py:436 on pA input):
+// the batch is staged once, filter + statistics run once, one DTW launch set per motif.  out is [nmotifs][nreads].
+int sk_motifseq_multi_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
+                                const double *motifs, const int32_t *motif_off, int32_t nmotifs,
+                                int32_t scale_mode, int32_t scale_low, int32_t scale_hi, sk_hit *out)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    if (nreads < 0) return sk_fail(SK_ERR_INVALID, "nreads < 0");
+    int rc = check_multi(motifs, motif_off, nmotifs, scale_mode);
+    if (rc) return rc;
+    if (nreads == 0) return SK_OK;
+    if (!out) return sk_fail(SK_ERR_INVALID, "NULL out");
+    int64_t total, maxlen;
+    if ((rc = stage_ragged_f64(c, sig, off, nreads, &total, &maxlen))) return rc;
+    const size_t ob = (size_t)nreads * (size_t)nmotifs * sizeof(sk_hit);
+    if ((rc = sk_reserve(c, &c->out, ob))) return rc;
+    rc = motifseq_multi_dev_f64(c, (const double *)c->sig.p, (const int64_t *)c->off.p, nreads, total, maxlen, motifs,
+                                motif_off, nmotifs, scale_mode, scale_low, scale_hi, (sk_hit *)c->out.p, nreads);
+    if (rc) return rc;
+    SK_HIP(hipMemcpyAsync(out, c->out.p, ob, hipMemcpyDeviceToHost, c->stream));
     if ((rc = finish_dtw_host(c))) return rc;
     return SK_OK;
 }

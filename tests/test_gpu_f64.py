@@ -440,3 +440,22 @@ def test_segment_ragged_f64_with_per_read_cuts(gpu, ora):
     bad = np.array([5, 99999], dtype=np.int32)
     with pytest.raises(Exception):
         api.segment_ragged_f64(np.zeros(10), np.array([0, 4, 10], dtype=np.int64), bad)
+
+
+def test_multi_motif_ragged_f64_equals_one_call_per_motif(gpu, example_model):
+    """sk_motifseq_multi_batch_f64 (the `for name in m_order` loop of MotifSeq.py:436 on pA input: the batch staged and
+    filtered once, every motif against it on the device) == one sk_motifseq_batch_f64 call per motif, medmad and zscale,
+    with reads the filter drops samples of, an empty read and enough reads for the screening scheme."""
+    from squigglekit_amd import api
+    rng = np.random.default_rng(5)
+    reads = _pa_reads(330, 3000, 21)
+    reads[3] = np.zeros(0)
+    reads[4][::7] = 1500.0                                   # dropped by the limits
+    flat = np.concatenate(reads)
+    off = np.concatenate([[0], np.cumsum([r.size for r in reads])]).astype(np.int64)
+    motifs = [example_model, example_model[10:90], rng.normal(0.0, 1.0, 33)]
+    for scale in ("medmad", "zscale"):
+        got = api.motifseq_multi_ragged_f64(flat, off, motifs, scale=scale)
+        for k, m in enumerate(motifs):
+            want = api.motifseq_reads_f64(reads, m, scale=scale)
+            assert got[k].tobytes() == want.tobytes(), (scale, k)
