@@ -453,7 +453,8 @@ def motifseq_batch(sig, lens, motif, scale="medmad", scale_low=0, scale_hi=1200,
     return out
 
 
-GUARD_FIELDS = ("premise_violations", "audited", "audit_mismatches", "image_rejects", "alarm", "exact_fallback")
+GUARD_FIELDS = ("premise_violations", "audited", "audit_mismatches", "image_rejects", "alarm", "exact_fallback",
+                "second_windows")
 
 
 def last_dtw_guard():

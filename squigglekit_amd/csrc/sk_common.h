@@ -45,6 +45,8 @@ struct sk_ctx {
     hipEvent_t  ev_r[2] = {nullptr, nullptr};   // its ordering events: pass Q done / early retry done
     hipStream_t stream4 = nullptr;    // fourth stream (created on first use): the audit's exact sweep beside the window passes
     hipEvent_t  ev_a = nullptr;       // audit sweep done
+    hipEvent_t  ev_s[2] = {nullptr, nullptr};   // second clusters (siblings) on the third stream: pass Q done / their round done
+    uint32_t    dtw_sparse_calls = 0; // calls whose audit would be exposed (few, long reads): every K-th is audited
     hipEvent_t  ev_chunk[9] = {};     // ordering events between the two streams (no timing)
     hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};   // prep start/stop, main start/stop
     bool        ev_valid = false;
@@ -82,6 +84,9 @@ struct sk_ctx {
     sk_buf retry;     // DTW retry list: [0] = count, [1] = pad, [2 ..] = reads (segmenter: [0] = count, [1 ..] = reads)
     sk_buf dtwcnt;    // [0] = reads retried by the exact pass, summed over the launches of one API call (device); [1] second tier; +16 clock; +32 guard counters
     sk_buf audit;     // the audit's read list ([0] = count, [2 ..] = reads) and its exact records
+    sk_buf sib;       // window passes: [0..3] count, then {read, jlo, jhi, -} per second cluster of candidate columns
+    sk_buf sibout;    // ... and pass W's record per sibling
+    sk_buf sibstate;  // ... their own pass-P state and window records (the round runs beside the main window passes)
     bool   retry_dev = false;   // the last DTW call left its retry count on the device (read lazily)
     std::vector<unsigned> motifq_host;
     bool   motifq_valid = false;

@@ -72,6 +72,7 @@ static const sk_tunable SK_TUNABLES[] = {
     {"SK_DTW_NOSORT",         "1",           "window passes take the reads in file order"},
     {"SK_DTW_SORT_MIN",       "1",           "window passes sort chunks of at least this many reads"},
     {"SK_DTW_NO_EARLY",       "1",           "no early exact retry beside the window passes"},
+    {"SK_DTW_NO_SIBLINGS",    "1",           "reads whose candidate columns fall into two clusters take the exact pass (no second window)"},
     {"SK_DTW_NOGUARD",        "1",           "screening scheme without its run-time guard (premise test in the window pass, audit, gated exact fallback): A/B cost runs"},
     {"SK_DTW_AUDIT_PERIOD",   "0 1 64",      "the audit re-runs one read in this many with the exact pass (default 4096; 0: no audit)"},
     {"SK_DTW_HOLE",           "qerr1 fma64 fma64x", "tests: a known precision hole put back (E = 1; the fma sample image for float64 reads, with / without the image-error guard) -- the guard has to notice and the records must not change"},
@@ -194,7 +195,7 @@ int sk_shutdown(void)
         (void)hipStreamSynchronize(c->stream);
         sk_buf *bufs[] = {&c->sig, &c->len, &c->off, &c->comp, &c->prep, &c->mask,
                           &c->motif, &c->out, &c->out2, &c->misc, &c->ckpt, &c->retry, &c->motifq, &c->lastq, &c->qflag,
-                          &c->motif64, &c->commbuf, &c->dtwcnt, &c->wsoft, &c->wstate, &c->wrec, &c->motifw, &c->lsum, &c->wrecq, &c->order, &c->pacal, &c->seghints, &c->audit, &c->rlen};
+                          &c->motif64, &c->commbuf, &c->dtwcnt, &c->wsoft, &c->wstate, &c->wrec, &c->motifw, &c->lsum, &c->wrecq, &c->order, &c->pacal, &c->seghints, &c->audit, &c->rlen, &c->sib, &c->sibout, &c->sibstate};
         for (sk_buf *b : bufs) free_buf(b);
         for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev[i]);
         for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
@@ -211,6 +212,7 @@ int sk_shutdown(void)
         if (c->stream4) {
             (void)hipStreamSynchronize(c->stream4);
             if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+            for (int i = 0; i < 2; i++) if (c->ev_s[i]) (void)hipEventDestroy(c->ev_s[i]);
             (void)hipStreamDestroy(c->stream4);
         }
         (void)hipStreamDestroy(c->stream);

@@ -654,7 +654,24 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
     const bool guarded = qok && sk_tune("SK_DTW_NOGUARD") == nullptr;
     int audit_period = 4096;
     if (const char *e = sk_tune("SK_DTW_AUDIT_PERIOD")) { const int v = atoi(e); if (v >= 0) audit_period = v; }
-    const int naudit = (guarded && audit_period > 0) ? (int)((a->nreads + audit_period - 1) / audit_period) : 0;
+    int naudit = (guarded && audit_period > 0) ? (int)((a->nreads + audit_period - 1) / audit_period) : 0;
+    // The audit costs one exact sweep's LATENCY whatever the number of reads it takes (one wavefront each, side by side):
+    // (maxlen + 64) steps of 8 ceil(N/64) + 20 instructions.  Beside the window passes of a large call that is free;
+    // a call of few, long reads (25 000 of 37 000 samples: 3.4 ms of sweep beside 0.9 ms of windows, in a 20 ms call)
+    // would wait for it.  So where the sweep is expected to outlast the window passes by more than 2 % of the call,
+    // only every K-th such call of this context is audited, K chosen to keep the AVERAGE cost at those 2 %.  The
+    // premise test (a) and the image bound stay on every call; an explicit SK_DTW_AUDIT_PERIOD audits every call.
+    if (naudit && sk_tune("SK_DTW_AUDIT_PERIOD") == nullptr) {
+        const double audit_ms = (double)(maxlen + 64) * (8.0 * ((N + 63) / 64) + 20.0) * 5.0 / 2.4e6;
+        const double window_ms = (double)a->nreads * N * 5.85e-8;
+        const double call_ms = (double)a->nreads * (double)maxlen * N * 7.4e-11;
+        const double exposed = audit_ms - window_ms;
+        if (exposed > 0.02 * call_ms) {
+            double kd = exposed / (0.02 * call_ms + 1e-9);
+            const uint32_t K = kd > 64.0 ? 64u : (uint32_t)kd + 1u;
+            if (c->dtw_sparse_calls++ % K) naudit = 0;
+        }
+    }
     int32_t *alist = nullptr;  sk_hit *aout = nullptr;
     if (naudit) {
         if ((rc = sk_reserve(c, &c->audit, ((size_t)naudit + 2) * sizeof(int32_t) + 16 + (size_t)naudit * sizeof(sk_hit)))) return rc;

@@ -88,7 +88,12 @@ struct sdtw_kargs {
     unsigned      *wstate;      // [slot][L][R+2]: restart state of the window pass (pass P -> pass W)
     void          *wrec;        // [slot] {tbase, jlo, jhi, flags}: pass P -> pass W
     void          *wrec_q;      // [read - read0] {-, jlo, jhi, -}: pass Q's epilogue -> the first tier of pass P
-    int32_t        tier2;       // pass P: look for the candidate columns again (second tier) instead of taking pass Q's
+    int32_t        tier2;       // pass P: 1 = look for the candidate columns again (second tier) instead of taking pass Q's;
+                                // 2 = the launch covers the sibling list (a read's second cluster of candidate columns)
+    void          *sib;         // [chunk] {read, jlo, jhi, -}: second clusters, appended by pass Q's epilogue (nullptr: none)
+    int32_t       *sib_cnt;     //         their number (device; may run past sib_cap: entries beyond it were not stored)
+    int            sib_cap;     //         capacity of the list
+    sk_hit        *sib_out;     // [chunk] pass W's result per sibling slot (n = 1: certified)
     // pass Q with the filter + medmad statistics fused in as a prologue (int16 reads): the wave preps its own reads
     const int16_t *fz_raw;      // raw rows (same stride), or nullptr: prep / samples were filled by an earlier kernel
     const int32_t *fz_len;

@@ -120,14 +120,29 @@ struct wrec {
     int32_t jlo, jhi;   // candidate columns
     int32_t flags;      // 1: screened (a window exists)  2: the state was restored from a checkpoint
 };
+// A read whose candidate columns fall into TWO clusters more than wmax apart (two near-minima far from each other: 0.02 % of
+// 4 000-sample reads, 0.5 % at 37 000 samples) used to take the exact single pass -- a full sweep, whose latency shows when
+// the batch is small and the reads are long (3.4 ms beside 1 ms of window passes at 25 000 x 36 977).  Since round 5 the
+// first cluster goes through the window passes as the read's own [jlo, jhi] and the second one as a SIBLING: a second,
+// short launch of pass P / pass W over the sibling list, whose results a combine kernel merges (the smaller exact distance
+// wins, the lower column on a tie -- np.argmin's first minimum; a sibling that cannot be certified sends the read to the
+// exact pass after all).  Three clusters, or a cluster wider than wmax: exact pass, as before.
+struct sibrec {
+    int32_t r;          // read
+    int32_t jlo, jhi;   // the second cluster's candidate columns
+    int32_t pad;
+};
 
 // Candidate columns of read r: [jlo, jhi] = the first and the last column whose screening cost is within 2E of the
 // screening minimum b (jhi < jlo: none).  Pass Q left, per checkpoint interval c and lane l', the minimum over the
 // last-row columns c * ck + q * L + l' - (L - 1), q = 0 .. ck / L - 1: only intervals whose summary is within the
 // threshold can hold a candidate, so a read costs (nck + 1) * L summary words here instead of its whole last row.
 // Every lane of the read's group calls this with its own l and gets the group's result.
+// (clo, chi: only columns inside [clo, chi] count -- the two clusters of a read whose candidates lie too far apart for one
+// window, round 5)
 template <int L>
-__device__ __forceinline__ void candidate_columns(const sdtw_kargs &a, int r, int n, unsigned b, int l, int &jlo_out, int &jhi_out)
+__device__ __forceinline__ void candidate_columns(const sdtw_kargs &a, int r, int n, unsigned b, int l, int &jlo_out, int &jhi_out,
+                                                  int clo = 0, int chi = 0x7fffffff)
 {
     const unsigned *lastq = a.lastq + (int64_t)(r - a.read0) * a.lq_stride;
     const unsigned *ls = a.lsum + (int64_t)(r - a.read0) * (a.nck + 1) * L + l;
@@ -139,7 +154,7 @@ __device__ __forceinline__ void candidate_columns(const sdtw_kargs &a, int r, in
             const int j0 = cc * a.ck + l - (L - 1);
             for (int q = 0; q < a.ck / L; q++) {
                 const int j = j0 + q * L;
-                if (j >= 0 && j < n && lastq[j + L] <= thr) { jlo = min(jlo, j); jhi = max(jhi, j); }   // (rows start L early)
+                if (j >= clo && j <= chi && j >= 0 && j < n && lastq[j + L] <= thr) { jlo = min(jlo, j); jhi = max(jhi, j); }   // (rows start L early)
             }
         }
     }
@@ -426,9 +441,32 @@ void k_sdtw_q(const sdtw_kargs a)
     if (a.wrec_q) {                                 // epilogue: the candidate columns, for the first tier of pass P
         int jlo, jhi;
         candidate_columns<L>(a, r, n, bq, l, jlo, jhi);
+        // candidates too far apart for one window: two clusters?  (group-uniform: every lane of the group holds jlo / jhi)
+        int sjlo = 0, sjhi = -1;
+        if (a.sib && live && bq < QSAFE && jhi >= jlo && jhi - jlo > a.wmax) {
+            int alo, ahi, blo, bhi;
+            candidate_columns<L>(a, r, n, bq, l, alo, ahi, jlo, jlo + a.wmax);
+            candidate_columns<L>(a, r, n, bq, l, blo, bhi, jlo + a.wmax + 1);
+            if (bhi >= blo && bhi - blo <= a.wmax) {
+                // (lane 0 books the sibling's slot; the list is short -- its launches are sized for it -- and a read
+                // that finds it full stays unscreened)
+                int slot_ok = 0;
+                if (l == 0) {
+                    const int idx = atomicAdd(a.sib_cnt, 1);
+                    if (idx < a.sib_cap) {
+                        sibrec sb;
+                        sb.r = r; sb.jlo = blo; sb.jhi = bhi; sb.pad = 0;
+                        ((sibrec *)a.sib)[idx] = sb;
+                        slot_ok = 1;
+                    }
+                }
+                slot_ok = __shfl(slot_ok, lane - l);
+                if (slot_ok) { jhi = ahi; sjlo = blo; sjhi = bhi; }
+            }
+        }
         if (live && l == 0) {
             wrec w;
-            w.tbase = 0; w.jlo = jlo; w.jhi = jhi; w.flags = 0;
+            w.tbase = 0; w.jlo = jlo; w.jhi = jhi; w.flags = (sjhi >= sjlo) ? 4 : 0;      // 4: the read has a sibling
             ((wrec *)a.wrec_q)[r - a.read0] = w;
             // a read the window passes cannot take (no usable minimum, candidates too far apart) goes to the exact
             // retry -- which starts now, beside the window passes, instead of behind them
@@ -464,7 +502,7 @@ void k_sdtw_p(const sdtw_kargs a)
     }
     const bool live = slot < nreads;
     if (!live) slot = nreads - 1;
-    const int r = a.wl_list ? a.wl_list[slot] : a.read0 + slot;
+    const int r = a.tier2 == 2 ? ((const sibrec *)a.sib)[slot].r : a.wl_list ? a.wl_list[slot] : a.read0 + slot;
 
     int n;
     double center = 0.0, scale = 1.0;
@@ -488,10 +526,13 @@ void k_sdtw_p(const sdtw_kargs a)
     // The first tier finds them in pass Q's epilogue (the read's wave scans the interval minima it has just written:
     // latency that the other waves' sweeps hide); a second-tier launch looks again (its reads come from a list).
     const unsigned b = (unsigned)a.qflag[r - a.read0];   // the screening minimum (pass Q), QINF: not usable
-    int jlo, jhi;
+    int jlo, jhi, clustered = 0;                    // clustered: this window holds one of two clusters of candidates
     if (!a.tier2) {
         const wrec q = ((const wrec *)a.wrec_q)[r - a.read0];
-        jlo = q.jlo; jhi = q.jhi;
+        jlo = q.jlo; jhi = q.jhi; clustered = q.flags & 4;
+    } else if (a.tier2 == 2) {                      // a read's second cluster (sibling list, pass Q's epilogue)
+        const sibrec q = ((const sibrec *)a.sib)[slot];
+        jlo = q.jlo; jhi = q.jhi; clustered = 4;
     } else {
         candidate_columns<L>(a, r, n, b, l, jlo, jhi);
     }
@@ -592,7 +633,7 @@ void k_sdtw_p(const sdtw_kargs a)
         if (l == 0) {
             wrec w;
             w.tbase = tbase; w.jlo = jlo; w.jhi = jhi;
-            w.flags = (screened ? 1 : 0) | (c0 > 0 ? 2 : 0);
+            w.flags = (screened ? 1 : 0) | (c0 > 0 ? 2 : 0) | clustered;
             ((wrec *)a.wrec)[slot] = w;
         }
     }
@@ -626,7 +667,7 @@ void k_sdtw_w(const sdtw_kargs a)
     }
     const bool live = slot < nreads;
     if (!live) slot = nreads - 1;
-    const int r = a.wl_list ? a.wl_list[slot] : a.read0 + slot;
+    const int r = a.tier2 == 2 ? ((const sibrec *)a.sib)[slot].r : a.wl_list ? a.wl_list[slot] : a.read0 + slot;
 
     int n, flags = 0;
     double center = 0.0, scale = 1.0;
@@ -795,7 +836,10 @@ void k_sdtw_w(const sdtw_kargs a)
         const unsigned lq = a.lastq[(int64_t)(r - a.read0) * a.lq_stride + j + L];   // (rows start L early)
         const unsigned bq = (unsigned)a.qflag[r - a.read0];
         const double u = bestD * QSCALE, e = (double)a.qerr;
-        const bool ok = fabs(u - (double)lq) <= e && u <= (double)bq + e;
+        // (one of two clusters: the row's minimum may sit in the other one -- this window's candidates only promise a
+        // screening cost within 2 E of it, hence an exact one within 3 E)
+        const double e2 = (rec.flags & 4) ? 3.0 * e : e;
+        const bool ok = fabs(u - (double)lq) <= e && u <= (double)bq + e2;
         if (!ok) { atomicAdd(&a.guard[SK_GUARD_VIOL], 1); atomicAdd(&a.guard[SK_GUARD_ALARM], 1); }
         return ok;
     };
@@ -805,14 +849,21 @@ void k_sdtw_w(const sdtw_kargs a)
         // tuning / sensitivity runs only: send a share of the reads to the exact retry whatever the window found
         const bool forced = a.force_retry && (((unsigned)r * 2654435761u) >> 22) < (unsigned)a.force_retry;
         bool certified = false;
-        if (n <= 0) {
+        if (a.tier2 == 2) {
+            // a second cluster: its result goes to the sibling's own record, the combine kernel merges (k_sib_combine)
+            h.dist = best; h.start = bestS; h.end = bestJ;
+            h.n = (n > 0 && screened && bestS >= 0 && !forced && premise_holds(best, bestJ)) ? 1 : 0;   // 1: certified
+            a.sib_out[slot] = h;
+        } else if (n <= 0) {
             h.dist = __builtin_nan(""); h.start = -1; h.end = -1;
             a.out[r] = h;
         } else if (screened && bestS >= 0 && !forced && (certified = premise_holds(best, bestJ))) {
             h.dist = best; h.start = bestS; h.end = bestJ;
             a.out[r] = h;
-        } else if (!screened && a.early_cnt) {
-            // (pass Q listed this read for the early exact retry, which writes its record -- perhaps right now)
+        } else if (!screened && a.early_cnt && !a.tier2) {
+            // (pass Q listed this read for the early exact retry, which writes its record -- perhaps right now.  In the second
+            // tier an unscreened read is one whose FIRST cluster did not certify -- the tier looks at all its candidates
+            // again and finds them too far apart: it falls through to the exact pass)
         } else {
             h.dist = __builtin_nan(""); h.start = -1; h.end = -1;    // overwritten by a later pass
             a.out[r] = h;
@@ -986,6 +1037,26 @@ __global__ __launch_bounds__(ORDER_TPB) void k_order_scatter(const order_args a)
     }
 }
 
+// second clusters -> the reads' records (struct sibrec)
+__global__ void k_sib_combine(const sibrec *sib, const int32_t *cnt, int cap, const sk_hit *so, sk_hit *out,
+                              int32_t *retry, int32_t *retry_cnt, int32_t *nsib_total)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0 && nsib_total) atomicAdd(nsib_total, min(*cnt, cap));     // (diagnostic: sk_last_dtw_guard out[6])
+    if (s >= min(*cnt, cap)) return;
+    const int r = sib[s].r;
+    sk_hit A = out[r];
+    const sk_hit B = so[s];
+    if (A.start < 0) return;                            // the first cluster did not certify: the read is on its way to the exact pass
+    if (B.n == 1) {
+        if (B.dist < A.dist) { A.dist = B.dist; A.start = B.start; A.end = B.end; out[r] = A; }   // (a tie keeps the lower column)
+    } else {                                            // the second cluster could not be certified: exact pass after all
+        A.dist = __builtin_nan(""); A.start = -1; A.end = -1;
+        out[r] = A;
+        retry[atomicAdd(retry_cnt, 1)] = r;
+    }
+}
+
 // Screening + certified window over all reads; fills out[] and the retry list (device).
 // The caller (sk_launch_sdtw) runs the exact pass on the listed reads.
 // span / span2: look-back of the window pass's first tier (every read) and of its second tier (the reads whose
@@ -1050,6 +1121,16 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
     if (sorted && (rc = sk_reserve(c, &c->order, ((size_t)chunk + ORDER_BINS) * sizeof(int32_t)))) return rc;
     const bool tiers = span2 > span;
     if (tiers && (rc = sk_reserve(c, &c->wsoft, ((size_t)chunk + 1) * sizeof(int32_t)))) return rc;
+    const bool siblings = sk_tune("SK_DTW_NO_SIBLINGS") == nullptr;
+    // (their list is short: a launch sized for the whole chunk costs 0.2 ms in workgroups that only look at the count)
+    const int sib_cap = (int)(chunk / 64 + 1024);
+    if (siblings) {
+        if ((rc = sk_reserve(c, &c->sib, 16 + (size_t)sib_cap * sizeof(sibrec)))) return rc;
+        if ((rc = sk_reserve(c, &c->sibout, (size_t)sib_cap * sizeof(sk_hit)))) return rc;
+        if ((rc = sk_reserve(c, &c->sibstate, (size_t)sib_cap * (state_bytes + sizeof(wrec))))) return rc;
+        if (c->stream3 && !c->ev_s[0])
+            for (int i = 0; i < 2; i++) SK_HIP(hipEventCreateWithFlags(&c->ev_s[i], hipEventDisableTiming));
+    }
 
     typedef void *(*pick_fn)(int, int, int);
     const pick_fn pk = a->feed == SK_FEED_I16 ? (pick_fn)sk_sdtwq_pick_feed0
@@ -1108,12 +1189,37 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
                        ((((uintptr_t)a->samples & 15) == 0 && (a->stride % 8) == 0) ? 2 : 0);
         }
         hipEvent_t *ev = &c->evpool[3 * (size_t)c->prof_chunks];
+        k.sib = nullptr; k.sib_cnt = nullptr; k.sib_out = nullptr; k.tier2 = 0;
+        if (siblings) {
+            SK_HIP(hipMemsetAsync(c->sib.p, 0, 16, c->stream));
+            k.sib_cnt = (int32_t *)c->sib.p; k.sib = (char *)c->sib.p + 16; k.sib_out = (sk_hit *)c->sibout.p;
+            k.sib_cap = sib_cap;
+        }
         SK_HIP(hipEventRecord(ev[0], c->stream));
         k.clk = (r0 == 0) ? (unsigned long long *)((char *)c->dtwcnt.p + 16) : nullptr;
         hipLaunchKernelGGL(fq, dim3(grid), dim3(256), fz_lds, c->stream, k);
         k.fz_raw = nullptr;                                 // (the later passes only read)
         if (d_early_cnt && r0 + chunk >= a->nreads) SK_HIP(hipEventRecord(c->ev_r[0], c->stream));   // last pass Q done
         SK_HIP(hipGetLastError());
+        if (siblings) {
+            // the second clusters (struct sibrec): one more short round of both window passes over the sibling list, with
+            // the wider look-back (there is no second tier for them).  A handful of reads -- pure latency (pre-roll +
+            // window, 0.3-0.9 ms): on the third stream, beside the main window passes, with state and records of its own
+            sdtw_kargs ks = k;
+            ks.tier2 = 2; ks.wl_list = nullptr; ks.wl_count = k.sib_cnt; ks.soft = nullptr; ks.soft_cnt = nullptr;
+            ks.span = tiers ? span2 : span; ks.total_ptr = nullptr; ks.nreads = sib_cap;
+            ks.wstate = (unsigned *)c->sibstate.p; ks.wrec = (char *)c->sibstate.p + (size_t)sib_cap * state_bytes;
+            const int sgrid = (sib_cap + reads_per_block - 1) / reads_per_block;
+            hipStream_t ss = c->stream3 ? c->stream3 : c->stream;
+            if (c->stream3) {
+                SK_HIP(hipEventRecord(c->ev_s[0], c->stream));
+                SK_HIP(hipStreamWaitEvent(c->stream3, c->ev_s[0], 0));
+            }
+            hipLaunchKernelGGL(fp, dim3(sgrid), dim3(256), 0, ss, ks);
+            hipLaunchKernelGGL(fw, dim3(sgrid), dim3(256), 0, ss, ks);
+            SK_HIP(hipGetLastError());
+            if (c->stream3) SK_HIP(hipEventRecord(c->ev_s[1], c->stream3));
+        }
         SK_HIP(hipEventRecord(ev[1], c->stream));
         const int32_t *order = nullptr;
         if (sorted && k.nreads >= sort_min) {
@@ -1147,6 +1253,13 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
         k.total_ptr = nullptr;
         hipLaunchKernelGGL(fw, dim3(grid), dim3(256), 0, c->stream, k);
         SK_HIP(hipGetLastError());
+        if (siblings) {                                     // the merge of the second clusters' records, behind both rounds
+            if (c->stream3) SK_HIP(hipStreamWaitEvent(c->stream, c->ev_s[1], 0));
+            hipLaunchKernelGGL(k_sib_combine, dim3((sib_cap + 255) / 256), dim3(256), 0, c->stream,
+                               (const sibrec *)k.sib, (const int32_t *)k.sib_cnt, sib_cap, (const sk_hit *)k.sib_out, k.out,
+                               d_retry, d_retry_cnt, (int32_t *)c->dtwcnt.p + 8 + 6);
+            SK_HIP(hipGetLastError());
+        }
         SK_HIP(hipEventRecord(ev[2], c->stream));
         c->prof_reads[c->prof_chunks < 64 ? c->prof_chunks : 63] = k.nreads;
         c->prof_chunks++;

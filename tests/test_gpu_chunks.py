@@ -156,8 +156,16 @@ def test_early_retry_equals_late_retry(gpu, ora, monkeypatch):
     for r in flat:                                        # MAD of a few units and one sample hundreds of MADs away
         sig[r, :] = 500 + (np.arange(M) % 3)
         sig[r, 1234] = 1190
+    # (round 5: a read with two clusters of candidate columns gets a second window instead of the exact pass --
+    # SK_DTW_NO_SIBLINGS=1 is round 4's behaviour, which this test is about; the default is compared with it below)
+    with_siblings = api.motifseq_batch(sig, lens, motif)
+    n_sib = api.last_dtw_guard()["second_windows"]
+    n_retry_sib = L.sk_last_dtw_retries()
+    monkeypatch.setenv("SK_DTW_NO_SIBLINGS", "1")
     got = api.motifseq_batch(sig, lens, motif)
     n_early = L.sk_last_dtw_retries()
+    assert with_siblings.tobytes() == got.tobytes()
+    assert n_sib >= twice.size // 2 and n_retry_sib < n_early, (n_sib, n_retry_sib, n_early)
     monkeypatch.setenv("SK_DTW_NO_EARLY", "1")
     late = api.motifseq_batch(sig, lens, motif)
     assert got.tobytes() == late.tobytes() and n_early == L.sk_last_dtw_retries()
@@ -165,6 +173,9 @@ def test_early_retry_equals_late_retry(gpu, ora, monkeypatch):
     monkeypatch.setenv("SK_DTW_SCRATCH_MB", "8")
     chunked = api.motifseq_batch(sig, lens, motif)
     assert chunked.tobytes() == got.tobytes()
+    monkeypatch.delenv("SK_DTW_NO_SIBLINGS")
+    chunked_sib = api.motifseq_batch(sig, lens, motif)             # second windows in every chunk
+    assert chunked_sib.tobytes() == got.tobytes() and api.last_dtw_guard()["second_windows"] == n_sib
     assert n_early >= twice.size, "the doubled reads should have gone to the exact retry (%d)" % n_early
     want = oracle_motifseq_threaded(ora, sig, lens, motif)
     ok = (got["flags"] & 2) == 0

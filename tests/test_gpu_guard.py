@@ -59,6 +59,7 @@ def test_guard_is_quiet_and_audits_on_a_healthy_build(gpu, ora, monkeypatch):
     sig = synth.squiggle_batch(R, M, 20260931, motif=motif)
     lens = np.full(R, M, dtype=np.int32)
     lens[::13] = np.random.default_rng(1).integers(1000, M, lens[::13].size)
+    monkeypatch.setenv("SK_DTW_AUDIT_PERIOD", "4096")            # (explicit: every call is audited, see the next test)
     base = api.motifseq_batch(sig, lens, motif)
     assert _screened(gpu)
     g = api.last_dtw_guard()
@@ -78,6 +79,27 @@ def test_guard_is_quiet_and_audits_on_a_healthy_build(gpu, ora, monkeypatch):
     rows = np.arange(0, R, 9)
     want = oracle_motifseq_threaded(ora, sig[rows], lens[rows], motif)
     assert np.all(_same(base[rows], want))
+
+
+def test_audit_of_small_calls_is_spread_over_calls(gpu):
+    """A call whose window passes are shorter than one exact sweep would WAIT for the audit (9 000 reads: 0.37 ms of
+    sweep beside 0.1 ms of windows).  By default such calls are audited one in K, K from the expected exposure (at most
+    64), so that the average cost stays near 2 % of the call; large calls (test_gpu_chunks) are audited every time."""
+    from squigglekit_amd import api, synth
+    motif = synth.synthetic_motif(200)
+    R, M = 9000, 4000
+    sig = synth.squiggle_batch(R, M, 20260937, motif=motif)
+    lens = np.full(R, M, dtype=np.int32)
+    base, counts = None, []
+    for _ in range(70):
+        got = api.motifseq_batch(sig, lens, motif)
+        g = api.last_dtw_guard()
+        assert g["premise_violations"] == 0 and g["audit_mismatches"] == 0 and g["exact_fallback"] == 0, g
+        counts.append(g["audited"])
+        base = got if base is None else base
+        assert got.tobytes() == base.tobytes()
+    assert set(counts) == {0, 3}, counts
+    assert 1 <= counts.count(3) <= 35, counts
 
 
 def test_hole_e_equals_one_is_caught(gpu, ora, monkeypatch):

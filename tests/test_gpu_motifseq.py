@@ -331,3 +331,99 @@ def test_motifseq_after_stall_extension(gpu, ora, example_model):
         d, s0, e0 = ora.dtw_subsequence(example_model, y)
         assert (hits["dist"][r], hits["start"][r], hits["end"][r]) == (d, s0, e0), r
     assert ncut >= 40                                  # the synthetic reads start with a stall
+
+
+@pytest.mark.parametrize("scale", ["medmad", "zscale"])
+def test_multi_motif_batch_through_the_fused_prologue(gpu, ora, scale):
+    """Enough reads for the screening scheme: the first motif's pass Q carries the filter + statistics (medmad, and since
+    round 5 zscale) as its prologue, the later motifs find the compacted samples / statistics in place -- records equal
+    to one call per motif and to the oracle on a sample."""
+    from squigglekit_amd import api, synth
+    motifs = [synth.synthetic_motif(200, seed=1), synth.synthetic_motif(163, seed=2), synth.synthetic_motif(64, seed=3)]
+    R, M = 900, 4000
+    sig = synth.squiggle_batch(R, M, 60708, motif=motifs[0])
+    lens = np.full(R, M, dtype=np.int32)
+    lens[::11] = np.random.default_rng(3).integers(1500, M, lens[::11].size)
+    outs = api.motifseq_multi_batch(sig, lens, motifs, scale=scale)
+    mode = {"medmad": 0, "zscale": 1}[scale]
+    rows = np.arange(0, R, 7)
+    for k, m in enumerate(motifs):
+        one = api.motifseq_batch(sig, lens, m, scale=scale)
+        assert outs[k].tobytes() == one.tobytes(), (scale, k)
+        want = ora.motifseq_batch_i16(sig[rows], lens[rows], m, scale_mode=mode)
+        for f in ("dist", "start", "end", "n"):
+            assert np.array_equal(outs[k][f][rows], want[f]), (scale, k, f)
+
+
+def test_two_clusters_of_candidate_columns_take_a_second_window(gpu, ora, monkeypatch):
+    """Reads that hold the motif twice, far apart (candidate columns in two clusters more than 512 columns from each
+    other): the second cluster is a SIBLING of the read in a second round of the window passes and the combine kernel
+    keeps the smaller exact distance, the lower column on a tie (np.argmin's first minimum, MotifSeq.py:437-439).  int16
+    rows of 4 000 and 20 000 samples: identical copies (a tie: the first wins), three copies (one cluster too many: exact
+    pass), copies 400 columns apart (one window).  float64 reads, where a copy can be worse by less than the screening's
+    2 E: copies whose costs differ by a hair either way (the sibling's record wins, or the read's own).  Against the oracle and
+    against SK_DTW_NO_SIBLINGS=1."""
+    from squigglekit_amd import api, synth
+    L = gpu.load()
+    motif = synth.synthetic_motif(200, seed=21)
+    copy = np.clip(np.rint(motif * 93.4 + 511.0), 1, 1199).astype(np.int16)
+    for M in (4000, 20000):
+        R = 640
+        sig = synth.squiggle_batch(R, M, 880 + M, motif=None)
+        lens = np.full(R, M, dtype=np.int32)
+        far = M - 1200
+        kinds = {}
+        for r in range(0, R, 4):
+            k = (r // 4) % 3
+            kinds[r] = k
+            sig[r, 300:500] = copy
+            if k == 2:
+                sig[r, 700:900] = copy                       # close together: one window
+            else:
+                sig[r, far:far + 200] = copy                 # k = 0: two clusters, a tie
+            if k == 1:
+                sig[r, M // 2:M // 2 + 200] = copy           # three clusters
+        got = api.motifseq_batch(sig, lens, motif)
+        g = api.last_dtw_guard()
+        retries = L.sk_last_dtw_retries()
+        monkeypatch.setenv("SK_DTW_NO_SIBLINGS", "1")
+        plain = api.motifseq_batch(sig, lens, motif)
+        retries_plain = L.sk_last_dtw_retries()
+        monkeypatch.delenv("SK_DTW_NO_SIBLINGS")
+        assert got.tobytes() == plain.tobytes()
+        n0 = sum(1 for k in kinds.values() if k == 0)
+        # (the copies' surroundings differ, so not every pair of them is within 2 E of each other: those reads have one cluster)
+        assert g["second_windows"] >= n0 // 2 and g["alarm"] == 0, (g, n0)
+        assert retries <= retries_plain - g["second_windows"] + 4, (retries, retries_plain, g)
+        rows = np.array(sorted(kinds))
+        want = ora.motifseq_batch_i16(sig[rows], lens[rows], motif)
+        for f in ("dist", "start", "end"):
+            assert np.array_equal(got[f][rows], want[f]), (M, f)
+        k_of = np.array([kinds[r] for r in rows])
+        assert np.mean(got["end"][rows][k_of == 0] < 600) > 0.6      # a tie goes to the first copy (some reads match better elsewhere)
+    # float64 reads: the second copy better / worse than the first by a hair (0.02 raw units on one sample: 2e-4 signal units)
+    R, M = 400, 4000
+    base = synth.squiggle_batch(R, M, 991, motif=None).astype(np.float64)
+    reads, kind = [], []
+    for r in range(R):
+        x = base[r].copy()
+        k = r % 4
+        if k < 2:
+            x[300:500] = copy
+            x[M - 1200:M - 1000] = copy
+            x[(300 if k == 0 else M - 1200) + 77] += 0.02    # k = 0: the first copy is the worse one, k = 1: the second
+        kind.append(k)
+        reads.append(x)
+    got = api.motifseq_reads_f64(reads, motif)
+    g = api.last_dtw_guard()
+    monkeypatch.setenv("SK_DTW_NO_SIBLINGS", "1")
+    plain = api.motifseq_reads_f64(reads, motif)
+    monkeypatch.delenv("SK_DTW_NO_SIBLINGS")
+    assert got.tobytes() == plain.tobytes() and g["second_windows"] >= 100 and g["alarm"] == 0, g
+    kind = np.array(kind)
+    two = got["end"][kind < 2]
+    # both outcomes occur: the first cluster holds the minimum, the second one does (the sibling's record replaces the read's)
+    assert (two < 600).sum() >= 10 and (two > M - 1200).sum() >= 5, (int((two < 600).sum()), int((two > M - 1200).sum()))
+    for r in np.flatnonzero(kind < 2):
+        f = ora.scale_outliers(reads[r], 0, 1200)
+        assert (got["dist"][r], got["start"][r], got["end"][r]) == ora.dtw_subsequence(motif, ora.medmad(f)[0]), r
