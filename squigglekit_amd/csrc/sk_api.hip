@@ -956,9 +956,20 @@ static int drna_roll_dev(sk_ctx *c, const int16_t *d_sig, int64_t stride, const 
     clamp_limits(&lo, &hi);
     const int64_t words = (stride + 63) / 64;
     const size_t sb = (size_t)nreads * (size_t)stride * sizeof(int16_t);
-    if ((rc = sk_reserve(c, &c->comp, sb))) return rc;
     if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
     if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * 2 * sizeof(uint64_t)))) return rc;
+    uint64_t *below = (uint64_t *)c->mask.p, *above = below + (size_t)nreads * (size_t)words;
+    // one look (round 5): a workgroup per read, prefix sums in LDS -- rows of up to ~35 000 samples, w < 65 536
+    if (sk_roll_one_lds(stride, p->w) && sk_tune("SK_ROLL_TWO_KERNELS") == nullptr && sk_tune("SK_DRNA_STEP") == nullptr) {
+        SK_HIP(hipEventRecord(c->ev[0], c->stream));
+        if ((rc = sk_launch_roll_one(c, d_sig, stride, d_len, nreads, lo, hi, p->w, p->std_scale, (sk_prep *)c->prep.p,
+                                     below, above))) return rc;
+        SK_HIP(hipEventRecord(c->ev[1], c->stream));
+        if ((rc = sk_launch_roll_walk(c, below, above, (const sk_prep *)c->prep.p, nreads, p, d_xy, d_found))) return rc;
+        c->ev_valid = true;
+        return SK_OK;
+    }
+    if ((rc = sk_reserve(c, &c->comp, sb))) return rc;
     // prefix sums of the filtered samples: 4 bytes each when every window sum fits 31 bits (sk_launch_roll_stats)
     const size_t pbytes = (p->w < 65536 && sk_tune("SK_DRNA_STEP") == nullptr) ? sizeof(uint32_t) : sizeof(int64_t);
     if ((rc = sk_reserve(c, &c->misc, (size_t)nreads * (size_t)(stride + 1) * pbytes))) return rc;
@@ -967,7 +978,6 @@ static int drna_roll_dev(sk_ctx *c, const int16_t *d_sig, int64_t stride, const 
     rc = sk_launch_prep_i16(c, d_sig, stride, d_len, nreads, lo, hi,
                             SK_PREP_MEDMAD, 0.0, (int16_t *)c->comp.p, (sk_prep *)c->prep.p, nullptr, 0);
     if (rc) return rc;
-    uint64_t *below = (uint64_t *)c->mask.p, *above = below + (size_t)nreads * (size_t)words;
     rc = sk_launch_roll_stats(c, (const int16_t *)c->comp.p, stride, (sk_prep *)c->prep.p, nreads, p->w,
                               p->std_scale, (int64_t *)c->misc.p, below, above);
     if (rc) return rc;

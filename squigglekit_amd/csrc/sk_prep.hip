@@ -16,6 +16,7 @@
 // HBM traffic per read: M*2 B in, n*2 B out (compacted samples, needed in order by the DTW /
 // segment kernels), 48 B of statistics, n/8 B of mask (segmenter only).
 #include "sk_common.h"
+#include <limits.h>
 #include <math.h>
 #include <stdlib.h>
 
@@ -215,7 +216,7 @@ __device__ void build_tree(int m, Scratch *sc)
 // wave 0 folds the partial sums bottom-up (parent = left + right), wave-synchronously.
 // BCAST = false: only wavefront 0 gets the result (the caller continues in thread 0), which saves the
 // two barriers of the broadcast.
-template <bool BCAST, typename Term>
+template <bool BCAST, int NT = TPB, typename Term>
 __device__ double pairwise_chunk(int m, Scratch *sc, Term term)
 {
     const int tid = threadIdx.x;
@@ -236,7 +237,7 @@ __device__ double pairwise_chunk(int m, Scratch *sc, Term term)
     }
     const int grp = tid >> 3, j = tid & 7;
     const int nleaf = sc->nleaf;
-    for (int li = grp; li < nleaf; li += TPB / 8) {
+    for (int li = grp; li < nleaf; li += NT / 8) {
         const int id = sc->leaf[li];
         const unsigned e = sc->tab[id];
         const int s = (int)(e >> 16), len = (int)(e & 0xffffu);
@@ -1197,14 +1198,245 @@ void k_roll_stats(const int16_t *__restrict__ comp, int64_t stride, sk_prep *__r
             gt = t > bot;                                    // :302
         }
         const unsigned long long bl = __ballot(lt), ba = __ballot(gt);
-        if (lane == 0) {
+        if (lane == 0 && i < n) {                            // (words that start behind the read have no row in the masks)
             below[(int64_t)(i >> 6) * mask_rows + r] = bl;
             above[(int64_t)(i >> 6) * mask_rows + r] = ba;
         }
     }
 }
 
+// ---- the same in ONE look (round 5) ----------------------------------------------------------------------------------
+// k_prep_i16 + k_roll_stats move every sample through HBM four times over (compacted copy out and in, 4-byte prefix sums
+// out and six times in).  Here a workgroup of 1024 lanes keeps the read's prefix sums in LDS -- 4 bytes a sample, reads of
+// up to ~37 000 samples in the CU's 160 KB -- and HBM sees the raw samples once and the two bit masks:
+//   1. filter + order-preserving compaction + prefix sum in one sweep: a lane takes 8 raw samples, the block scans
+//      (count kept, sum kept), the lane writes P[pos + 1 ..] for its kept samples;
+//   2. mn / std of the rolling mean in numpy's order: the full 8192-chunks are regular trees (64 leaves of 128, halves
+//      all the way up), so all their leaves are summed side by side by 8-lane groups and one wavefront per chunk folds
+//      its 64 leaf sums with six shifts; the last, ragged chunk goes through pairwise_chunk;
+//   t = RN(S / w) itself costs three FP64 operations, not the division's thirty (see tval below);
+//   3. the masks t < bot, t > bot without one: RN(S / w) is monotone in the integer window sum S, so thread 0
+//      finds the two integer thresholds around bot * w (eight candidates each, judged with the real division) and the
+//      mask sweep compares integers.
+// P is laid out with one word of padding behind every 8 (roll_idx): the sweep's lanes write runs of up to 8 entries
+// 8 apart, and the 8-lane groups of a wavefront read leaves 128 samples apart -- both would fall on the same 8 LDS banks.
+constexpr int ROLL_NT = 1024;
+constexpr int ROLL_NW = ROLL_NT / 64;
+constexpr int ROLL_MAXFULL = 5;                              // full 8192-chunks of a read that fits in LDS
+struct RollShared {
+    int       wcnt[2][ROLL_NW];                              // per-wave kept counts / sums (double buffered by tile parity)
+    int       wsum[2][ROLL_NW];
+    double    leaf[ROLL_MAXFULL][64];
+    double    chunk[ROLL_MAXFULL + 1];
+    long long thr[2];                                        // S < thr[0] <=> t < bot;  S > thr[1] <=> t > bot
+};
+static_assert(sizeof(RollShared) % 16 == 0, "P behind it is 16-byte aligned");
+__host__ __device__ __forceinline__ int roll_idx(int i) { return i + (i >> 3); }
+
+template <typename Term>
+__device__ double roll_numpy_sum(int n, Scratch *sc, RollShared *rs, Term term)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nfull = n / NPY_BUFSIZE, mlast = n % NPY_BUFSIZE;
+    const int grp = tid >> 3, j = tid & 7;
+    for (int L = grp; L < nfull * 64; L += ROLL_NT / 8) {
+        const int s = L * PW_BLOCK;
+        double r = term(s + j);
+#pragma unroll 4
+        for (int i = 8; i < PW_BLOCK; i += 8) r += term(s + i + j);
+        r += dpp_shl_f64<1>(r);
+        r += dpp_shl_f64<2>(r);
+        r += dpp_shl_f64<4>(r);
+        if (j == 0) rs->leaf[L >> 6][L & 63] = r;
+    }
+    lds_barrier();
+    if (wv < nfull) {                                        // one wavefront per full chunk: parent = left + right, six levels
+        double v = rs->leaf[wv][lane];
+        v += dpp_shl_f64<1>(v);
+        v += dpp_shl_f64<2>(v);
+        v += dpp_shl_f64<4>(v);
+        v += dpp_shl_f64<8>(v);
+        v += __shfl_down(v, 16);
+        v += __shfl_down(v, 32);
+        if (lane == 0) rs->chunk[wv] = v;
+    }
+    lds_barrier();
+    double res = 0.0;
+    for (int c = 0; c < nfull; c++) res += rs->chunk[c];
+    if (mlast > 0 || nfull == 0)
+        res += pairwise_chunk<true, ROLL_NT>(mlast, sc, [&](int i) { return term(nfull * NPY_BUFSIZE + i); });
+    else
+        lds_barrier();                                       // (rs->leaf / chunk are free for the next sum)
+    return res;
+}
+
+__global__ __launch_bounds__(ROLL_NT)
+void k_roll_one(const int16_t *__restrict__ sig, int64_t stride, const int32_t *__restrict__ len, int nreads,
+                int lo, int hi, int w, double std_scale, int vec_ok, sk_prep *__restrict__ prep,
+                uint64_t *__restrict__ below, uint64_t *__restrict__ above, int64_t mask_rows)
+{
+    extern __shared__ __align__(16) unsigned char roll_lds[];
+    Scratch *sc = (Scratch *)roll_lds;
+    RollShared *rs = (RollShared *)(roll_lds + sizeof(Scratch));
+    unsigned *P = (unsigned *)(roll_lds + sizeof(Scratch) + sizeof(RollShared));
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { sc->tree_m = -1; P[0] = 0u; }
+    auto row_len = [&](int r) -> int { const int m = len[r]; return m < 0 ? 0 : (m > stride ? (int)stride : m); };
+
+    // A persistent workgroup (the LDS leaves room for one or two per CU, so nothing else hides a read's first load or
+    // the launch of the next workgroup): the first 16 bytes of the NEXT read are requested before this read's statistics.
+    int r = blockIdx.x;
+    int M = r < nreads ? row_len(r) : 0;
+    uint4 qn = make_uint4(0u, 0u, 0u, 0u);
+    if (r < nreads && vec_ok && tid * 8 + 8 <= M) qn = *(const uint4 *)(sig + (int64_t)r * stride + tid * 8);
+    for (; r < nreads; r += gridDim.x) {
+        const int16_t *row = sig + (int64_t)r * stride;
+
+        // ---- 1. filter, compaction, prefix sums (wrapping uint32: w < 65 536, their differences do not wrap)
+        int ccarry = 0;
+        unsigned scarry = 0u;
+        int parity = 0;
+        for (int base = 0; base < M; base += ROLL_NT * 8, parity ^= 1) {
+            const int i0 = base + tid * 8;
+            int v[8];
+            const uint4 q = qn;
+            if (vec_ok && i0 + ROLL_NT * 8 + 8 <= M) qn = *(const uint4 *)(row + i0 + ROLL_NT * 8);    // the next tile
+            if (vec_ok && i0 + 8 <= M) {
+                const unsigned qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) { v[2 * k] = (int)(short)(qq[k] & 0xffffu); v[2 * k + 1] = (int)(short)(qq[k] >> 16); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = (i0 + k < M) ? (int)row[i0 + k] : lo;     // (lo is not kept)
+            }
+            int c = 0, s = 0;
+            unsigned keep = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool kept = v[k] > lo && v[k] < hi;                                   // scale_outliers: strictly inside
+                c += kept ? 1 : 0;
+                s += kept ? v[k] : 0;
+                keep |= (kept ? 1u : 0u) << k;
+            }
+            const int inc_c = wave_incl_scan(c, lane), inc_s = wave_incl_scan(s, lane);
+            if (lane == 63) { rs->wcnt[parity][wv] = inc_c; rs->wsum[parity][wv] = inc_s; }
+            lds_barrier();
+            int bc = 0, bs = 0, tc = 0, ts = 0;
+#pragma unroll
+            for (int i = 0; i < ROLL_NW; i++) {
+                const int cc = rs->wcnt[parity][i], ss = rs->wsum[parity][i];
+                if (i < wv) { bc += cc; bs += ss; }
+                tc += cc; ts += ss;
+            }
+            int pos = ccarry + bc + inc_c - c;
+            unsigned run = scarry + (unsigned)(bs + inc_s - s);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if ((keep >> k) & 1u) { run += (unsigned)v[k]; pos++; P[roll_idx(pos)] = run; }
+            ccarry += tc;
+            scarry += (unsigned)ts;
+        }
+        const int n = ccarry;
+        const int rn = r + gridDim.x;
+        int Mn = 0;
+        if (rn < nreads) {
+            Mn = row_len(rn);
+            if (vec_ok && tid * 8 + 8 <= Mn) qn = *(const uint4 *)(sig + (int64_t)rn * stride + tid * 8);
+        }
+        lds_barrier();
+
+        // ---- 2. numpy-order mean and std of the rolling mean (the expressions of k_roll_stats)
+        const long long cnt = (n >= w) ? (long long)n - w + 1 : 0;
+        const double dw = (double)w;
+        auto wsum = [&](int i) -> int { return (int)(P[roll_idx(i + 1)] - P[roll_idx(i + 1 - w)]); };    // i >= w - 1
+        // t = RN(S / w) in three operations: the quotient estimate, its exact remainder, one correction -- correctly
+        // rounded for |S| < 2^31, w < 2^16 (tools/ubench/check_intdiv.c: the argument, and 1.3 G quotients against the division)
+        const double inv_w = 1.0 / dw;
+        auto tval = [&](int i) -> double {
+            const double s = (double)wsum(i);
+            const double q = s * inv_w;
+            return fma(fma(-q, dw, s), inv_w, q);
+        };
+        const double mn = roll_numpy_sum(n, sc, rs, [&](int i) { return (i >= w - 1) ? tval(i) : 0.0; }) / (double)cnt;
+        const double ss = roll_numpy_sum(n, sc, rs, [&](int i) {
+            if (i < w - 1) return 0.0;
+            const double d = mn - tval(i);
+            return d * d;
+        });
+        const double sd = sqrt(ss / (double)(cnt - 1));
+        const double bot = mn - (sd * std_scale);
+        if (tid == 0) {
+            sk_prep pr;
+            pr.n = n; pr.flags = n > 0 ? 0 : SK_FLAG_EMPTY;
+            pr.center = mn; pr.scale = sd; pr.top = bot; pr.bot = bot;
+            prep[r] = pr;
+        }
+        // ---- 3. integer thresholds of the two comparisons: eight candidates around bot * w, one lane each
+        if (wv == 0) {
+            long long lt, gt;
+            const double x = bot * dw;
+            if (bot != bot) { lt = LLONG_MIN; gt = LLONG_MAX; }                 // NaN: neither t < bot nor t > bot
+            else if (x >= 2147483652.0) { lt = LLONG_MAX; gt = LLONG_MAX; }     // every window sum is below
+            else if (x <= -2147483653.0) { lt = LLONG_MIN; gt = LLONG_MIN; }    // every window sum is above
+            else {
+                const long long s0 = (long long)floor(x);
+                const double t = (double)(s0 - 3 + (lane & 7)) / dw;             // (the real division: these decide)
+                const int nlt = __popcll(__ballot(lane < 8 && t < bot)), ngt = __popcll(__ballot(lane < 8 && t > bot));
+                lt = s0 - 3 + nlt;                                               // smallest S with t(S) >= bot (t is monotone in S)
+                gt = s0 + 4 - ngt;                                               // largest S with t(S) <= bot
+            }
+            if (lane == 0) { rs->thr[0] = lt; rs->thr[1] = gt; }
+        }
+        lds_barrier();
+        const long long thr_lt = rs->thr[0], thr_gt = rs->thr[1];
+        for (int base = 0; base < n; base += ROLL_NT) {
+            const int i = base + tid;
+            bool lt = false, gt = false;
+            if (i < n && i >= w - 1) {
+                const long long S = (long long)wsum(i);
+                lt = S < thr_lt;                             // :297 / :300
+                gt = S > thr_gt;                             // :302
+            }
+            const unsigned long long bl = __ballot(lt), ba = __ballot(gt);
+            if (lane == 0 && i < n) {
+                below[(int64_t)(i >> 6) * mask_rows + r] = bl;
+                above[(int64_t)(i >> 6) * mask_rows + r] = ba;
+            }
+        }
+        M = Mn;
+        lds_barrier();                                       // (the next read writes P and the thresholds)
+    }
+}
+
 } // namespace
+
+// LDS of the one-look rolling-mean kernel for rows of `stride` samples (0: does not fit)
+size_t sk_roll_one_lds(int64_t stride, int32_t w)
+{
+    if (w >= 65536 || stride > (1 << 17)) return 0;
+    const size_t need = sizeof(Scratch) + sizeof(RollShared) + ((size_t)roll_idx((int)stride + 1) + 4) * sizeof(unsigned);
+    return need <= 160 * 1024 ? need : 0;
+}
+
+int sk_launch_roll_one(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads, int32_t lo,
+                       int32_t hi, int32_t w, double std_scale, sk_prep *d_prep, uint64_t *d_below, uint64_t *d_above)
+{
+    if (nreads <= 0) return SK_OK;
+    const size_t lds = sk_roll_one_lds(stride, w);
+    if (!lds) return sk_fail(SK_ERR_INVALID, "internal: the one-look rolling-mean kernel does not hold this read length");
+    if (lds > 64 * 1024)
+        SK_HIP(hipFuncSetAttribute((const void *)k_roll_one, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int vec_ok = (((uintptr_t)d_sig & 15) == 0 && (stride % 8) == 0) ? 1 : 0;
+    int per_cu = (int)((160 * 1024) / (lds + 256));
+    if (per_cu > 2) per_cu = 2;
+    if (const char *e = sk_tune("SK_PREP_PERCU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }
+    const long long g = (long long)c->num_cu * per_cu;
+    const int grid = g > nreads ? nreads : (int)g;
+    hipLaunchKernelGGL(k_roll_one, dim3(grid), dim3(ROLL_NT), lds, c->stream, d_sig, stride, d_len, nreads, lo, hi, w,
+                       std_scale, vec_ok, d_prep, d_below, d_above, (int64_t)nreads);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
+}
 
 int sk_launch_roll_stats(sk_ctx *c, const int16_t *d_comp, int64_t stride, sk_prep *d_prep, int32_t nreads,
                          int32_t w, double std_scale, int64_t *d_psum, uint64_t *d_below, uint64_t *d_above)

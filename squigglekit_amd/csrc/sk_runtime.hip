@@ -92,6 +92,7 @@ static const sk_tunable SK_TUNABLES[] = {
     {"SK_WALK_OWNPASS",       "1",           "segmenter walk: finds the quiet stretches and anchors in a pass of its own instead of taking the statistics kernel's hints"},
     {"SK_WALK_NOJUMP",        "1",           "segmenter walk: every run is hopped through, no jumps between the stretches of quiet entries"},
     {"SK_DRNA_STEP",          "1",           "dRNA_segmenter, both branches: the per-sample scans instead of the scans by runs / by transitions"},
+    {"SK_ROLL_TWO_KERNELS",   "1",           "dRNA_segmenter rolling-mean branch: filter kernel + prefix sums through HBM instead of the one-look kernel (prefix sums in LDS)"},
     {"SK_INGEST_MB",          "1 4",         "sub-batch size of the host entry points in MB"},
     {"SK_F64_OLD",            "1",           "float64 reads: numpy-order statistics kernel for every read"},
     {"SK_F64_LONG_LOOKS",     "1",           "float64 reads of 4 097 .. 40 960 samples: the window-by-window kernel (three to five looks at a read) instead of the workgroup-per-read one (one look)"},

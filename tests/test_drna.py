@@ -151,6 +151,42 @@ def test_gpu_rolling_branch(gpu, ora):
 
 
 @pytest.mark.gpu
+def test_gpu_rolling_branch_one_look_kernel(gpu, ora, monkeypatch):
+    """Rows of up to ~35 000 samples take the one-look kernel (k_roll_one: prefix sums in LDS, full 8192-chunks summed
+    side by side, integer thresholds instead of the division in the mask sweep).  Against the oracle over parameter
+    corners and read lengths around the 8192-chunk boundaries of numpy's summation, and record for record against the
+    two-kernel path."""
+    from squigglekit_amd import api, synth
+    from squigglekit_amd._lib import RollParams
+    reads, _ = _roll_reads()
+    rng = np.random.default_rng(20260941)
+    extra = [r for r in reads if r.size <= 34500]
+    extra += synth.drna_reads(24, 78, min_len=6000, max_len=34500)
+    for n in (0, 1, 7, 8, 9, 127, 128, 129, 2047, 8191, 8192, 8193, 16384, 16391, 24576 + 64, 32768, 32769, 34500):
+        x = (450 + 60 * np.sin(np.arange(n) / 900.0) + rng.normal(0, 12, n)).astype(np.int16)
+        if n > 4000: x[n // 3: n // 3 + 2500] -= 150          # a low stretch of acceptable length
+        extra.append(x)                                         # (inside the default limits: every sample is kept)
+    extra.append(np.r_[np.full(6000, 300), np.full(20000, 600)].astype(np.int16))
+    extra.append(np.full(30000, 32767, dtype=np.int16))         # everything filtered away
+    assert max(len(x) for x in extra) <= 34500
+    for kw in (dict(), dict(w=7, lo_thresh=3, seg_dist=2, shift=0), dict(w=1200, std_scale=0.1, lo_thresh=100),
+               dict(w=500, seg_dist=100000), dict(lim_low=300, lim_hi=700, w=300, lo_thresh=50), dict(w=1, lo_thresh=5),
+               dict(w=8192, lo_thresh=100, std_scale=0.3), dict(w=40000), dict(w=2000, std_scale=1e12),
+               dict(w=2000, std_scale=-1e12), dict(w=65535, lo_thresh=100, std_scale=0.05)):
+        p = RollParams(**kw)
+        got = api.drna_roll_reads(extra, p)
+        okw = {k: v for k, v in kw.items() if not k.startswith("lim")}
+        for r, g in zip(extra, got):
+            f = ora.scale_outliers(r.astype(float), p.lim_low, p.lim_hi)
+            assert g == ora.drna_roll(f, ora.RollParams(**okw)), (kw, len(r))
+        monkeypatch.setenv("SK_TUNING", "1")
+        monkeypatch.setenv("SK_ROLL_TWO_KERNELS", "1")
+        assert api.drna_roll_reads(extra, p) == got, kw
+        monkeypatch.delenv("SK_ROLL_TWO_KERNELS")
+        monkeypatch.delenv("SK_TUNING")
+
+
+@pytest.mark.gpu
 def test_cli_signal_branch(gpu, tmp_path, capsys):
     """`dRNA_segmenter.py -s file.tsv [-w N]` prints what the reference's branch prints once its window is
     defined; --strict-compat keeps the reference's failure."""
