@@ -221,7 +221,7 @@ def timed(w, comm, steps, warmup):
         g = (C.c_int32 * 8)()
         check(w.L.sk_last_dtw_guard(g))
         prof["guard"] = {"premise_violations": int(g[0]), "audited_reads": int(g[1]), "audit_mismatches": int(g[2]),
-                         "image_rejects": int(g[3]), "exact_fallback": int(g[5])}
+                         "image_rejects": int(g[3]), "exact_fallback": int(g[5]), "second_windows": int(g[6])}
     w.own_elapsed = elapsed                                # (this rank's; the return value is the maximum over ranks)
     if comm is not None:
         elapsed = float(comm.allgather_host(np.array([elapsed], dtype=np.float64)).max())

@@ -386,7 +386,8 @@ def other_paths_block(a, L, main):
                 "workload": "%d reads x %d float64 pA samples vs the example model (%d points), medmad" % (RL, MLf, model163.size),
                 "value": RL / secs, "unit": "reads/s", "ms_per_step": secs * 1e3,
                 "kernel_ms": {"prep": ev[0], "dtw": ev[1]},
-                "guard": {"premise_violations": int(g[0]), "audited_reads": int(g[1]), "audit_mismatches": int(g[2])},
+                "guard": {"premise_violations": int(g[0]), "audited_reads": int(g[1]), "audit_mismatches": int(g[2]),
+                          "second_windows": int(g[6])},
                 "roofline": {"bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
                              "prep_kernel_frac": (alg / (ev[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ev[0] > 0 else None,

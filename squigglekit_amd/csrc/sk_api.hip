@@ -961,11 +961,20 @@ static int drna_roll_dev(sk_ctx *c, const int16_t *d_sig, int64_t stride, const 
     uint64_t *below = (uint64_t *)c->mask.p, *above = below + (size_t)nreads * (size_t)words;
     // one look (round 5): a workgroup per read, prefix sums in LDS -- rows of up to ~35 000 samples, w < 65 536
     if (sk_roll_one_lds(stride, p->w) && sk_tune("SK_ROLL_TWO_KERNELS") == nullptr && sk_tune("SK_DRNA_STEP") == nullptr) {
+        // ... or as a stream, a wavefront per read with certified thresholds (windows of up to 12 000 samples)
+        const bool stream = sk_roll_stream_ok(stride, p->w, lo, hi) && sk_tune("SK_ROLL_ONE_LOOK") == nullptr;
+        if (stream && (rc = sk_reserve(c, &c->misc, ((size_t)nreads + 2) * sizeof(int32_t)))) return rc;
         SK_HIP(hipEventRecord(c->ev[0], c->stream));
-        if ((rc = sk_launch_roll_one(c, d_sig, stride, d_len, nreads, lo, hi, p->w, p->std_scale, (sk_prep *)c->prep.p,
-                                     below, above))) return rc;
+        if (stream)
+            rc = sk_launch_roll_stream(c, d_sig, stride, d_len, nreads, lo, hi, p->w, p->std_scale, (sk_prep *)c->prep.p,
+                                       below, above, (int32_t *)c->misc.p);
+        else
+            rc = sk_launch_roll_one(c, d_sig, stride, d_len, nreads, lo, hi, p->w, p->std_scale, (sk_prep *)c->prep.p,
+                                    below, above);
+        if (rc) return rc;
         SK_HIP(hipEventRecord(c->ev[1], c->stream));
-        if ((rc = sk_launch_roll_walk(c, below, above, (const sk_prep *)c->prep.p, nreads, p, d_xy, d_found))) return rc;
+        if ((rc = sk_launch_roll_walk(c, below, stream ? below + 1 : above, (const sk_prep *)c->prep.p, nreads, p, d_xy,
+                                      d_found, stream ? words : 0))) return rc;
         c->ev_valid = true;
         return SK_OK;
     }

@@ -194,13 +194,17 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
 struct sk_roll_params;
 // comp / prep as left by sk_launch_prep_i16; psum: nreads * (stride + 1) int64 scratch; masks: two
 // transposed bit masks (t < bot, t > bot), `words` words per read each, word wi of read r at [wi * nreads + r]
+bool sk_roll_stream_ok(int64_t stride, int32_t w, int32_t lo, int32_t hi);   // can the streaming kernel take these rows?
+int sk_launch_roll_stream(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads, int32_t lo,
+                          int32_t hi, int32_t w, double std_scale, sk_prep *d_prep, uint64_t *d_below, uint64_t *d_above,
+                          int32_t *d_redo /* [nreads + 2] */);
 size_t sk_roll_one_lds(int64_t stride, int32_t w);      // LDS of the one-look kernel for these rows (0: they do not fit)
 int sk_launch_roll_one(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads, int32_t lo,
                        int32_t hi, int32_t w, double std_scale, sk_prep *d_prep, uint64_t *d_below, uint64_t *d_above);
 int sk_launch_roll_stats(sk_ctx *c, const int16_t *d_comp, int64_t stride, sk_prep *d_prep, int32_t nreads,
                          int32_t w, double std_scale, int64_t *d_psum, uint64_t *d_below, uint64_t *d_above);
 int sk_launch_roll_walk(sk_ctx *c, const uint64_t *d_below, const uint64_t *d_above, const sk_prep *d_prep,
-                        int32_t nreads, const sk_roll_params *p, int32_t *d_xy, int32_t *d_found);
+                        int32_t nreads, const sk_roll_params *p, int32_t *d_xy, int32_t *d_found, int64_t row_words = 0);
 
 // ---- segmenter, streaming path (sk_segstat.hip) ----
 int  sk_segment_fast_row16(int64_t stride);

@@ -1273,7 +1273,8 @@ __device__ double roll_numpy_sum(int n, Scratch *sc, RollShared *rs, Term term)
 __global__ __launch_bounds__(ROLL_NT)
 void k_roll_one(const int16_t *__restrict__ sig, int64_t stride, const int32_t *__restrict__ len, int nreads,
                 int lo, int hi, int w, double std_scale, int vec_ok, sk_prep *__restrict__ prep,
-                uint64_t *__restrict__ below, uint64_t *__restrict__ above, int64_t mask_rows)
+                uint64_t *__restrict__ below, uint64_t *__restrict__ above, int64_t mask_rows, int64_t read_stride,
+                const int32_t *__restrict__ list, const int32_t *__restrict__ list_count)
 {
     extern __shared__ __align__(16) unsigned char roll_lds[];
     Scratch *sc = (Scratch *)roll_lds;
@@ -1285,11 +1286,15 @@ void k_roll_one(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
 
     // A persistent workgroup (the LDS leaves room for one or two per CU, so nothing else hides a read's first load or
     // the launch of the next workgroup): the first 16 bytes of the NEXT read are requested before this read's statistics.
-    int r = blockIdx.x;
-    int M = r < nreads ? row_len(r) : 0;
+    // (list: the reads k_roll_stream could not certify; otherwise every read of the batch)
+    const int total = list ? min(*list_count, nreads) : nreads;
+    auto read_of = [&](int k) -> int { return list ? list[k] : k; };
+    int k = blockIdx.x;
+    int r = k < total ? read_of(k) : 0;
+    int M = k < total ? row_len(r) : 0;
     uint4 qn = make_uint4(0u, 0u, 0u, 0u);
-    if (r < nreads && vec_ok && tid * 8 + 8 <= M) qn = *(const uint4 *)(sig + (int64_t)r * stride + tid * 8);
-    for (; r < nreads; r += gridDim.x) {
+    if (k < total && vec_ok && tid * 8 + 8 <= M) qn = *(const uint4 *)(sig + (int64_t)r * stride + tid * 8);
+    for (; k < total; k += gridDim.x) {
         const int16_t *row = sig + (int64_t)r * stride;
 
         // ---- 1. filter, compaction, prefix sums (wrapping uint32: w < 65 536, their differences do not wrap)
@@ -1337,9 +1342,10 @@ void k_roll_one(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
             scarry += (unsigned)ts;
         }
         const int n = ccarry;
-        const int rn = r + gridDim.x;
-        int Mn = 0;
-        if (rn < nreads) {
+        const int kn = k + gridDim.x;
+        int rn = 0, Mn = 0;
+        if (kn < total) {
+            rn = read_of(kn);
             Mn = row_len(rn);
             if (vec_ok && tid * 8 + 8 <= Mn) qn = *(const uint4 *)(sig + (int64_t)rn * stride + tid * 8);
         }
@@ -1399,13 +1405,255 @@ void k_roll_one(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
             }
             const unsigned long long bl = __ballot(lt), ba = __ballot(gt);
             if (lane == 0 && i < n) {
-                below[(int64_t)(i >> 6) * mask_rows + r] = bl;
-                above[(int64_t)(i >> 6) * mask_rows + r] = ba;
+                below[(int64_t)(i >> 6) * mask_rows + (int64_t)r * read_stride] = bl;     // (word stride, read stride)
+                above[(int64_t)(i >> 6) * mask_rows + (int64_t)r * read_stride] = ba;
             }
         }
-        M = Mn;
+        M = Mn; r = rn;
         lds_barrier();                                       // (the next read writes P and the thresholds)
     }
+}
+
+// ---- ... and as a stream (round 5): a wavefront per read, certified thresholds, no numpy-order sum -------------------
+// The branch uses mn and std of the rolling mean for ONE thing: bot = mn - std * std_scale, compared with every t
+// (`t < bot`, `t > bot`, dRNA_segmenter.py:297-302).  t = RN(S / w) is monotone in the integer window sum S, so the
+// comparisons are two integer thresholds on S (k_roll_one, step 3) -- and those only move when bot crosses one of the
+// values k / w, which are 1 / w apart, while everything numpy's order of summation can do to bot is 10^-11.  So, as the
+// segmenter does for its statistics (sk_segstat.hip): bot from EXACT integer sums (sum S, sum S^2: one streaming sweep
+// with a few registers of state), a bound `delta` on how far the reference's floating-point value can be from it
+// (roll_bot_delta: depth of numpy's summation tree times the unit roundoff times the magnitudes involved, doubled), the
+// thresholds at bot - delta and at bot + delta; if they agree the masks are certified, if not (bot * w within ~10^-7 of
+// an integer: about one read in ten million) the read goes on a list for k_roll_one, which computes in numpy's order.
+// A sweep rebuilds the prefix sums tile by tile (512 raw samples, a lane takes 8, one wave scan, no barrier) into a ring
+// of w + 576 entries in LDS (12 KB at w = 2 000: thirteen reads in flight per CU) and consumes the window sums 64
+// outputs at a time.  Sweep 1: n, sum S, sum S^2.  Sweep 2 (the read comes from L2 the second time): the masks.
+struct RollStreamArgs {
+    const int16_t *sig; int64_t stride; const int32_t *len; int nreads;
+    int lo, hi, w, vec_ok, ring;
+    double std_scale, amax, delta_scale;
+    sk_prep *prep; uint64_t *below, *above; int64_t mask_rows, read_stride;     // word stride, read stride of the masks
+    int32_t *redo;                                           // [0] count, [2 ..] reads for k_roll_one
+};
+
+// How far the reference's bot (pandas nanops on the float64 rolling mean: numpy pairwise sums, ddof = 1) can lie from
+// the one computed from exact sums.  u = 2^-53; D bounds the depth of any of numpy's summation trees over n terms
+// (16 serial adds per accumulator, 3 to merge the eight, <= 7 levels, one add per 8192-chunk); A >= |t|.
+//   mn:  |fl(sum t) / cnt - mean| <= (D + 3) u A              (t itself is rounded: + u A, the division: + u A)
+//   std: the squares are summed about the ROUNDED mean: sqrt(var + cnt/(cnt-1) em^2) - sd <= 1.5 em; rounded t: 1.5 u A;
+//        differences, squares, sum, division, root: (D + 8) u relative
+//   bot: two more roundings.  All of it doubled.
+__device__ __forceinline__ double roll_bot_delta(int n, double amax, double mn, double sd, double sc)
+{
+    const double u = 1.1102230246251565e-16, D = 40.0 + (double)(n >> 13), asc = fabs(sc);
+    const double em = (D + 3.0) * u * amax;
+    return 2.0 * (em * (1.0 + 1.5 * asc) + asc * ((D + 8.0) * u * sd + 1.5 * u * amax) + 12.0 * u * (fabs(mn) + 2.0 * asc * sd));
+}
+
+__global__ __launch_bounds__(64)
+void k_roll_stream(const RollStreamArgs a)
+{
+    extern __shared__ unsigned roll_ring[];                  // ring of prefix sums
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x;
+    const int RS = a.ring, w = a.w;
+    int M = a.len[r];
+    M = M < 0 ? 0 : (M > a.stride ? (int)a.stride : M);
+    const int16_t *row = a.sig + (int64_t)r * a.stride;
+    auto wrap = [&](unsigned m) -> unsigned { return min(m, m - (unsigned)RS); };        // m < 2 RS
+
+    // one sweep over the raw samples; consume(done, slot of P[done + 1], g) is called for g <= 8 whole groups of 64 outputs
+    // from `done` on, consume_tail(done, slot, avail) for the last avail < 64
+    auto sweep = [&](auto &&consume, auto &&consume_tail) -> int {
+        int ncar = 0, done = 0;
+        unsigned scar = 0u;
+        unsigned wslot = 1u;                                 // slot of P[ncar + 1] (uniform; P[0] = 0 sits in slot 0)
+        unsigned dslot = 1u;                                 // slot of P[done + 1]
+        if (lane == 0) roll_ring[0] = 0u;
+        // four tiles (2 048 samples, 32 bytes a lane in flight beyond the ones being scanned): with one tile ahead the chip
+        // has 3 MB outstanding, and 8 TB/s times the memory's latency is five times that
+        uint4 qa[4], qb[4];
+        auto fetch = [&](int b, uint4 (&q)[4]) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int i0 = b + t * 512 + lane * 8;
+                q[t] = make_uint4(0u, 0u, 0u, 0u);
+                if (a.vec_ok && i0 + 8 <= M) q[t] = *(const uint4 *)(row + i0);
+            }
+        };
+        auto tile = [&](int base, const uint4 q) {
+            const int i0 = base + lane * 8;
+            int v[8];
+            if (a.vec_ok && i0 + 8 <= M) {
+                const unsigned qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) { v[2 * k] = (int)(short)(qq[k] & 0xffffu); v[2 * k + 1] = (int)(short)(qq[k] >> 16); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = (i0 + k < M) ? (int)row[i0 + k] : a.lo;
+            }
+            int c = 0, s = 0;
+            unsigned keep = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool kept = v[k] > a.lo && v[k] < a.hi;
+                c += kept ? 1 : 0;
+                s += kept ? v[k] : 0;
+                keep |= (kept ? 1u : 0u) << k;
+            }
+            // (nothing dropped in this tile -- the usual case: the counts are known, and a lane's 8 entries go out in a straight
+            // line with immediate offsets unless the ring's end falls among them)
+            const bool allkept = __ballot(keep != 0xffu) == 0ull;
+            const int inc_s = wave_incl_scan(s, lane);
+            const int ts = __builtin_amdgcn_readlane(inc_s, 63);
+            int tc = 512, excl_c = 8 * lane;
+            if (!allkept) {
+                const int inc_c = wave_incl_scan(c, lane);
+                tc = __builtin_amdgcn_readlane(inc_c, 63);
+                excl_c = inc_c - c;
+            }
+            unsigned slot = wrap(wslot + (unsigned)excl_c);                // (excl_c <= 504 < RS)
+            unsigned run = scar + (unsigned)(inc_s - s);
+            if (allkept && __ballot(slot + 7u >= (unsigned)RS) == 0ull) {
+                unsigned *p = roll_ring + slot;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { run += (unsigned)v[k]; p[k] = run; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if ((keep >> k) & 1u) {
+                        run += (unsigned)v[k];
+                        roll_ring[slot] = run;
+                        slot = wrap(slot + 1u);
+                    }
+            }
+            ncar += tc;
+            scar += (unsigned)ts;
+            wslot = wrap(wslot + (unsigned)tc);
+            // whole groups of 64 outputs that are ready: up to 8, their LDS reads issued together
+            const int g = (ncar - done) >> 6;
+            if (g > 0) {
+                consume(done, dslot, g);
+                done += 64 * g;
+                dslot = wrap(dslot + 64u * (unsigned)g);
+            }
+        };
+        fetch(0, qa);
+        for (int base = 0; base < M; base += 2048) {
+            fetch(base + 2048, qb);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (base + t * 512 < M) tile(base + t * 512, qa[t]);      // (uniform)
+                qa[t] = qb[t];
+            }
+        }
+        if (done < ncar) consume_tail(done, dslot, ncar - done);
+        return ncar;
+    };
+    // window sum of output i = done + lane: P[i + 1] - P[i + 1 - w]   (i < w - 1: the caller does not use it)
+    const unsigned back = (unsigned)(RS - w);                // slot(i + 1 - w) = slot(i + 1) + RS - w (mod RS); w < RS
+    auto wsum = [&](unsigned dslot) -> int {                 // dslot < 2 RS
+        const unsigned sa = wrap(wrap(dslot) + (unsigned)lane);
+        const unsigned sb = wrap(sa + back);
+        return (int)(roll_ring[sa] - roll_ring[sb]);
+    };
+    // the window sums of up to 8 groups, all loads before any use (groups beyond g read stale entries: not used); when
+    // neither stretch of the ring wraps, two addresses and sixteen loads with immediate offsets
+    auto wsums = [&](unsigned dslot, int (&S)[8]) {
+        const unsigned db = wrap(dslot + back);              // (uniform)
+        if (dslot + 575u < (unsigned)RS && db + 575u < (unsigned)RS) {
+            const unsigned *pa = roll_ring + dslot + lane, *pb = roll_ring + db + lane;
+#pragma unroll
+            for (int k = 0; k < 8; k++) S[k] = (int)(pa[64 * k] - pb[64 * k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) S[k] = wsum(dslot + 64u * (unsigned)k);
+        }
+    };
+
+    // ---- sweep 1: exact sums
+    long long accS = 0;
+    unsigned long long accQ = 0ull;
+    auto add1 = [&](int S) { accS += (long long)S; accQ += (unsigned long long)((long long)S * (long long)S); };
+    const int n = sweep([&](int done, unsigned dslot, int g) {
+        int S[8];
+        wsums(dslot, S);
+#pragma unroll
+        for (int k = 0; k < 8; k++) add1((k < g && done + 64 * k + lane >= w - 1) ? S[k] : 0);
+    }, [&](int done, unsigned dslot, int avail) {
+        const int S = wsum(dslot);
+        add1((lane < avail && done + lane >= w - 1) ? S : 0);
+    });
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { accS += __shfl_xor(accS, d); accQ += __shfl_xor(accQ, d); }
+
+    // ---- bot from the exact sums, its uncertainty, the thresholds at both ends
+    const long long cnt = (n >= w) ? (long long)n - w + 1 : 0;
+    const double dw = (double)w;
+    long long thr_lt = LLONG_MIN, thr_gt = LLONG_MAX;        // NaN bot: no bit in either mask
+    double mn = __builtin_nan(""), sd = __builtin_nan(""), bot = __builtin_nan("");
+    bool certified = true;
+    if (cnt >= 1) mn = (double)accS / ((double)cnt * dw);
+    if (cnt >= 2 && a.std_scale == a.std_scale) {
+        // cnt sum S^2 - (sum S)^2 in 128 bits (exact, >= 0), then one conversion
+        const unsigned long long ucnt = (unsigned long long)cnt, as = (unsigned long long)(accS < 0 ? -accS : accS);
+        const unsigned long long hi1 = __umul64hi(ucnt, accQ), lo1 = ucnt * accQ;
+        const unsigned long long hi2 = __umul64hi(as, as), lo2 = as * as;
+        const unsigned long long lo = lo1 - lo2, hi = hi1 - hi2 - (lo1 < lo2 ? 1ull : 0ull);
+        const double num = (double)hi * 18446744073709551616.0 + (double)lo;
+        sd = sqrt(num / ((double)cnt * (double)(cnt - 1) * dw * dw));
+        bot = mn - sd * a.std_scale;
+        const double delta = a.delta_scale * roll_bot_delta(n, a.amax, mn, sd, a.std_scale);
+        const double b0 = bot - delta, b1 = bot + delta;
+        const double x0 = b0 * dw, x1 = b1 * dw;
+        if (!(delta == delta) || !(x0 > -4.0e18) || !(x1 < 4.0e18)) certified = false;
+        else {
+            // lanes 0-7 judge the eight integers around b0 w against b0, lanes 8-15 those around b1 w against b1
+            const double bb = (lane & 8) ? b1 : b0;
+            const long long s0 = (long long)floor((lane & 8) ? x1 : x0);
+            const double t = (double)(s0 - 3 + (lane & 7)) / dw;
+            const unsigned long long mlt = __ballot(lane < 16 && t < bb), mgt = __ballot(lane < 16 && t > bb);
+            const long long s00 = __shfl(s0, 0), s01 = __shfl(s0, 8);
+            const long long lt0 = s00 - 3 + __popcll(mlt & 0xffull), lt1 = s01 - 3 + __popcll(mlt & 0xff00ull);
+            const long long gt0 = s00 + 4 - __popcll(mgt & 0xffull), gt1 = s01 + 4 - __popcll(mgt & 0xff00ull);
+            certified = (lt0 == lt1) && (gt0 == gt1);
+            thr_lt = lt0; thr_gt = gt0;
+        }
+    }
+    if (lane == 0) {
+        sk_prep pr;
+        pr.n = n; pr.flags = n > 0 ? 0 : SK_FLAG_EMPTY;
+        pr.center = mn; pr.scale = sd; pr.top = bot; pr.bot = bot;   // (diagnostic values: within delta of the reference's)
+        a.prep[r] = pr;
+        if (!certified) a.redo[2 + atomicAdd(a.redo, 1)] = r;
+    }
+    if (!certified) return;                                  // k_roll_one writes this read's masks
+
+    // ---- sweep 2: the masks
+    unsigned long long *brow = (unsigned long long *)a.below + (int64_t)r * a.read_stride;
+    unsigned long long *arow = (unsigned long long *)a.above + (int64_t)r * a.read_stride;
+    (void)sweep([&](int done, unsigned dslot, int g) {
+        int S[8];
+        wsums(dslot, S);
+        unsigned long long myb = 0ull, mya = 0ull;           // lane k keeps word k of this batch
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool valid = done + 64 * k + lane >= w - 1;
+            const unsigned long long bl = __ballot(valid && (long long)S[k] < thr_lt), ba = __ballot(valid && (long long)S[k] > thr_gt);
+            if (lane == k) { myb = bl; mya = ba; }
+        }
+        if (lane < g) {
+            brow[(int64_t)((done >> 6) + lane) * a.mask_rows] = myb;
+            arow[(int64_t)((done >> 6) + lane) * a.mask_rows] = mya;
+        }
+    }, [&](int done, unsigned dslot, int avail) {
+        const int S = wsum(dslot);
+        const bool valid = lane < avail && done + lane >= w - 1;
+        const unsigned long long bl = __ballot(valid && (long long)S < thr_lt), ba = __ballot(valid && (long long)S > thr_gt);
+        if (lane == 0) {
+            brow[(int64_t)(done >> 6) * a.mask_rows] = bl;
+            arow[(int64_t)(done >> 6) * a.mask_rows] = ba;
+        }
+    });
 }
 
 } // namespace
@@ -1433,7 +1681,55 @@ int sk_launch_roll_one(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
     const long long g = (long long)c->num_cu * per_cu;
     const int grid = g > nreads ? nreads : (int)g;
     hipLaunchKernelGGL(k_roll_one, dim3(grid), dim3(ROLL_NT), lds, c->stream, d_sig, stride, d_len, nreads, lo, hi, w,
-                       std_scale, vec_ok, d_prep, d_below, d_above, (int64_t)nreads);
+                       std_scale, vec_ok, d_prep, d_below, d_above, (int64_t)nreads, (int64_t)1, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
+}
+
+// can the streaming kernel take this call?  (the ring fits a wavefront's share of LDS; the sums of window sums and of
+// their squares stay inside 64 bits; the reads it cannot certify fit k_roll_one)
+bool sk_roll_stream_ok(int64_t stride, int32_t w, int32_t lo, int32_t hi)
+{
+    if (!sk_roll_one_lds(stride, w) || w > 12000) return false;
+    const double amax = fmax(fabs((double)lo), fabs((double)hi));
+    const double smax = amax * (double)w;
+    return smax < 2147483000.0 && smax * smax * (double)stride < 9.0e18;
+}
+
+int sk_launch_roll_stream(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads, int32_t lo,
+                          int32_t hi, int32_t w, double std_scale, sk_prep *d_prep, uint64_t *d_below, uint64_t *d_above,
+                          int32_t *d_redo)
+{
+    if (nreads <= 0) return SK_OK;
+    (void)d_above;                                           // (the two masks are interleaved in d_below's buffer, see below)
+    RollStreamArgs a;
+    a.sig = d_sig; a.stride = stride; a.len = d_len; a.nreads = nreads; a.lo = lo; a.hi = hi; a.w = w;
+    a.vec_ok = (((uintptr_t)d_sig & 15) == 0 && (stride % 8) == 0) ? 1 : 0;
+    a.ring = (w + 576 + 7) & ~7;
+    a.std_scale = std_scale; a.amax = fmax(fabs((double)lo), fabs((double)hi));
+    a.delta_scale = 1.0;
+    if (const char *e = sk_tune("SK_ROLL_DELTA_SCALE")) { const double v = atof(e); if (v > 0.0) a.delta_scale = v; }
+    // masks read-major here, the two interleaved ([read][word]{below, above}: a wavefront writes its read's words one
+    // after the other, and the walk's two loads of a step fall into one line); word-major, as the other kernels lay them
+    // out, every 8-byte word a wavefront writes is a line of its own
+    a.prep = d_prep; a.below = d_below; a.above = d_below + 1; a.mask_rows = 2; a.read_stride = 2 * ((stride + 63) / 64);
+    a.redo = d_redo;
+    const size_t ring_lds = ((size_t)a.ring + 8) * sizeof(unsigned);
+    SK_HIP(hipMemsetAsync(d_redo, 0, 2 * sizeof(int32_t), c->stream));
+    if (ring_lds > 64 * 1024)
+        SK_HIP(hipFuncSetAttribute((const void *)k_roll_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds));
+    hipLaunchKernelGGL(k_roll_stream, dim3(nreads), dim3(64), ring_lds, c->stream, a);
+    SK_HIP(hipGetLastError());
+    // the reads it could not certify (normally none): numpy's order, k_roll_one over the list
+    const size_t lds = sk_roll_one_lds(stride, w);
+    if (lds > 64 * 1024)
+        SK_HIP(hipFuncSetAttribute((const void *)k_roll_one, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const bool all_listed = a.delta_scale > 1e6;             // (tests: everything is redone -- give the list the whole chip)
+    const int grid = all_listed ? (c->num_cu < nreads ? c->num_cu : nreads) : (nreads < 32 ? nreads : 32);
+    hipLaunchKernelGGL(k_roll_one, dim3(grid), dim3(ROLL_NT), lds, c->stream, d_sig, stride, d_len, nreads, lo, hi, w,
+                       std_scale, a.vec_ok, d_prep, a.below, a.above, a.mask_rows, a.read_stride, (const int32_t *)(d_redo + 2),
+                       (const int32_t *)d_redo);
     SK_HIP(hipGetLastError());
     return SK_OK;
 }

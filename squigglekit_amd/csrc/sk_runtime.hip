@@ -93,6 +93,8 @@ static const sk_tunable SK_TUNABLES[] = {
     {"SK_WALK_NOJUMP",        "1",           "segmenter walk: every run is hopped through, no jumps between the stretches of quiet entries"},
     {"SK_DRNA_STEP",          "1",           "dRNA_segmenter, both branches: the per-sample scans instead of the scans by runs / by transitions"},
     {"SK_ROLL_TWO_KERNELS",   "1",           "dRNA_segmenter rolling-mean branch: filter kernel + prefix sums through HBM instead of the one-look kernel (prefix sums in LDS)"},
+    {"SK_ROLL_ONE_LOOK",      "1",           "dRNA_segmenter rolling-mean branch: the workgroup-per-read kernel in numpy's order for every read instead of the streaming kernel with certified thresholds"},
+    {"SK_ROLL_DELTA_SCALE",   "1e13",        "dRNA_segmenter rolling-mean branch: multiplier of the certification margin (large: every read is redone in numpy's order)"},
     {"SK_INGEST_MB",          "1 4",         "sub-batch size of the host entry points in MB"},
     {"SK_F64_OLD",            "1",           "float64 reads: numpy-order statistics kernel for every read"},
     {"SK_F64_LONG_LOOKS",     "1",           "float64 reads of 4 097 .. 40 960 samples: the window-by-window kernel (three to five looks at a read) instead of the workgroup-per-read one (one look)"},

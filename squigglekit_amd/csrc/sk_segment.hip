@@ -326,7 +326,7 @@ struct RollWalk { int seg_dist, hi_thresh, lo_thresh, shift; };
 
 template <bool BY_RUNS>
 __global__ __launch_bounds__(64)
-void k_roll_walk(const uint64_t *__restrict__ below, const uint64_t *__restrict__ above, int64_t mask_rows,
+void k_roll_walk(const uint64_t *__restrict__ below, const uint64_t *__restrict__ above, int64_t mask_rows, int64_t read_stride,
                  const sk_prep *__restrict__ prep, int nreads, RollWalk p,
                  int32_t *__restrict__ xy, int32_t *__restrict__ found)
 {
@@ -340,7 +340,7 @@ void k_roll_walk(const uint64_t *__restrict__ below, const uint64_t *__restrict_
         if (!done && len <= p.hi_thresh && len >= p.lo_thresh) { fx = sa - p.shift; fy = sb - p.shift; done = true; }
     };
     for (int wi = 0; wi * 64 < n; wi++) {
-        const uint64_t B = below[(int64_t)wi * mask_rows + r], A = above[(int64_t)wi * mask_rows + r];
+        const uint64_t B = below[(int64_t)wi * mask_rows + (int64_t)r * read_stride], A = above[(int64_t)wi * mask_rows + (int64_t)r * read_stride];
         if (!begin && B == 0ull) continue;                    // nothing opens in this word
         const int lim = min(64, n - wi * 64);
         if (BY_RUNS) {
@@ -397,18 +397,21 @@ void k_roll_walk(const uint64_t *__restrict__ below, const uint64_t *__restrict_
 } // namespace
 
 int sk_launch_roll_walk(sk_ctx *c, const uint64_t *d_below, const uint64_t *d_above, const sk_prep *d_prep,
-                        int32_t nreads, const sk_roll_params *p, int32_t *d_xy, int32_t *d_found)
+                        int32_t nreads, const sk_roll_params *p, int32_t *d_xy, int32_t *d_found, int64_t row_words)
 {
+    // row_words: 0 -- the masks are word-major ([word][read]); otherwise read-major rows of that many words with the two
+    // masks interleaved, d_above = d_below + 1 (k_roll_stream)
     if (nreads <= 0) return SK_OK;
+    const int64_t ws = row_words ? 2 : (int64_t)nreads, rs = row_words ? 2 * row_words : 1;
     RollWalk wp;
     wp.seg_dist = p->seg_dist; wp.hi_thresh = p->hi_thresh; wp.lo_thresh = p->lo_thresh; wp.shift = p->shift;
     const int grid = (nreads + 63) / 64;
     SK_HIP(hipEventRecord(c->ev[2], c->stream));
     if (sk_tune("SK_DRNA_STEP") == nullptr)
-        hipLaunchKernelGGL(k_roll_walk<true>, dim3(grid), dim3(64), 0, c->stream, d_below, d_above, (int64_t)nreads, d_prep,
+        hipLaunchKernelGGL(k_roll_walk<true>, dim3(grid), dim3(64), 0, c->stream, d_below, d_above, ws, rs, d_prep,
                            nreads, wp, d_xy, d_found);
     else
-        hipLaunchKernelGGL(k_roll_walk<false>, dim3(grid), dim3(64), 0, c->stream, d_below, d_above, (int64_t)nreads, d_prep,
+        hipLaunchKernelGGL(k_roll_walk<false>, dim3(grid), dim3(64), 0, c->stream, d_below, d_above, ws, rs, d_prep,
                            nreads, wp, d_xy, d_found);
     SK_HIP(hipGetLastError());
     SK_HIP(hipEventRecord(c->ev[3], c->stream));

@@ -152,10 +152,11 @@ def test_gpu_rolling_branch(gpu, ora):
 
 @pytest.mark.gpu
 def test_gpu_rolling_branch_one_look_kernel(gpu, ora, monkeypatch):
-    """Rows of up to ~35 000 samples take the one-look kernel (k_roll_one: prefix sums in LDS, full 8192-chunks summed
-    side by side, integer thresholds instead of the division in the mask sweep).  Against the oracle over parameter
-    corners and read lengths around the 8192-chunk boundaries of numpy's summation, and record for record against the
-    two-kernel path."""
+    """Rows of up to ~35 000 samples take the streaming kernel (k_roll_stream: a wavefront per read, bot from exact
+    integer sums, thresholds certified against everything numpy's summation order can do to it) with k_roll_one (prefix
+    sums in LDS, numpy's order, integer thresholds) for the reads it cannot certify and for windows above 12 000.
+    Against the oracle over parameter corners and read lengths around the 8192-chunk boundaries of numpy's summation,
+    and record for record against each other and the two-kernel path."""
     from squigglekit_amd import api, synth
     from squigglekit_amd._lib import RollParams
     reads, _ = _roll_reads()
@@ -179,10 +180,13 @@ def test_gpu_rolling_branch_one_look_kernel(gpu, ora, monkeypatch):
         for r, g in zip(extra, got):
             f = ora.scale_outliers(r.astype(float), p.lim_low, p.lim_hi)
             assert g == ora.drna_roll(f, ora.RollParams(**okw)), (kw, len(r))
+        # default: the streaming kernel with certified thresholds (windows of up to 12 000 samples), its uncertifiable
+        # reads through k_roll_one; then k_roll_one for every read, every read through the redo list, the two-kernel path
         monkeypatch.setenv("SK_TUNING", "1")
-        monkeypatch.setenv("SK_ROLL_TWO_KERNELS", "1")
-        assert api.drna_roll_reads(extra, p) == got, kw
-        monkeypatch.delenv("SK_ROLL_TWO_KERNELS")
+        for key, val in (("SK_ROLL_ONE_LOOK", "1"), ("SK_ROLL_DELTA_SCALE", "1e13"), ("SK_ROLL_TWO_KERNELS", "1")):
+            monkeypatch.setenv(key, val)
+            assert api.drna_roll_reads(extra, p) == got, (kw, key)
+            monkeypatch.delenv(key)
         monkeypatch.delenv("SK_TUNING")
 
 

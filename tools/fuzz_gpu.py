@@ -51,6 +51,7 @@ def main():
         ql = [None, "8", "16", "64"][int(rng.integers(4))]
         for key, val in (("SK_DTW_QL", ql), ("SK_DTW_NOFUSE", "1" if rng.random() < 0.3 else None),
                          ("SK_DTW_NO_EARLY", "1" if rng.random() < 0.3 else None),
+                         ("SK_DTW_NO_SIBLINGS", "1" if rng.random() < 0.2 else None),  # two clusters: exact pass / second window
                          ("SK_DTW_SORT_MIN", "1" if rng.random() < 0.5 else None)):     # window passes in sorted order
             if val is None:
                 os.environ.pop(key, None)
@@ -174,12 +175,22 @@ def main():
                     bad += 1
                     print("DRNA mismatch n=%d %s step=%s" % (len(x), dkw, os.environ.get("SK_DRNA_STEP")))
             rkw = [dict(), dict(w=int(rng.choice([3, 64, 999, 2000, 5000]))),
-                   dict(w=800, lo_thresh=200, seg_dist=int(rng.choice([1, 300, 5000])), std_scale=0.25)][int(rng.integers(3))]
+                   dict(w=800, lo_thresh=200, seg_dist=int(rng.choice([1, 300, 5000])), std_scale=0.25),
+                   dict(w=int(rng.integers(1, 9000)), lo_thresh=int(rng.choice([5, 500, 2000])),
+                        std_scale=float(rng.choice([-0.5, 0.0, 0.1, 0.5, 2.0])))][int(rng.integers(4))]
+            # (round 5: rows of up to ~35 000 samples take the one-look kernel, k_roll_one; the two-kernel path on request)
+            rsw = rng.random()
+            rkey = "SK_ROLL_TWO_KERNELS" if rsw < 0.12 else "SK_ROLL_ONE_LOOK" if rsw < 0.3 else \
+                   "SK_ROLL_DELTA_SCALE" if rsw < 0.4 else None
+            if rkey:
+                os.environ[rkey] = "1e13" if rkey == "SK_ROLL_DELTA_SCALE" else "1"
             for x, g in zip(dreads, api.drna_roll_reads(dreads, RollParams(**rkw))):
                 if g != ora.drna_roll(ora.scale_outliers(x.astype(float), 0, 1200), ora.RollParams(**rkw)):
                     bad += 1
-                    print("DRNA ROLL mismatch n=%d %s step=%s" % (len(x), rkw, os.environ.get("SK_DRNA_STEP")))
+                    print("DRNA ROLL mismatch n=%d %s step=%s switch=%s" % (len(x), rkw, os.environ.get("SK_DRNA_STEP"), rkey))
             os.environ.pop("SK_DRNA_STEP", None)
+            for key in ("SK_ROLL_TWO_KERNELS", "SK_ROLL_ONE_LOOK", "SK_ROLL_DELTA_SCALE"):
+                os.environ.pop(key, None)
     print("fuzz: %d rounds, %d mismatching configurations" % (rounds, bad))
     sys.exit(1 if bad else 0)
 
