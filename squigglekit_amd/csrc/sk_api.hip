@@ -960,9 +960,9 @@ static int drna_roll_dev(sk_ctx *c, const int16_t *d_sig, int64_t stride, const 
     if ((rc = sk_reserve(c, &c->mask, (size_t)nreads * (size_t)words * 2 * sizeof(uint64_t)))) return rc;
     uint64_t *below = (uint64_t *)c->mask.p, *above = below + (size_t)nreads * (size_t)words;
     // one look (round 5): a workgroup per read, prefix sums in LDS -- rows of up to ~35 000 samples, w < 65 536
-    if (sk_roll_one_lds(stride, p->w) && sk_tune("SK_ROLL_TWO_KERNELS") == nullptr && sk_tune("SK_DRNA_STEP") == nullptr) {
-        // ... or as a stream, a wavefront per read with certified thresholds (windows of up to 12 000 samples)
-        const bool stream = sk_roll_stream_ok(stride, p->w, lo, hi) && sk_tune("SK_ROLL_ONE_LOOK") == nullptr;
+    // ... or as a stream, a wavefront per read with certified thresholds (windows of up to 12 000 samples, rows of any length)
+    const bool stream = sk_roll_stream_ok(stride, p->w, lo, hi) && sk_tune("SK_ROLL_ONE_LOOK") == nullptr;
+    if ((stream || sk_roll_one_lds(stride, p->w)) && sk_tune("SK_ROLL_TWO_KERNELS") == nullptr && sk_tune("SK_DRNA_STEP") == nullptr) {
         if (stream && (rc = sk_reserve(c, &c->misc, ((size_t)nreads + 2) * sizeof(int32_t)))) return rc;
         SK_HIP(hipEventRecord(c->ev[0], c->stream));
         if (stream)

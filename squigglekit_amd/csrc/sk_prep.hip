@@ -1239,47 +1239,54 @@ __device__ double roll_numpy_sum(int n, Scratch *sc, RollShared *rs, Term term)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nfull = n / NPY_BUFSIZE, mlast = n % NPY_BUFSIZE;
     const int grp = tid >> 3, j = tid & 7;
-    for (int L = grp; L < nfull * 64; L += ROLL_NT / 8) {
-        const int s = L * PW_BLOCK;
-        double r = term(s + j);
-#pragma unroll 4
-        for (int i = 8; i < PW_BLOCK; i += 8) r += term(s + i + j);
-        r += dpp_shl_f64<1>(r);
-        r += dpp_shl_f64<2>(r);
-        r += dpp_shl_f64<4>(r);
-        if (j == 0) rs->leaf[L >> 6][L & 63] = r;
-    }
-    lds_barrier();
-    if (wv < nfull) {                                        // one wavefront per full chunk: parent = left + right, six levels
-        double v = rs->leaf[wv][lane];
-        v += dpp_shl_f64<1>(v);
-        v += dpp_shl_f64<2>(v);
-        v += dpp_shl_f64<4>(v);
-        v += dpp_shl_f64<8>(v);
-        v += __shfl_down(v, 16);
-        v += __shfl_down(v, 32);
-        if (lane == 0) rs->chunk[wv] = v;
-    }
-    lds_barrier();
     double res = 0.0;
-    for (int c = 0; c < nfull; c++) res += rs->chunk[c];
+    for (int c0 = 0; c0 < nfull; c0 += ROLL_MAXFULL) {       // (one round for a read that fits in LDS)
+        const int nb = min(ROLL_MAXFULL, nfull - c0);
+        for (int L = grp; L < nb * 64; L += ROLL_NT / 8) {
+            const int s = (c0 * 64 + L) * PW_BLOCK;
+            double r = term(s + j);
+#pragma unroll 4
+            for (int i = 8; i < PW_BLOCK; i += 8) r += term(s + i + j);
+            r += dpp_shl_f64<1>(r);
+            r += dpp_shl_f64<2>(r);
+            r += dpp_shl_f64<4>(r);
+            if (j == 0) rs->leaf[L >> 6][L & 63] = r;
+        }
+        lds_barrier();
+        if (wv < nb) {                                       // one wavefront per full chunk: parent = left + right, six levels
+            double v = rs->leaf[wv][lane];
+            v += dpp_shl_f64<1>(v);
+            v += dpp_shl_f64<2>(v);
+            v += dpp_shl_f64<4>(v);
+            v += dpp_shl_f64<8>(v);
+            v += __shfl_down(v, 16);
+            v += __shfl_down(v, 32);
+            if (lane == 0) rs->chunk[wv] = v;
+        }
+        lds_barrier();
+        for (int c = 0; c < nb; c++) res += rs->chunk[c];
+        lds_barrier();                                       // (rs->leaf / chunk are free for the next round / sum)
+    }
     if (mlast > 0 || nfull == 0)
         res += pairwise_chunk<true, ROLL_NT>(mlast, sc, [&](int i) { return term(nfull * NPY_BUFSIZE + i); });
-    else
-        lds_barrier();                                       // (rs->leaf / chunk are free for the next sum)
     return res;
 }
 
+// GLOBALP: the prefix sums of a row too long for LDS live in a scratch row of global memory, one per workgroup (only the
+// list of k_roll_stream's uncertifiable reads comes this way: a handful of reads in a hundred million)
+template <bool GLOBALP>
 __global__ __launch_bounds__(ROLL_NT)
 void k_roll_one(const int16_t *__restrict__ sig, int64_t stride, const int32_t *__restrict__ len, int nreads,
                 int lo, int hi, int w, double std_scale, int vec_ok, sk_prep *__restrict__ prep,
                 uint64_t *__restrict__ below, uint64_t *__restrict__ above, int64_t mask_rows, int64_t read_stride,
-                const int32_t *__restrict__ list, const int32_t *__restrict__ list_count)
+                const int32_t *__restrict__ list, const int32_t *__restrict__ list_count,
+                unsigned *__restrict__ gscratch, int64_t grow_words)
 {
     extern __shared__ __align__(16) unsigned char roll_lds[];
     Scratch *sc = (Scratch *)roll_lds;
     RollShared *rs = (RollShared *)(roll_lds + sizeof(Scratch));
-    unsigned *P = (unsigned *)(roll_lds + sizeof(Scratch) + sizeof(RollShared));
+    unsigned *P = GLOBALP ? gscratch + (int64_t)blockIdx.x * grow_words
+                          : (unsigned *)(roll_lds + sizeof(Scratch) + sizeof(RollShared));
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) { sc->tree_m = -1; P[0] = 0u; }
     auto row_len = [&](int r) -> int { const int m = len[r]; return m < 0 ? 0 : (m > stride ? (int)stride : m); };
@@ -1349,7 +1356,8 @@ void k_roll_one(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
             Mn = row_len(rn);
             if (vec_ok && tid * 8 + 8 <= Mn) qn = *(const uint4 *)(sig + (int64_t)rn * stride + tid * 8);
         }
-        lds_barrier();
+        if (GLOBALP) __syncthreads();                        // (the prefix sums are global stores of other wavefronts)
+        else lds_barrier();
 
         // ---- 2. numpy-order mean and std of the rolling mean (the expressions of k_roll_stats)
         const long long cnt = (n >= w) ? (long long)n - w + 1 : 0;
@@ -1410,7 +1418,8 @@ void k_roll_one(const int16_t *__restrict__ sig, int64_t stride, const int32_t *
             }
         }
         M = Mn; r = rn;
-        lds_barrier();                                       // (the next read writes P and the thresholds)
+        if (GLOBALP) __syncthreads();
+        else lds_barrier();                                  // (the next read writes P and the thresholds)
     }
 }
 
@@ -1673,16 +1682,16 @@ int sk_launch_roll_one(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
     const size_t lds = sk_roll_one_lds(stride, w);
     if (!lds) return sk_fail(SK_ERR_INVALID, "internal: the one-look rolling-mean kernel does not hold this read length");
     if (lds > 64 * 1024)
-        SK_HIP(hipFuncSetAttribute((const void *)k_roll_one, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SK_HIP(hipFuncSetAttribute((const void *)k_roll_one<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int vec_ok = (((uintptr_t)d_sig & 15) == 0 && (stride % 8) == 0) ? 1 : 0;
     int per_cu = (int)((160 * 1024) / (lds + 256));
     if (per_cu > 2) per_cu = 2;
     if (const char *e = sk_tune("SK_PREP_PERCU")) { int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }
     const long long g = (long long)c->num_cu * per_cu;
     const int grid = g > nreads ? nreads : (int)g;
-    hipLaunchKernelGGL(k_roll_one, dim3(grid), dim3(ROLL_NT), lds, c->stream, d_sig, stride, d_len, nreads, lo, hi, w,
+    hipLaunchKernelGGL(k_roll_one<false>, dim3(grid), dim3(ROLL_NT), lds, c->stream, d_sig, stride, d_len, nreads, lo, hi, w,
                        std_scale, vec_ok, d_prep, d_below, d_above, (int64_t)nreads, (int64_t)1, (const int32_t *)nullptr,
-                       (const int32_t *)nullptr);
+                       (const int32_t *)nullptr, (unsigned *)nullptr, (int64_t)0);
     SK_HIP(hipGetLastError());
     return SK_OK;
 }
@@ -1691,7 +1700,7 @@ int sk_launch_roll_one(sk_ctx *c, const int16_t *d_sig, int64_t stride, const in
 // their squares stay inside 64 bits; the reads it cannot certify fit k_roll_one)
 bool sk_roll_stream_ok(int64_t stride, int32_t w, int32_t lo, int32_t hi)
 {
-    if (!sk_roll_one_lds(stride, w) || w > 12000) return false;
+    if (w > 12000 || stride > (1 << 21)) return false;
     const double amax = fmax(fabs((double)lo), fabs((double)hi));
     const double smax = amax * (double)w;
     return smax < 2147483000.0 && smax * smax * (double)stride < 9.0e18;
@@ -1721,15 +1730,27 @@ int sk_launch_roll_stream(sk_ctx *c, const int16_t *d_sig, int64_t stride, const
         SK_HIP(hipFuncSetAttribute((const void *)k_roll_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds));
     hipLaunchKernelGGL(k_roll_stream, dim3(nreads), dim3(64), ring_lds, c->stream, a);
     SK_HIP(hipGetLastError());
-    // the reads it could not certify (normally none): numpy's order, k_roll_one over the list
+    // the reads it could not certify (normally none): numpy's order, k_roll_one over the list -- prefix sums in LDS when
+    // the rows fit there, in a scratch row per workgroup otherwise
     const size_t lds = sk_roll_one_lds(stride, w);
-    if (lds > 64 * 1024)
-        SK_HIP(hipFuncSetAttribute((const void *)k_roll_one, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const bool all_listed = a.delta_scale > 1e6;             // (tests: everything is redone -- give the list the whole chip)
-    const int grid = all_listed ? (c->num_cu < nreads ? c->num_cu : nreads) : (nreads < 32 ? nreads : 32);
-    hipLaunchKernelGGL(k_roll_one, dim3(grid), dim3(ROLL_NT), lds, c->stream, d_sig, stride, d_len, nreads, lo, hi, w,
-                       std_scale, a.vec_ok, d_prep, a.below, a.above, a.mask_rows, a.read_stride, (const int32_t *)(d_redo + 2),
-                       (const int32_t *)d_redo);
+    const bool all_listed = a.delta_scale > 1e6;             // (tests: everything is redone -- give the list more of the chip)
+    int grid = all_listed ? (c->num_cu < nreads ? c->num_cu : nreads) : (nreads < 32 ? nreads : 32);
+    if (lds) {
+        if (lds > 64 * 1024)
+            SK_HIP(hipFuncSetAttribute((const void *)k_roll_one<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_roll_one<false>, dim3(grid), dim3(ROLL_NT), lds, c->stream, d_sig, stride, d_len, nreads, lo, hi, w,
+                           std_scale, a.vec_ok, d_prep, a.below, a.above, a.mask_rows, a.read_stride,
+                           (const int32_t *)(d_redo + 2), (const int32_t *)d_redo, (unsigned *)nullptr, (int64_t)0);
+    } else {
+        const int64_t grow = ((int64_t)roll_idx((int)stride + 1) + 8) & ~(int64_t)3;
+        while (grid > 1 && (size_t)grid * (size_t)grow * sizeof(unsigned) > ((size_t)1 << 30)) grid /= 2;
+        int rc = sk_reserve(c, &c->comp, (size_t)grid * (size_t)grow * sizeof(unsigned));
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_roll_one<true>, dim3(grid), dim3(ROLL_NT), sizeof(Scratch) + sizeof(RollShared) + 16, c->stream,
+                           d_sig, stride, d_len, nreads, lo, hi, w, std_scale, a.vec_ok, d_prep, a.below, a.above,
+                           a.mask_rows, a.read_stride, (const int32_t *)(d_redo + 2), (const int32_t *)d_redo,
+                           (unsigned *)c->comp.p, grow);
+    }
     SK_HIP(hipGetLastError());
     return SK_OK;
 }

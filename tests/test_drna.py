@@ -122,8 +122,51 @@ def test_oracle_rolling_edge_cases(ora):
     assert res is not None and res[0] < res[1]
 
 
+def _bot_delta(n, amax, mn, sd, sc):
+    """csrc/sk_prep.hip roll_bot_delta, restated: how far the reference's floating-point bot may lie from the one formed
+    from exact integer sums (the streaming kernel certifies its thresholds at bot - delta and bot + delta)."""
+    u, D, asc = 2.0 ** -53, 40.0 + (n >> 13), abs(sc)
+    em = (D + 3.0) * u * amax
+    return 2.0 * (em * (1.0 + 1.5 * asc) + asc * ((D + 8.0) * u * sd + 1.5 * u * amax) + 12.0 * u * (abs(mn) + 2.0 * asc * sd))
+
+
+def test_rolling_bot_from_exact_sums_lies_within_the_certification_margin(ora):
+    """k_roll_stream never sums in numpy's order: it takes bot = mn - std * std_scale from exact integer sums of the
+    window sums and certifies the two integer thresholds against everything the reference's order of summation can do.
+    Here (no GPU): the reference-order value (the oracle's, pinned to pandas) stays within HALF the margin of the exact
+    one -- the kernel doubles the bound -- on noisy, smooth, near-constant, huge-offset, short and long reads, and the
+    margin is small against the grid 1 / w the comparisons live on."""
+    import math
+    rng = np.random.default_rng(20260951)
+    worst = 0.0
+    cases = []
+    for n in (2001, 2500, 8192, 8193, 20000, 70000):
+        cases.append((450 + 60 * np.sin(np.arange(n) / 700.0) + rng.normal(0, 15, n)).astype(np.int64))
+        cases.append(rng.integers(1, 1200, n))
+        cases.append(np.full(n, 1199, dtype=np.int64) - (np.arange(n) % 977 == 0))          # near constant, large level
+        cases.append(np.r_[np.full(n // 3, 300), np.full(n - n // 3, 900)].astype(np.int64))
+    for x in cases:
+        for w, sc in ((2000, 0.5), (7, 0.5), (1999, -3.0), (12000, 0.1), (500, 40.0)):
+            n = x.size
+            if n < w + 2:
+                continue
+            res, t, (mn, sd, bot) = ora.drna_roll(x.astype(float), ora.RollParams(w=w, std_scale=sc), want_t=True)
+            P = np.concatenate([[0], np.cumsum(x)])
+            S = [int(v) for v in (P[w:] - P[:-w])]
+            cnt = len(S)
+            s1, s2 = sum(S), sum(v * v for v in S)
+            mn_x = s1 / (cnt * w)
+            sd_x = math.sqrt((cnt * s2 - s1 * s1) / (cnt * (cnt - 1) * w * w))
+            bot_x = mn_x - sd_x * sc
+            delta = _bot_delta(n, 1200.0, mn_x, sd_x, sc)
+            assert abs(bot - bot_x) <= 0.5 * delta, (n, w, sc, bot, bot_x, delta)
+            assert delta * w < 1e-4, (n, w, sc, delta)                       # (the thresholds move when bot * w crosses an integer)
+            worst = max(worst, abs(bot - bot_x) / delta)
+    print("largest |bot(reference order) - bot(exact)| / margin: %.3g" % worst)
+
+
 @pytest.mark.gpu
-def test_gpu_rolling_branch(gpu, ora):
+def test_gpu_rolling_branch(gpu, ora, monkeypatch):
     """HIP path of the --signal branch vs the reference's stdout (both windows) and vs the oracle over
     parameter corners, short reads and reads with outliers."""
     from squigglekit_amd import api
@@ -148,6 +191,14 @@ def test_gpu_rolling_branch(gpu, ora):
         for r, g in zip(extra, got):
             f = ora.scale_outliers(r.astype(float), p.lim_low, p.lim_hi)
             assert g == ora.drna_roll(f, ora.RollParams(**okw)), (kw, len(r))
+        # (rows of 140 000 samples: the streaming kernel takes them, and what it cannot certify -- here, on request,
+        # every read -- goes through k_roll_one with its prefix sums in a scratch row of global memory; the two-kernel path)
+        monkeypatch.setenv("SK_TUNING", "1")
+        for key, val in (("SK_ROLL_DELTA_SCALE", "1e13"), ("SK_ROLL_TWO_KERNELS", "1")):
+            monkeypatch.setenv(key, val)
+            assert api.drna_roll_reads(extra, p) == got, (kw, key)
+            monkeypatch.delenv(key)
+        monkeypatch.delenv("SK_TUNING")
 
 
 @pytest.mark.gpu

@@ -1,6 +1,6 @@
 """The tuning surface: every environment switch the library reads is in one table (csrc/sk_runtime.hip SK_TUNABLES +
 _lib.PY_TUNABLES).  Each one is flipped ALONE, to every value the table lists, on a ragged 3 000-read batch through
-both tools' batch calls (int16 and float64) -- the records must not change by a byte -- and none of them is read
+both tools' batch calls (int16 and float64) and the two dRNA branches -- the records must not change by a byte -- and none of them is read
 unless SK_TUNING=1 is set as well."""
 import ctypes as C
 import os
@@ -52,14 +52,20 @@ def _batch():
     return sig, lens, motif, pa
 
 
+_DRNA = []
+
+
 def _records(sig, lens, motif, pa):
-    from squigglekit_amd import api
+    from squigglekit_amd import api, synth
+    if not _DRNA:
+        _DRNA.extend(synth.drna_reads(12, 5, min_len=5000, max_len=20000))
+    drna = [repr(api.drna_segment_reads(_DRNA)).encode(), repr(api.drna_roll_reads(_DRNA)).encode()]
     hits = api.motifseq_batch(sig, lens, motif, scale="medmad")
     hz = api.motifseq_batch(sig[:600], lens[:600], motif, scale="zscale")
     segs, nsegs = api.segment_batch(sig, np.maximum(lens - 1, 0))
     sf = api.segment_reads_f64(pa)
     hf = api.motifseq_reads_f64(pa, motif, scale="medmad")
-    return [hits.tobytes(), hz.tobytes(), segs.tobytes(), nsegs.tobytes(), repr(sf).encode(), hf.tobytes()]
+    return [hits.tobytes(), hz.tobytes(), segs.tobytes(), nsegs.tobytes(), repr(sf).encode(), hf.tobytes()] + drna
 
 
 @pytest.mark.gpu
