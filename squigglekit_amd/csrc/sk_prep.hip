@@ -1469,6 +1469,11 @@ void k_roll_stream(const RollStreamArgs a)
     M = M < 0 ? 0 : (M > a.stride ? (int)a.stride : M);
     const int16_t *row = a.sig + (int64_t)r * a.stride;
     auto wrap = [&](unsigned m) -> unsigned { return min(m, m - (unsigned)RS); };        // m < 2 RS
+    // lo < x < hi for two packed samples at once: x == clamp(x, lo + 1, hi - 1) (limits outside int16 saturate, which changes nothing
+    // for an int16 x; an empty range switches the packed test off)
+    const int lo1 = max(a.lo + 1, -32768), hi1 = min(a.hi - 1, 32767);
+    const bool pk_ok = lo1 <= hi1;
+    const unsigned pk_lo = ((unsigned)lo1 & 0xffffu) * 0x10001u, pk_hi = ((unsigned)hi1 & 0xffffu) * 0x10001u;
 
     // one sweep over the raw samples; consume(done, slot of P[done + 1], g) is called for g <= 8 whole groups of 64 outputs
     // from `done` on, consume_tail(done, slot, avail) for the last avail < 64
@@ -1491,42 +1496,61 @@ void k_roll_stream(const RollStreamArgs a)
         };
         auto tile = [&](int base, const uint4 q) {
             const int i0 = base + lane * 8;
-            int v[8];
-            if (a.vec_ok && i0 + 8 <= M) {
-                const unsigned qq[4] = {q.x, q.y, q.z, q.w};
+            const bool vec = a.vec_ok && i0 + 8 <= M;
+            const unsigned qq[4] = {q.x, q.y, q.z, q.w};
+            // Nothing dropped in this tile -- the usual case, found with four packed clamps per lane: the counts are known,
+            // the lane's sum is the last of its local prefix sums, and its 8 entries go out in a straight line with
+            // immediate offsets unless the ring's end falls among them.
+            bool lane_all = vec && pk_ok;
 #pragma unroll
-                for (int k = 0; k < 4; k++) { v[2 * k] = (int)(short)(qq[k] & 0xffffu); v[2 * k + 1] = (int)(short)(qq[k] >> 16); }
+            for (int k = 0; k < 4; k++) lane_all = lane_all && clamp_pk_i16(qq[k], pk_lo, pk_hi) == qq[k];
+            int tc, ts;
+            if (__ballot(!lane_all) == 0ull) {
+                unsigned pre[8];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    pre[2 * k] = (unsigned)(int)(short)(qq[k] & 0xffffu);
+                    pre[2 * k + 1] = (unsigned)((int)qq[k] >> 16);
+                }
+#pragma unroll
+                for (int k = 1; k < 8; k++) pre[k] += pre[k - 1];
+                const int s = (int)pre[7];
+                const int inc_s = wave_incl_scan(s, lane);
+                ts = __builtin_amdgcn_readlane(inc_s, 63);
+                tc = 512;
+                const unsigned run0 = scar + (unsigned)(inc_s - s);
+                unsigned slot = wrap(wslot + 8u * (unsigned)lane);
+                if (__ballot(slot + 7u >= (unsigned)RS) == 0ull) {
+                    unsigned *p = roll_ring + slot;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) p[k] = run0 + pre[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { roll_ring[slot] = run0 + pre[k]; slot = wrap(slot + 1u); }
+                }
             } else {
+                int v[8];
+                if (vec) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[k] = (i0 + k < M) ? (int)row[i0 + k] : a.lo;
-            }
-            int c = 0, s = 0;
-            unsigned keep = 0u;
+                    for (int k = 0; k < 4; k++) { v[2 * k] = (int)(short)(qq[k] & 0xffffu); v[2 * k + 1] = (int)(short)(qq[k] >> 16); }
+                } else {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const bool kept = v[k] > a.lo && v[k] < a.hi;
-                c += kept ? 1 : 0;
-                s += kept ? v[k] : 0;
-                keep |= (kept ? 1u : 0u) << k;
-            }
-            // (nothing dropped in this tile -- the usual case: the counts are known, and a lane's 8 entries go out in a straight
-            // line with immediate offsets unless the ring's end falls among them)
-            const bool allkept = __ballot(keep != 0xffu) == 0ull;
-            const int inc_s = wave_incl_scan(s, lane);
-            const int ts = __builtin_amdgcn_readlane(inc_s, 63);
-            int tc = 512, excl_c = 8 * lane;
-            if (!allkept) {
-                const int inc_c = wave_incl_scan(c, lane);
+                    for (int k = 0; k < 8; k++) v[k] = (i0 + k < M) ? (int)row[i0 + k] : a.lo;      // (lo is not kept)
+                }
+                int c = 0, s = 0;
+                unsigned keep = 0u;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const bool kept = v[k] > a.lo && v[k] < a.hi;                                   // scale_outliers: strictly inside
+                    c += kept ? 1 : 0;
+                    s += kept ? v[k] : 0;
+                    keep |= (kept ? 1u : 0u) << k;
+                }
+                const int inc_s = wave_incl_scan(s, lane), inc_c = wave_incl_scan(c, lane);
+                ts = __builtin_amdgcn_readlane(inc_s, 63);
                 tc = __builtin_amdgcn_readlane(inc_c, 63);
-                excl_c = inc_c - c;
-            }
-            unsigned slot = wrap(wslot + (unsigned)excl_c);                // (excl_c <= 504 < RS)
-            unsigned run = scar + (unsigned)(inc_s - s);
-            if (allkept && __ballot(slot + 7u >= (unsigned)RS) == 0ull) {
-                unsigned *p = roll_ring + slot;
-#pragma unroll
-                for (int k = 0; k < 8; k++) { run += (unsigned)v[k]; p[k] = run; }
-            } else {
+                unsigned slot = wrap(wslot + (unsigned)(inc_c - c));       // (inc_c - c <= 504 < RS)
+                unsigned run = scar + (unsigned)(inc_s - s);
 #pragma unroll
                 for (int k = 0; k < 8; k++)
                     if ((keep >> k) & 1u) {
@@ -1586,8 +1610,13 @@ void k_roll_stream(const RollStreamArgs a)
     const int n = sweep([&](int done, unsigned dslot, int g) {
         int S[8];
         wsums(dslot, S);
+        if (done >= w - 1) {                                 // (uniform: past the first w - 1 outputs every lane counts)
 #pragma unroll
-        for (int k = 0; k < 8; k++) add1((k < g && done + 64 * k + lane >= w - 1) ? S[k] : 0);
+            for (int k = 0; k < 8; k++) add1(k < g ? S[k] : 0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) add1((k < g && done + 64 * k + lane >= w - 1) ? S[k] : 0);
+        }
     }, [&](int done, unsigned dslot, int avail) {
         const int S = wsum(dslot);
         add1((lane < avail && done + lane >= w - 1) ? S : 0);
@@ -1640,15 +1669,28 @@ void k_roll_stream(const RollStreamArgs a)
     // ---- sweep 2: the masks
     unsigned long long *brow = (unsigned long long *)a.below + (int64_t)r * a.read_stride;
     unsigned long long *arow = (unsigned long long *)a.above + (int64_t)r * a.read_stride;
+    // (|S| < 2^31 - 600 by the launch's check, so the two comparisons fit 32 bits: S < thr_lt <=> S <= le, S > thr_gt <=> S >= ge
+    // with the thresholds saturated -- INT_MIN as `le` is "never", INT_MAX as `ge` is "never")
+    const long long le64 = thr_lt == LLONG_MIN ? (long long)INT_MIN : thr_lt - 1, ge64 = thr_gt == LLONG_MAX ? (long long)INT_MAX : thr_gt + 1;
+    const int le = (int)(le64 < INT_MIN ? INT_MIN : le64 > INT_MAX ? INT_MAX : le64);
+    const int ge = (int)(ge64 < INT_MIN ? INT_MIN : ge64 > INT_MAX ? INT_MAX : ge64);
     (void)sweep([&](int done, unsigned dslot, int g) {
         int S[8];
         wsums(dslot, S);
         unsigned long long myb = 0ull, mya = 0ull;           // lane k keeps word k of this batch
+        if (done >= w - 1) {                                 // (uniform: past the first w - 1 outputs every lane counts)
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const bool valid = done + 64 * k + lane >= w - 1;
-            const unsigned long long bl = __ballot(valid && (long long)S[k] < thr_lt), ba = __ballot(valid && (long long)S[k] > thr_gt);
-            if (lane == k) { myb = bl; mya = ba; }
+            for (int k = 0; k < 8; k++) {
+                const unsigned long long bl = __ballot(S[k] <= le), ba = __ballot(S[k] >= ge);
+                if (lane == k) { myb = bl; mya = ba; }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool valid = done + 64 * k + lane >= w - 1;
+                const unsigned long long bl = __ballot(valid && S[k] <= le), ba = __ballot(valid && S[k] >= ge);
+                if (lane == k) { myb = bl; mya = ba; }
+            }
         }
         if (lane < g) {
             brow[(int64_t)((done >> 6) + lane) * a.mask_rows] = myb;
@@ -1657,7 +1699,7 @@ void k_roll_stream(const RollStreamArgs a)
     }, [&](int done, unsigned dslot, int avail) {
         const int S = wsum(dslot);
         const bool valid = lane < avail && done + lane >= w - 1;
-        const unsigned long long bl = __ballot(valid && (long long)S < thr_lt), ba = __ballot(valid && (long long)S > thr_gt);
+        const unsigned long long bl = __ballot(valid && S <= le), ba = __ballot(valid && S >= ge);
         if (lane == 0) {
             brow[(int64_t)(done >> 6) * a.mask_rows] = bl;
             arow[(int64_t)(done >> 6) * a.mask_rows] = ba;

@@ -339,8 +339,19 @@ void k_roll_walk(const uint64_t *__restrict__ below, const uint64_t *__restrict_
         const int len = sb - sa;
         if (!done && len <= p.hi_thresh && len >= p.lo_thresh) { fx = sa - p.shift; fy = sb - p.shift; done = true; }
     };
+    // (the next pair of words is requested before this one is looked at: a lane's loop is a chain of dependent loads otherwise)
+    const uint64_t *bp = below + (int64_t)r * read_stride, *ap = above + (int64_t)r * read_stride;
+    // (read-major masks are interleaved, {below, above} side by side: one 16-byte load per step)
+    const bool pairs = mask_rows == 2 && above == below + 1;
+    auto fetch = [&](int wi, uint64_t &B, uint64_t &A) {
+        if (pairs) { const ulonglong2 v = *(const ulonglong2 *)(bp + 2 * (int64_t)wi); B = v.x; A = v.y; }
+        else { B = bp[(int64_t)wi * mask_rows]; A = ap[(int64_t)wi * mask_rows]; }
+    };
+    uint64_t Bn = 0ull, An = 0ull;
+    if (n > 0) fetch(0, Bn, An);
     for (int wi = 0; wi * 64 < n; wi++) {
-        const uint64_t B = below[(int64_t)wi * mask_rows + (int64_t)r * read_stride], A = above[(int64_t)wi * mask_rows + (int64_t)r * read_stride];
+        const uint64_t B = Bn, A = An;
+        if ((wi + 1) * 64 < n) fetch(wi + 1, Bn, An);
         if (!begin && B == 0ull) continue;                    // nothing opens in this word
         const int lim = min(64, n - wi * 64);
         if (BY_RUNS) {
