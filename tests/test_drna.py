@@ -2,6 +2,7 @@
 CPU: oracle vs what the reference printed (goldens from tools/gen_golden.py).
 GPU: HIP path vs the oracle (all segments) and vs the reference's stdout (first segment)."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -120,6 +121,18 @@ def test_oracle_rolling_edge_cases(ora):
     assert ora.drna_roll(np.full(9000, 400.0)) is None                  # constant: nothing below mn - 0 
     res = ora.drna_roll(np.r_[np.full(6000, 300.0), np.full(20000, 600.0)])
     assert res is not None and res[0] < res[1]
+
+
+def test_three_operation_quotient_equals_the_division(tmp_path):
+    """k_roll_one forms t = RN(S / w) as q = S RN(1/w); r = fma(-q, w, S); t = fma(r, RN(1/w), q).  tools/ubench/
+    check_intdiv.c holds the argument and compares with the C division over every w < 65 536; here a short run of it
+    (13 M quotients; the full run, 1.3 G, is in DESIGN.md 4.2b)."""
+    import subprocess
+    exe = str(tmp_path / "check_intdiv")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ubench", "check_intdiv.c")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"], check=True)
+    out = subprocess.run([exe, "200"], check=True, capture_output=True, text=True).stdout
+    assert out.strip().endswith(" 0 mismatches"), out
 
 
 def _bot_delta(n, amax, mn, sd, sc):
