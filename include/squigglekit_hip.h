@@ -357,8 +357,10 @@ int sk_last_dtw_tier2(void);
  * audited one call in K <= 64, so that waiting for the sweep costs about 2 % on average: out[1] = 0 on the others;
  * SK_TUNING=1 SK_DTW_AUDIT_PERIOD=n audits every call), out[2] audited reads whose record differed (the exact record wins), out[3] reads kept
  * away from the screening because their sample image cannot be bounded tightly enough (exact pass, by design),
- * out[4] = out[0] + out[2] (the alarm), out[5] = 1 when the alarm made the library redo the WHOLE call with the
- * exact single pass, out[6] reads whose candidate columns fell into two clusters and took a second window instead of the
+ * out[4] = out[0] + out[2] (the alarm), out[5] = 1 when the alarm made the library redo reads with the exact single
+ * pass -- every read of the launch set that raised it (one motif over one ingest sub-batch) and of every later launch
+ * set of the same call; launch sets of a multi-motif / sub-batched call that finished earlier passed their own premise
+ * test and audit and are kept, out[6] reads whose candidate columns fell into two clusters and took a second window instead of the
  * exact pass (diagnostic), out[7] reserved.  In a healthy build out[0] = out[2] = out[4] = out[5] = 0, always.  The
  * two short forms return out[0] / out[2] (or a negative status).  The reference has no counterpart: mlpy's one
  * exact pass (/root/reference/MotifSeq.py:437-439) is what every record must equal. */

@@ -21,7 +21,8 @@ class SquiggleKitError(RuntimeError):
         self.code = code
 
 
-SK_ERR_OVERFLOW = -6
+# sk_status (include/squigglekit_hip.h)
+SK_OK, SK_ERR_INVALID, SK_ERR_NO_DEVICE, SK_ERR_HIP, SK_ERR_NOMEM, SK_ERR_UNSUPPORTED, SK_ERR_OVERFLOW = 0, -1, -2, -3, -4, -5, -6
 SK_SCALE = {"medmad": 0, "zscale": 1}
 SK_FLAG_EMPTY, SK_FLAG_DEGENERATE, SK_FLAG_RECENTRE = 1, 2, 4
 

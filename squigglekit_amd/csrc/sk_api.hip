@@ -147,6 +147,7 @@ void *sk_host_alloc(size_t bytes)
 {
     sk_ctx *c = sk_cur();
     if (!c) return nullptr;
+    sk_ctx_guard c_lock(c);
     void *p = nullptr;
     hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -174,8 +175,8 @@ static int finish_dtw_host(sk_ctx *c)
     SK_HIP(hipStreamSynchronize(c->stream));
     if (g[4])
         fprintf(stderr, "squigglekit: DTW screening guard: %d premise violation(s), %d audit mismatch(es) of %d audited reads -- "
-                        "the call was %s by the exact pass; please report this\n", g[0], g[2], g[1],
-                g[5] ? "redone" : "NOT redone");
+                        "the launch set(s) concerned and every later one of this call were %s by the exact pass; please report this\n",
+                g[0], g[2], g[1], g[5] ? "redone" : "NOT redone");
     return SK_OK;
 }
 
@@ -185,6 +186,7 @@ int sk_motifseq_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_l
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     return motifseq_dev(c, d_sig, stride, d_len, nreads, motif, nmotif, scale_mode, scale_low, scale_hi, d_out, 0);
 }
 
@@ -244,6 +246,7 @@ int sk_motifseq_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     int rc = check_i16(sig, stride, len, nreads);
     if (rc) return rc;
     if ((rc = check_len_host(len, nreads, stride))) return rc;
@@ -329,6 +332,7 @@ int sk_motifseq_multi_dev_i16(const int16_t *d_sig, int64_t stride, const int32_
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     int rc = check_i16(d_sig, stride, d_len, nreads);
     if (rc) return rc;
     if ((rc = check_multi(motifs, motif_off, nmotifs, scale_mode))) return rc;
@@ -352,6 +356,7 @@ int sk_motifseq_multi_batch_i16(const int16_t *sig, int64_t stride, const int32_
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     int rc = check_i16(sig, stride, len, nreads);
     if (rc) return rc;
     if ((rc = check_len_host(len, nreads, stride))) return rc;
@@ -482,6 +487,7 @@ int sk_motifseq_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (nreads < 0) return sk_fail(SK_ERR_INVALID, "nreads < 0");
     if (!motif || nmotif <= 0) return sk_fail(SK_ERR_INVALID, "empty motif");
     if (scale_mode != SK_SCALE_MEDMAD && scale_mode != SK_SCALE_ZSCALE)
@@ -508,6 +514,7 @@ int sk_motifseq_multi_batch_f64(const double *sig, const int64_t *off, int32_t n
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (nreads < 0) return sk_fail(SK_ERR_INVALID, "nreads < 0");
     int rc = check_multi(motifs, motif_off, nmotifs, scale_mode);
     if (rc) return rc;
@@ -531,6 +538,7 @@ int sk_motifseq_dev_f64(const double *d_sig, const int64_t *d_off, int32_t nread
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (nreads < 0 || total < 0 || max_len < 0 || max_len > 0x7fffff00) return sk_fail(SK_ERR_INVALID, "bad sizes");
     if (!motif || nmotif <= 0) return sk_fail(SK_ERR_INVALID, "empty motif");
     if (scale_mode != SK_SCALE_MEDMAD && scale_mode != SK_SCALE_ZSCALE)
@@ -547,6 +555,7 @@ int sk_dtw_subsequence_batch(const double *x, int32_t nx, const double *y, const
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (nreads < 0 || nx <= 0 || !x) return sk_fail(SK_ERR_INVALID, "bad query");
     if (nreads == 0) return SK_OK;
     if (!y || !off || !out) return sk_fail(SK_ERR_INVALID, "NULL y/off/out");
@@ -585,6 +594,7 @@ int sk_dtw_subsequence(const double *x, int32_t nx, const double *y, int32_t ny,
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!x || !y || nx <= 0 || ny <= 0) return sk_fail(SK_ERR_INVALID, "empty x or y");
     int rc;
     if ((rc = sk_reserve(c, &c->sig, (size_t)ny * sizeof(double)))) return rc;
@@ -617,6 +627,7 @@ int sk_normalise_i16(const int16_t *sig, int32_t len, int32_t scale_mode,
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (len < 0 || (len && (!sig || !out))) return sk_fail(SK_ERR_INVALID, "bad arguments");
     if (scale_mode != SK_SCALE_MEDMAD && scale_mode != SK_SCALE_ZSCALE)
         return sk_fail(SK_ERR_INVALID, "unknown scale mode %d", scale_mode);
@@ -653,6 +664,7 @@ int sk_normalise_f64(const double *sig, int32_t len, int32_t scale_mode,
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (len < 0 || (len && (!sig || !out))) return sk_fail(SK_ERR_INVALID, "bad arguments");
     if (scale_mode != SK_SCALE_MEDMAD && scale_mode != SK_SCALE_ZSCALE)
         return sk_fail(SK_ERR_INVALID, "unknown scale mode %d", scale_mode);
@@ -686,6 +698,7 @@ int sk_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_le
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     int rc = check_i16(d_sig, stride, d_len, nreads);
     if (rc) return rc;
     if ((rc = check_seg_params(p))) return rc;
@@ -729,6 +742,7 @@ int sk_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t *len,
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     int rc = check_i16(sig, stride, len, nreads);
     if (rc) return rc;
     if ((rc = check_len_host(len, nreads, stride))) return rc;
@@ -830,6 +844,7 @@ int sk_segment_batch_f64_len(const double *sig, const int64_t *off, const int32_
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (nreads < 0) return sk_fail(SK_ERR_INVALID, "nreads < 0");
     int rc = check_seg_params(p);
     if (rc) return rc;
@@ -883,6 +898,7 @@ int sk_segment_batch_i16_pa(const int16_t *sig, int64_t stride, const int32_t *l
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     int rc = check_i16(sig, stride, len, nreads);
     if (rc) return rc;
     if ((rc = check_len_host(len, nreads, stride))) return rc;
@@ -936,6 +952,7 @@ int sk_segment_dev_f64(const double *d_sig, const int64_t *d_off, int32_t nreads
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (nreads < 0 || total < 0 || max_len < 0 || max_len > 0x7fffff00) return sk_fail(SK_ERR_INVALID, "bad sizes");
     int rc = check_seg_params(p);
     if (rc) return rc;
@@ -1044,6 +1061,7 @@ int sk_drna_roll_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     int rc = check_i16(d_sig, stride, d_len, nreads);
     if (rc) return rc;
     if ((rc = check_roll(p))) return rc;
@@ -1057,6 +1075,7 @@ int sk_drna_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t 
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     int rc = check_i16(d_sig, stride, d_len, nreads);
     if (rc) return rc;
     if ((rc = check_drna(p, max_segs))) return rc;
@@ -1070,6 +1089,7 @@ int sk_drna_roll_batch_i16(const int16_t *sig, int64_t stride, const int32_t *le
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     int rc = check_i16(sig, stride, len, nreads);
     if (rc) return rc;
     if ((rc = check_len_host(len, nreads, stride))) return rc;
@@ -1096,6 +1116,7 @@ int sk_drna_segment_batch_i16(const int16_t *sig, int64_t stride, const int32_t 
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     int rc = check_i16(sig, stride, len, nreads);
     if (rc) return rc;
     if ((rc = check_len_host(len, nreads, stride))) return rc;
@@ -1127,6 +1148,7 @@ int sk_synth_squiggles_dev(int16_t *d_sig, int64_t stride, int32_t nreads, int32
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!d_sig || stride < nsamples || nreads < 0 || nsamples < 0)
         return sk_fail(SK_ERR_INVALID, "bad arguments");
     const int16_t *d_m = nullptr;
@@ -1153,6 +1175,7 @@ int sk_synth_variant_dev(int16_t *d_sig, int64_t stride, int32_t nreads, int32_t
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!d_sig || !o || stride < nsamples || nreads < 0 || nsamples < 0 || o->row0 < 0)
         return sk_fail(SK_ERR_INVALID, "bad arguments");
     int rc;
@@ -1190,6 +1213,7 @@ int sk_synth_pa_dev(const int16_t *d_raw, int64_t stride, int32_t nreads, int32_
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!d_raw || !d_out || !d_off || stride < nsamples || nreads < 0 || nsamples < 0 || !(digitisation > 0))
         return sk_fail(SK_ERR_INVALID, "bad arguments");
     int rc = sk_launch_raw_to_pa(c, d_raw, stride, nreads, nsamples, offset, range / digitisation, d_out, d_off);
@@ -1204,6 +1228,7 @@ int sk_last_f64_retries(void)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!c->f64_stream || !c->retry.p) return -1;
     int32_t n = 0;
     SK_HIP(hipStreamSynchronize(c->stream));
@@ -1218,6 +1243,7 @@ int sk_dtw_subsequence_cref(const double *x, int32_t nx, const double *y, int32_
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!x || !y || nx <= 0 || ny <= 0) return sk_fail(SK_ERR_INVALID, "empty x or y");
     const size_t cells = (size_t)nx * (size_t)ny;
     if (cells > ((size_t)1 << 28)) return sk_fail(SK_ERR_UNSUPPORTED, "%d x %d cost matrix is over 2 GB", nx, ny);

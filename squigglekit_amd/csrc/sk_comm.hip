@@ -94,6 +94,7 @@ int sk_comm_init_rank(const void *id128, int nranks, int rank)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!id128 || nranks <= 0 || rank < 0 || rank >= nranks) return sk_fail(SK_ERR_INVALID, "bad id / rank / nranks");
     if (c->comm) return sk_fail(SK_ERR_INVALID, "device %d already has a communicator", c->device);
     Rccl *R = rccl();
@@ -131,6 +132,7 @@ int sk_comm_info(int *nranks, int *rank)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!c->comm) return sk_fail(SK_ERR_INVALID, "no communicator on device %d", c->device);
     Rccl *R = rccl();
     if (!R) return no_rccl();
@@ -148,6 +150,7 @@ int sk_comm_allgather_dev(const void *d_send, void *d_recv, size_t bytes)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!c->comm) return sk_fail(SK_ERR_INVALID, "no communicator on device %d", c->device);
     if (bytes && (!d_send || !d_recv)) return sk_fail(SK_ERR_INVALID, "NULL buffer");
     Rccl *R = rccl();
@@ -161,6 +164,7 @@ int sk_comm_allgather_host(const void *send, void *recv, size_t bytes)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!c->comm) return sk_fail(SK_ERR_INVALID, "no communicator on device %d", c->device);
     if (!send || !recv || bytes == 0) return sk_fail(SK_ERR_INVALID, "bad buffer");
     int n = 0;
@@ -179,6 +183,7 @@ int sk_comm_destroy(void)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!c->comm) return SK_OK;
     Rccl *R = rccl();
     if (!R) return no_rccl();

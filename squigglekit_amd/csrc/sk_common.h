@@ -47,6 +47,7 @@ struct sk_ctx {
     hipEvent_t  ev_a = nullptr;       // audit sweep done
     hipEvent_t  ev_s[2] = {nullptr, nullptr};   // second clusters (siblings) on the third stream: pass Q done / their round done
     uint32_t    dtw_sparse_calls = 0; // calls whose audit would be exposed (few, long reads): every K-th is audited
+    uint32_t    dtw_audit_calls = 0;  // audited launches so far: salt of the audit's choice of reads (k_audit_pick)
     hipEvent_t  ev_chunk[9] = {};     // ordering events between the two streams (no timing)
     hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};   // prep start/stop, main start/stop
     bool        ev_valid = false;
@@ -110,6 +111,19 @@ struct sk_ctx {
 const char *sk_tune(const char *name);
 
 // ---- runtime (sk_runtime.hip) ----
+// Every entry point that touches a context holds that context's lock from sk_cur() to its return (SURVEY 8(b):
+// "per-device context guarded by a mutex"): two host threads bound to the same slot take turns call by call -- the
+// scratch buffers sk_reserve may free, the streams' event slots and the "last call" counters belong to one call at a
+// time.  Recursive: entry points call each other.  Contexts of different slots never wait for each other.
+void sk_ctx_lock(sk_ctx *c);
+void sk_ctx_unlock(sk_ctx *c);
+struct sk_ctx_guard {
+    sk_ctx *c;
+    explicit sk_ctx_guard(sk_ctx *ctx) : c(ctx) { if (c) sk_ctx_lock(c); }
+    ~sk_ctx_guard() { if (c) sk_ctx_unlock(c); }
+    sk_ctx_guard(const sk_ctx_guard &) = delete;
+    sk_ctx_guard &operator=(const sk_ctx_guard &) = delete;
+};
 sk_ctx *sk_cur(void);                       // bound context or nullptr (error set)
 sk_ctx *sk_ctx_of(int device);              // context slot of a device (ready or not)
 int  sk_bound_device(void);                 // device the calling thread is bound to, or -1

@@ -15,6 +15,10 @@ static thread_local char  g_err[512] = "";
 static thread_local int   g_cur = -1;
 static sk_ctx             g_ctx[SK_MAX_DEVICES];
 static std::mutex         g_mu;
+static std::recursive_mutex g_ctx_mu[SK_MAX_DEVICES];      // one per context slot (sk_ctx_guard)
+
+void sk_ctx_lock(sk_ctx *c)   { g_ctx_mu[c - g_ctx].lock(); }
+void sk_ctx_unlock(sk_ctx *c) { g_ctx_mu[c - g_ctx].unlock(); }
 
 int sk_fail(int code, const char *fmt, ...)
 {
@@ -167,6 +171,7 @@ int sk_init_slot(int slot, int device)
         return sk_fail(SK_ERR_INVALID, "context slot %d out of range (0..%d)", slot, SK_MAX_DEVICES - 1);
     std::lock_guard<std::mutex> lk(g_mu);
     sk_ctx *c = &g_ctx[slot];
+    sk_ctx_guard c_lock(c);
     if (c->ready && c->device != device)
         return sk_fail(SK_ERR_INVALID, "context slot %d already serves device %d", slot, c->device);
     SK_HIP(hipSetDevice(device));
@@ -193,6 +198,7 @@ int sk_shutdown(void)
     std::lock_guard<std::mutex> lk(g_mu);
     for (int d = 0; d < SK_MAX_DEVICES; d++) {
         sk_ctx *c = &g_ctx[d];
+        sk_ctx_guard c_lock(c);                            // (a call in flight on another thread finishes first)
         if (!c->ready) continue;
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
@@ -212,10 +218,12 @@ int sk_shutdown(void)
             for (int i = 0; i < 2; i++) if (c->ev_r[i]) (void)hipEventDestroy(c->ev_r[i]);
             (void)hipStreamDestroy(c->stream3);
         }
+        // (the sibling-round events belong to the third stream's launches, not to the audit's: they exist whenever
+        // stream3 does, also under SK_DTW_NOGUARD / SK_DTW_AUDIT_PERIOD=0 where stream4 never is created)
+        for (int i = 0; i < 2; i++) if (c->ev_s[i]) (void)hipEventDestroy(c->ev_s[i]);
         if (c->stream4) {
             (void)hipStreamSynchronize(c->stream4);
             if (c->ev_a) (void)hipEventDestroy(c->ev_a);
-            for (int i = 0; i < 2; i++) if (c->ev_s[i]) (void)hipEventDestroy(c->ev_s[i]);
             (void)hipStreamDestroy(c->stream4);
         }
         (void)hipStreamDestroy(c->stream);
@@ -229,6 +237,7 @@ int sk_sync(void)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     SK_HIP(hipStreamSynchronize(c->stream));
     return SK_OK;
 }
@@ -237,6 +246,7 @@ int sk_device_name(char *buf, int cap)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!buf || cap <= 0) return sk_fail(SK_ERR_INVALID, "bad buffer");
     hipDeviceProp_t prop;
     SK_HIP(hipGetDeviceProperties(&prop, c->device));
@@ -249,6 +259,7 @@ int sk_device_pci_bus_id(char *buf, int cap)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!buf || cap < 16) return sk_fail(SK_ERR_INVALID, "bad buffer");
     SK_HIP(hipDeviceGetPCIBusId(buf, cap, c->device));
     return SK_OK;
@@ -258,6 +269,7 @@ void *sk_dev_alloc(size_t bytes)
 {
     sk_ctx *c = sk_cur();
     if (!c) return nullptr;
+    sk_ctx_guard c_lock(c);
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
     if (e != hipSuccess) {
@@ -271,6 +283,7 @@ int sk_dev_free(void *dptr)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (dptr) SK_HIP(hipFree(dptr));
     return SK_OK;
 }
@@ -279,6 +292,7 @@ int sk_dev_upload(void *dst_dev, const void *src_host, size_t bytes)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (bytes && (!dst_dev || !src_host)) return sk_fail(SK_ERR_INVALID, "NULL pointer");
     SK_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
     SK_HIP(hipStreamSynchronize(c->stream));
@@ -289,6 +303,7 @@ int sk_dev_download(void *dst_host, const void *src_dev, size_t bytes)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (bytes && (!dst_host || !src_dev)) return sk_fail(SK_ERR_INVALID, "NULL pointer");
     SK_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
     SK_HIP(hipStreamSynchronize(c->stream));
@@ -299,6 +314,7 @@ int sk_last_kernel_ms(float *prep_ms, float *main_ms)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!c->ev_valid) return sk_fail(SK_ERR_INVALID, "no timed call yet");
     SK_HIP(hipEventSynchronize(c->ev[3]));
     float a = 0.f, b = 0.f;
@@ -314,6 +330,7 @@ int sk_last_dtw_profile(float *dist_ms, int *dist_launches, float *start_ms, int
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     float a = 0.f, b = 0.f;
     int mx = 0;
     for (int i = 0; i < c->prof_chunks; i++) {
@@ -337,6 +354,7 @@ int sk_last_dtw_retries(void)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (c->retry_dev && c->dtwcnt.p) {              // the count stayed on the device: fetch it now
         int32_t n = 0;
         if (hipMemcpyAsync(&n, c->dtwcnt.p, sizeof n, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -351,6 +369,7 @@ int sk_last_dtw_clock(double *ghz)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!ghz) return sk_fail(SK_ERR_INVALID, "NULL pointer");
     *ghz = 0.0;
     if (!(c->retry_dev && c->dtwcnt.p)) return SK_OK;
@@ -370,6 +389,7 @@ int sk_last_dtw_guard(int32_t *out)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!out) return sk_fail(SK_ERR_INVALID, "NULL pointer");
     memset(out, 0, 8 * sizeof(int32_t));
     if (!(c->retry_dev && c->dtwcnt.p)) return SK_OK;
@@ -397,6 +417,7 @@ int sk_last_dtw_tier2(void)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
     if (!(c->retry_dev && c->dtwcnt.p)) return 0;
     int32_t n = 0;
     if (hipMemcpyAsync(&n, (const int32_t *)c->dtwcnt.p + 1, sizeof n, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||

@@ -292,8 +292,10 @@ void k_sdtw(const sdtw_kargs a)
 }
 
 // ---- the audit (round 5): which reads, and the comparison -----------------------------------------------------
-// read of audit slot s: a hashed position inside [s * period, (s + 1) * period)
-__global__ void k_audit_pick(int32_t *list, int naudit, int period, int nreads)
+// read of audit slot s: a hashed position inside [s * period, (s + 1) * period).  `salt` is the context's count of
+// audited calls: a stream of equally shaped calls audits different positions call after call (lane group within a wave,
+// chunk boundary, place in the sorted order), and a call's choice is still a function of (call number, shape) alone.
+__global__ void k_audit_pick(int32_t *list, int naudit, int period, int nreads, unsigned salt)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s == 0) { list[0] = naudit; list[1] = 0; }
@@ -301,6 +303,7 @@ __global__ void k_audit_pick(int32_t *list, int naudit, int period, int nreads)
     const int64_t base = (int64_t)s * period;
     const int span = (int)min((int64_t)period, (int64_t)nreads - base);
     unsigned h = (unsigned)s * 2654435761u + 0x9E3779B9u;
+    h ^= salt * 0x9E3779B9u;
     h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
     list[2 + s] = (int)(base + (int64_t)(h % (unsigned)span));
 }
@@ -319,9 +322,9 @@ __global__ void k_audit_compare(const int32_t *list, const sk_hit *exact, sk_hit
     atomicAdd(&guard[SK_GUARD_ALARM], 1);
 }
 
-static void sk_audit_pick(int32_t *list, int naudit, int period, int nreads, hipStream_t st)
+static void sk_audit_pick(int32_t *list, int naudit, int period, int nreads, unsigned salt, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_audit_pick, dim3((naudit + 255) / 256), dim3(256), 0, st, list, naudit, period, nreads);
+    hipLaunchKernelGGL(k_audit_pick, dim3((naudit + 255) / 256), dim3(256), 0, st, list, naudit, period, nreads, salt);
 }
 static void sk_audit_compare(const int32_t *list, const sk_hit *exact, sk_hit *out, int naudit, int32_t *guard, hipStream_t st)
 {
@@ -647,9 +650,14 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
     // (b) AUDIT: one read in every `period` (hashed position inside each run of `period` reads; 4 096) is also swept
     //     by the exact single pass, on the third stream beside the window passes, into records of its own; a compare
     //     kernel behind everything counts the records that differ, and the exact one wins;
-    // (c) FALLBACK: if (a) or (b) counted anything the premise is broken for reasons unknown, so no record of this call
-    //     is trusted: the exact single pass over ALL reads is enqueued behind a gate word and returns at once while
-    //     that word is zero (no host synchronisation anywhere).  sk_last_dtw_guard() reports the counters.
+    // (c) FALLBACK: if (a) or (b) counted anything the premise is broken for reasons unknown, so no record of this LAUNCH
+    //     SET (one motif over one sub-batch: what this function enqueues) is trusted: the exact single pass over all of
+    //     its reads is enqueued behind a gate word and returns at once while that word is zero (no host synchronisation
+    //     anywhere).  sk_last_dtw_guard() reports the counters.  Scope: an API call that makes several launch sets
+    //     (multi-motif, the host entry points' ingest sub-batches) shares ONE set of counters (`accumulate`), so after
+    //     an alarm every LATER launch set of the call runs exactly as well (the gate stays open); launch sets that
+    //     finished BEFORE the alarm without one of their own are not redone -- each of them passed its own premise
+    //     test and its own audit.  The message on stderr says "launch set(s)" for that reason.
     int32_t *guard = (int32_t *)c->dtwcnt.p + 8;
     const bool guarded = qok && sk_tune("SK_DTW_NOGUARD") == nullptr;
     int audit_period = 4096;
@@ -680,7 +688,7 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
     }
     auto launch_audit = [&](hipStream_t stream) -> int {    // the exact pass over the audit reads (records by slot)
         if (!naudit) return SK_OK;
-        sk_audit_pick(alist, naudit, audit_period, a->nreads, stream ? stream : c->stream);
+        sk_audit_pick(alist, naudit, audit_period, a->nreads, c->dtw_audit_calls++, stream ? stream : c->stream);
         SK_HIP(hipGetLastError());
         sdtw_kargs kr = k;
         kr.read0 = 0; kr.ridx = alist + 2; kr.count_ptr = alist; kr.ckpt = nullptr; kr.out = aout; kr.out_by_slot = 1;

@@ -1169,6 +1169,11 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
         if (need > k.lds_wave_words) k.lds_wave_words = need;
     }
     fz_lds = (size_t)4 * (size_t)k.lds_wave_words * sizeof(unsigned);
+    // (64 KB per workgroup without an opt-in attribute, 5 KB of it static: only the tuning variable SK_DTW_CK can ask
+    // for more -- L = 8 with ck >= 512 -- and gets a message instead of a failed launch)
+    if (fz_lds + 5 * 1024 > 64 * 1024)
+        return sk_fail(SK_ERR_INVALID, "SK_DTW_CK=%d with %d lanes per read needs %zu bytes of LDS per workgroup (limit 65536): "
+                       "use a smaller multiple of 64", ck, L, fz_lds + 5 * 1024);
 
     const size_t nchunks = (size_t)((a->nreads + chunk - 1) / chunk);
     while (c->evpool.size() < 3 * nchunks) {

@@ -502,7 +502,8 @@ def run_sharded(devices, total, fn, rccl=False, reshard=None):
     A rank whose shard fails with a library error (a device that dropped out, ran out of memory, ...) does not take the
     job down while other devices are healthy ("never abort the stream of reads"): its block is cut up
     over the surviving devices and run again there, with one line on stderr.  Only for shards that do not talk to each
-    other (reshard defaults to `not rccl`); invalid arguments (SK_ERR_INVALID) fail on every device alike and are raised.
+    other (reshard defaults to `not rccl`); invalid arguments (SK_ERR_INVALID), unsupported shapes and max_segs overflows
+    fail on every device alike and are raised at once.
     If every rank failed, or the second attempt fails too, the first error is raised."""
     import sys
     g = group_for(devices, rccl=rccl)
@@ -517,7 +518,9 @@ def run_sharded(devices, total, fn, rccl=False, reshard=None):
                 _fault_hook(comm.rank)
             return fn(lo, hi, comm)
         except _lib.SquiggleKitError as e:
-            if not reshard or e.code == -2:                          # SK_ERR_INVALID: the caller's arguments
+            # the caller's arguments / a shape no device covers fail everywhere alike: raised.  A lost device
+            # (SK_ERR_NO_DEVICE), a failed HIP call, an allocation failure: the block goes to the survivors.
+            if not reshard or e.code in (_lib.SK_ERR_INVALID, _lib.SK_ERR_UNSUPPORTED, _lib.SK_ERR_OVERFLOW):
                 raise
             with mu:
                 failed.append((comm.rank, lo, hi, e))

@@ -150,10 +150,33 @@ def test_run_sharded_reruns_a_failed_ranks_block_on_the_survivors(ora, monkeypat
     monkeypatch.setattr(multigpu, "_fault_hook", lambda rank: (_ for _ in ()).throw(_lib.SquiggleKitError(-3, "all gone")))
     with pytest.raises(_lib.SquiggleKitError):
         multigpu.run_sharded([0, 2], 23, shard)
+    # the caller's arguments being wrong (SK_ERR_INVALID = -1) on ONE rank: raised at once, nothing is re-run
     multigpu._groups[(0, 2)] = multigpu.ThreadGroup((0, 2), rccl=False, bind=False)
-    monkeypatch.setattr(multigpu, "_fault_hook", lambda rank: (_ for _ in ()).throw(_lib.SquiggleKitError(-2, "bad argument")))
-    with pytest.raises(_lib.SquiggleKitError):
+    del calls[:]
+
+    def bad_argument(rank):
+        if rank == 1:
+            raise _lib.SquiggleKitError(_lib.SK_ERR_INVALID, "bad argument")
+    monkeypatch.setattr(multigpu, "_fault_hook", bad_argument)
+    with pytest.raises(_lib.SquiggleKitError) as ei:
         multigpu.run_sharded([0, 2], 23, shard)
+    assert ei.value.code == _lib.SK_ERR_INVALID and sorted(calls) == [(0, 12)]
+    capsys.readouterr()
+    # a device that is gone (SK_ERR_NO_DEVICE = -2, "device lost"): resharded like any other device failure
+    for key in ((0, 1, 2), (0, 1)):
+        multigpu._groups[key] = multigpu.ThreadGroup(key, rccl=False, bind=False)
+    del calls[:]
+    out[:] = np.zeros_like(want)
+
+    def lost(rank):
+        if rank == 2:
+            raise _lib.SquiggleKitError(_lib.SK_ERR_NO_DEVICE, "device lost (injected)")
+    monkeypatch.setattr(multigpu, "_fault_hook", lost)
+    g = multigpu.run_sharded([0, 1, 2], 23, shard)
+    monkeypatch.setattr(multigpu, "_fault_hook", None)
+    assert out.tobytes() == want.tobytes() and g.devices == [0, 1]
+    assert "device 2 (rank 2) failed on reads 16..22" in capsys.readouterr().err
+    assert (_lib.SK_ERR_INVALID, _lib.SK_ERR_NO_DEVICE, _lib.SK_ERR_HIP, _lib.SK_ERR_NOMEM) == (-1, -2, -3, -4)
     multigpu._groups.clear()
 
 
