@@ -133,6 +133,18 @@ int sk_segment_batch_f64_len(const double *sig, const int64_t *off, const int32_
  * offset, range of read r (what a fast5 / BLOW5 record carries).  The caller applies [:Num] via len[]. */
 int sk_segment_batch_i16_pa(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads, const double *calib,
                             const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs);
+/* Since round 6 the samples of this route stay int16 on the device: v(x) = rint((x + offset) * unit * 100) / 100 is a
+ * non-decreasing function of the sample, so scale_outliers' limits, np.median, np.std (from exact integer centi-pA sums)
+ * and the two thresholds of get_segs (segmenter.py:311-318, 410-414, 431) are found in the raw domain -- 2 bytes a sample
+ * instead of 8 -- and certified against numpy's rounding; reads that cannot be certified are redone from their float64
+ * values in numpy's order.  sk_pa_calib turns the records' {digitisation, offset, range} into the {offset, raw_unit}
+ * pairs of the device-resident form (range cut to two decimals first, segmenter.py:385); sk_last_pa_retries: reads of
+ * the last such call that took the redo (-1: the call expanded every row to float64 -- rows whose stride is not a
+ * multiple of 8). */
+int sk_pa_calib(const double *calib, int32_t nreads, double *cal2);
+int sk_segment_dev_i16_pa(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads, const double *d_cal2,
+                          const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs);
+int sk_last_pa_retries(void);
 /* device-resident form of sk_segment_batch_i16 (all pointers device). */
 int sk_segment_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
                        const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs);

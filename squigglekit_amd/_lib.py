@@ -111,6 +111,9 @@ ABI = {
                                        _vp, _vp, C.c_int32]),
     "sk_segment_batch_f64": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(SegParams), _vp, _vp, C.c_int32]),
     "sk_segment_batch_i16_pa": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, C.POINTER(SegParams), _vp, _vp, C.c_int32]),
+    "sk_pa_calib": (C.c_int, [_vp, C.c_int32, _vp]),
+    "sk_segment_dev_i16_pa": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, C.POINTER(SegParams), _vp, _vp, C.c_int32]),
+    "sk_last_pa_retries": (C.c_int, []),
     "sk_segment_batch_f64_len": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.POINTER(SegParams), _vp, _vp, C.c_int32]),
     "sk_segment_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, C.POINTER(SegParams),
                                      _vp, _vp, C.c_int32]),

@@ -236,8 +236,10 @@ def _over_devices(devices, R, call):
 
 def segment_batch_pa(sig, lens, calib, params=None, max_segs=64, devices=None):
     """Raw int16 rows through the pA route (segmenter.py:345-349: fast5 / slow5 input without --raw_signal): the
-    conversion np.round((raw + offset) * (float("%.2f" % range) / digitisation), 2) runs on the GPU, then the float64
-    segmenter path.  calib: float64 [R, 3] = digitisation, offset, range per read.  Returns (segs, nsegs).
+    conversion np.round((raw + offset) * (float("%.2f" % range) / digitisation), 2) is a monotone map of the sample, so
+    since round 6 the rows stay int16 on the GPU and limits, median, std and thresholds are found in the raw domain
+    (k_seg_stats<.., PA>; reads it cannot certify are redone from their float64 values in numpy's order).
+    calib: float64 [R, 3] = digitisation, offset, range per read.  Returns (segs, nsegs).
     devices (or api.set_devices / --gpus): the reads are block-sharded like segment_batch's."""
     L = _lib.load()
     sig = np.ascontiguousarray(sig, dtype=np.int16)
@@ -255,6 +257,12 @@ def segment_batch_pa(sig, lens, calib, params=None, max_segs=64, devices=None):
             max_segs = int(nsegs.max()) + 8
             continue
         return segs[:R], nsegs[:R]
+
+
+def last_pa_retries():
+    """Reads of the most recent segment_batch_pa call on this thread's device (its last sub-batch) that took the
+    numpy-order redo; -1 when the call expanded its rows to float64 instead of staying in the raw domain."""
+    return int(_lib.load().sk_last_pa_retries())
 
 
 def segment_ragged_f64(values, off, lens=None, params=None, max_segs=64, devices=None):

@@ -891,8 +891,92 @@ int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads, 
 
 // Raw reads through the pA route: what segmenter.py does with fast5 / slow5 input unless --raw_signal is given
 // (segmenter.py:345-349, 366-370: np.round(convert_to_pA_numpy(sig, digitisation, range, offset), 2) with range first
-// cut to two decimals, float("{0:.2f}".format(range)), :385) -- made on the device from the int16 rows, then the float64
-// segmenter path.  calib[3 r ..] = digitisation, offset, range of read r (what a fast5 / BLOW5 record carries).
+// cut to two decimals, float("{0:.2f}".format(range)), :385).  calib[3 r ..] = digitisation, offset, range of read r
+// (what a fast5 / BLOW5 record carries) -> cal2[2 r ..] = {offset, raw_unit = range / digitisation}.
+int sk_pa_calib(const double *calib, int32_t nreads, double *cal2)
+{
+    if (nreads < 0 || (nreads > 0 && (!calib || !cal2))) return sk_fail(SK_ERR_INVALID, "NULL calib / cal2");
+    for (int32_t r = 0; r < nreads; r++) {
+        const double dig = calib[3 * r], ofs = calib[3 * r + 1], rng = calib[3 * r + 2];
+        char txt[512];
+        snprintf(txt, sizeof txt, "%.2f", rng);              // float("{0:.2f}".format(range))
+        cal2[2 * r] = ofs;
+        cal2[2 * r + 1] = strtod(txt, nullptr) / dig;        // raw_unit = range / digitisation
+    }
+    return SK_OK;
+}
+
+// Device-resident core.  Since round 6 the values stay int16: the pA conversion is a monotone map of the sample, so
+// limits, median, std and the two thresholds are found in the raw domain (k_seg_stats<.., PA>, sk_segstat.hip: 2 bytes a
+// sample instead of 8; reads it cannot certify are redone from their float64 values in numpy's order).  Rows the
+// streaming kernel does not take (stride not a multiple of 8, unaligned): the float64 image of every row, then the
+// float64 segmenter path -- what every call did before round 6.
+static int segment_dev_i16_pa(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
+                              const double *d_cal2, const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs)
+{
+    int rc;
+    c->pa_raw = 0;
+    if (sk_segment_pa_applies(d_sig, stride, p->std_scale)) {
+        c->pa_raw = 1;
+        const size_t mb = (size_t)nreads * (size_t)sk_segment_fast_row16(stride) * 16;
+        if ((rc = sk_reserve(c, &c->prep, (size_t)nreads * sizeof(sk_prep)))) return rc;
+        if ((rc = sk_reserve(c, &c->mask, mb))) return rc;
+        if ((rc = sk_reserve(c, &c->retry, ((size_t)nreads + 16) * sizeof(int32_t)))) return rc;
+        if ((rc = sk_reserve(c, &c->comp, (size_t)c->num_cu * (size_t)stride * sizeof(double)))) return rc;
+        SK_HIP(hipMemsetAsync(d_segs, 0, (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t), c->stream));
+        rc = sk_launch_segment_fast(c, d_sig, stride, d_len, nreads, p, p->lim_low, p->lim_hi, (sk_prep *)c->prep.p, c->mask.p,
+                                    (int32_t *)c->retry.p, d_segs, d_nsegs, max_segs, d_cal2, (double *)c->comp.p);
+        if (rc) return rc;
+        c->ev_valid = true;
+        return SK_OK;
+    }
+    // every read in a slot of `stride` doubles; the cut to len[r] is the float64 path's per-read length
+    const int64_t total = (int64_t)nreads * stride;
+    c->pa_off_host.resize((size_t)nreads + 1);
+    for (int32_t r = 0; r <= nreads; r++) c->pa_off_host[r] = (int64_t)r * stride;
+    if ((rc = sk_reserve(c, &c->sig, (size_t)(total > 0 ? total : 1) * sizeof(double)))) return rc;
+    if ((rc = sk_reserve(c, &c->off, c->pa_off_host.size() * sizeof(int64_t)))) return rc;
+    SK_HIP(hipMemcpyAsync(c->off.p, c->pa_off_host.data(), c->pa_off_host.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    SK_HIP(hipStreamSynchronize(c->stream));                 // (the vector may be resized by the next call)
+    rc = sk_launch_rows_to_pa(c, d_sig, stride, nreads, (const int64_t *)c->off.p, d_cal2, (double *)c->sig.p);
+    if (rc) return rc;
+    return segment_dev_f64(c, (const double *)c->sig.p, (const int64_t *)c->off.p, nreads, total, stride, p,
+                           d_segs, d_nsegs, max_segs, d_len);
+}
+
+// Reads of the most recent sk_segment_*_i16_pa call (its last sub-batch) that the raw-domain kernel could not certify and
+// that were redone from their float64 values; -1 when that call expanded every read to float64 instead.
+int sk_last_pa_retries(void)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
+    if (!c->pa_raw) return -1;
+    SK_HIP(hipStreamSynchronize(c->stream));
+    int total = 0;
+    for (const int32_t *ptr : c->pa_retry_ptrs) {
+        int32_t v = 0;
+        SK_HIP(hipMemcpy(&v, ptr, sizeof v, hipMemcpyDeviceToHost));
+        total += v;
+    }
+    return total;
+}
+
+int sk_segment_dev_i16_pa(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads, const double *d_cal2,
+                          const sk_seg_params *p, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
+    int rc = check_i16(d_sig, stride, d_len, nreads);
+    if (rc) return rc;
+    if ((rc = check_seg_params(p))) return rc;
+    if (max_segs <= 0) return sk_fail(SK_ERR_INVALID, "max_segs must be positive");
+    if (nreads == 0) return SK_OK;
+    if (!d_cal2 || !d_segs || !d_nsegs) return sk_fail(SK_ERR_INVALID, "NULL cal2/segs/nsegs");
+    return segment_dev_i16_pa(c, d_sig, stride, d_len, nreads, d_cal2, p, d_segs, d_nsegs, max_segs);
+}
+
 int sk_segment_batch_i16_pa(const int16_t *sig, int64_t stride, const int32_t *len, int32_t nreads, const double *calib,
                             const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs)
 {
@@ -906,38 +990,45 @@ int sk_segment_batch_i16_pa(const int16_t *sig, int64_t stride, const int32_t *l
     if (max_segs <= 0) return sk_fail(SK_ERR_INVALID, "max_segs must be positive");
     if (nreads == 0) return SK_OK;
     if (!calib || !segs || !nsegs) return sk_fail(SK_ERR_INVALID, "NULL calib/segs/nsegs");
-    std::vector<int64_t> off((size_t)nreads + 1);
     std::vector<double> cal((size_t)nreads * 2);
-    int64_t maxlen = 0;
-    off[0] = 0;
-    for (int32_t r = 0; r < nreads; r++) {
-        off[r + 1] = off[r] + len[r];
-        if (len[r] > maxlen) maxlen = len[r];
-        const double dig = calib[3 * r], ofs = calib[3 * r + 1], rng = calib[3 * r + 2];
-        char txt[512];
-        snprintf(txt, sizeof txt, "%.2f", rng);              // float("{0:.2f}".format(range))
-        cal[2 * r] = ofs;
-        cal[2 * r + 1] = strtod(txt, nullptr) / dig;         // raw_unit = range / digitisation
-    }
-    const int64_t total = off[nreads];
+    if ((rc = sk_pa_calib(calib, nreads, cal.data()))) return rc;
     const size_t sb = (size_t)nreads * (size_t)stride * sizeof(int16_t);
     const size_t gb = (size_t)nreads * 2 * (size_t)max_segs * sizeof(int32_t);
     if ((rc = sk_reserve(c, &c->misc, sb))) return rc;
-    if ((rc = sk_reserve(c, &c->sig, (size_t)(total > 0 ? total : 1) * sizeof(double)))) return rc;
-    if ((rc = sk_reserve(c, &c->off, off.size() * sizeof(int64_t)))) return rc;
+    if ((rc = sk_reserve(c, &c->len, (size_t)nreads * sizeof(int32_t)))) return rc;
     if ((rc = sk_reserve(c, &c->pacal, cal.size() * sizeof(double)))) return rc;
     if ((rc = sk_reserve(c, &c->out, gb))) return rc;
     if ((rc = sk_reserve(c, &c->out2, (size_t)nreads * sizeof(int32_t)))) return rc;
-    SK_HIP(hipMemcpyAsync(c->misc.p, sig, sb, hipMemcpyHostToDevice, c->stream));
-    SK_HIP(hipMemcpyAsync(c->off.p, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     SK_HIP(hipMemcpyAsync(c->pacal.p, cal.data(), cal.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    SK_HIP(hipStreamSynchronize(c->stream));                 // off / cal go out of scope
-    rc = sk_launch_rows_to_pa(c, (const int16_t *)c->misc.p, stride, nreads, (const int64_t *)c->off.p,
-                              (const double *)c->pacal.p, (double *)c->sig.p);
-    if (rc) return rc;
-    rc = segment_dev_f64(c, (const double *)c->sig.p, (const int64_t *)c->off.p, nreads, total, maxlen, p,
-                         (int32_t *)c->out.p, (int32_t *)c->out2.p, max_segs);
-    if (rc) return rc;
+    SK_HIP(hipMemcpyAsync(c->len.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    // rows in sub-batches, the copy of one beside the kernels of the one before (as sk_segment_batch_i16)
+    const SubBatches B = sub_batches(nreads, stride);
+    if (B.n > 1 && (rc = second_stream(c))) return rc;
+    SK_HIP(hipStreamSynchronize(c->stream));                 // cal goes out of scope; len / cal are there for every sub-batch
+    // (the float64 fallback keeps its lengths in c->len as well: it gets a copy of its own)
+    const bool raw_domain = sk_segment_pa_applies(c->misc.p, stride, p->std_scale);
+    if (!raw_domain) {
+        if ((rc = sk_reserve(c, &c->rlen, (size_t)nreads * sizeof(int32_t)))) return rc;
+        SK_HIP(hipMemcpyAsync(c->rlen.p, len, (size_t)nreads * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
+    for (int32_t bi = 0; bi < (raw_domain ? B.n : 1); bi++) {
+        const int32_t per = raw_domain ? B.per : nreads;
+        const int32_t r0 = bi * per;
+        const int32_t nr = (nreads - r0 < per) ? nreads - r0 : per;
+        if (nr <= 0) break;
+        int16_t *d_sig = (int16_t *)c->misc.p + (size_t)r0 * (size_t)stride;
+        hipStream_t cs = (raw_domain && B.n > 1) ? c->stream2 : c->stream;
+        SK_HIP(hipMemcpyAsync(d_sig, sig + (size_t)r0 * (size_t)stride, (size_t)nr * (size_t)stride * sizeof(int16_t),
+                              hipMemcpyHostToDevice, cs));
+        if (cs != c->stream) {
+            SK_HIP(hipEventRecord(c->ev_chunk[bi & 7], cs));
+            SK_HIP(hipStreamWaitEvent(c->stream, c->ev_chunk[bi & 7], 0));
+        }
+        rc = segment_dev_i16_pa(c, d_sig, stride, (const int32_t *)(raw_domain ? c->len.p : c->rlen.p) + r0, nr,
+                                (const double *)c->pacal.p + 2 * (size_t)r0, p,
+                                (int32_t *)c->out.p + (size_t)r0 * 2 * (size_t)max_segs, (int32_t *)c->out2.p + r0, max_segs);
+        if (rc) return rc;
+    }
     SK_HIP(hipMemcpyAsync(segs, c->out.p, gb, hipMemcpyDeviceToHost, c->stream));
     SK_HIP(hipMemcpyAsync(nsegs, c->out2.p, (size_t)nreads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     SK_HIP(hipStreamSynchronize(c->stream));

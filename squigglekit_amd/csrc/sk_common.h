@@ -92,6 +92,9 @@ struct sk_ctx {
     std::vector<unsigned> motifq_host;
     bool   motifq_valid = false;
     int    f64_stream = 0;   // the last float64 call took the streaming statistics kernel (its retry count: retry[0])
+    int    pa_raw = 0;       // the last pA call of raw rows stayed in the raw domain (k_seg_stats<.., PA>)
+    std::vector<const int32_t *> pa_retry_ptrs;   // ... the device counters of its numpy-order redo lists (one per chunk)
+    std::vector<int64_t> pa_off_host;             // slot offsets of the float64 fallback of that route
     int    last_retry = 0;   // reads that needed the exact single-pass retry in the last DTW call
     std::vector<hipEvent_t> evpool;   // per-launch events of the two-pass DTW (3 per chunk)
     int    prof_chunks = 0;  // chunks of the last two-pass DTW call (0: single pass)
@@ -223,9 +226,16 @@ int sk_launch_roll_walk(sk_ctx *c, const uint64_t *d_below, const uint64_t *d_ab
 // ---- segmenter, streaming path (sk_segstat.hip) ----
 int  sk_segment_fast_row16(int64_t stride);
 bool sk_segment_fast_applies(const void *d_sig, int64_t stride, int32_t lo, int32_t hi, double std_scale);
+// d_cal != nullptr: the pA route in the raw domain (round 6) -- [nreads][2] = {offset, range / digitisation}; lo / hi are
+// then the limits in pA and d_scratch holds num_cu rows of `stride` doubles for the numpy-order redo
 int  sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
                             const sk_seg_params *p, int32_t lo, int32_t hi, sk_prep *d_prep, void *d_mask2,
-                            int32_t *d_retry, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs);
+                            int32_t *d_retry, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs,
+                            const double *d_cal = nullptr, double *d_scratch = nullptr);
+bool sk_segment_pa_applies(const void *d_sig, int64_t stride, double std_scale);
+int  sk_launch_prep_pa_listed(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, const double *d_cal,
+                              const int32_t *d_list, const int32_t *d_count, int grid, double lo, double hi, double std_scale,
+                              double *d_scratch, int64_t scratch_stride, sk_prep *d_prep, void *d_mask2, int row16);
 
 // ---- segment walk (sk_segment.hip) ----
 struct sk_drna_params;

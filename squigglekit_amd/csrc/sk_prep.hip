@@ -950,10 +950,44 @@ struct PrepF64Shared {
     unsigned long long sel_list[SEL_LIST];
 };
 
+// where a read's float64 samples come from: the caller's doubles, or (round 6) int16 raw samples through the pA
+// conversion of segmenter.py:345-349 -- np.round((x + offset) * unit, 2) = rint(y * 100) / 100, value for value what
+// k_rows_to_pa (sk_synth.hip) writes -- for the reads the raw-domain pA segmenter (k_seg_stats<.., PA>) cannot certify
+struct RowF64 {
+    const double *p;
+    __device__ __forceinline__ double operator[](int i) const { return p[i]; }
+};
+struct RowPA {
+    const int16_t *p;
+    double offset, unit;
+    __device__ __forceinline__ double operator[](int i) const
+    {
+        const double v = ((double)p[i] + offset) * unit;
+        return rint(v * 100.0) / 100.0;
+    }
+};
+
+template <bool LISTED, typename Row>
+__device__ void prep_f64_core(PrepF64Shared *sh, int r, const Row row, int M, double *__restrict__ crow,
+                              double lo, double hi, int mode, double std_scale, sk_prep *__restrict__ prep,
+                              uint64_t *__restrict__ maskT, int64_t mask_rows, const ListedF64 &la);
+
 template <bool LISTED>
 __device__ void prep_f64_read(PrepF64Shared *sh, int r, const double *__restrict__ sig, const int64_t *__restrict__ off,
                               double lo, double hi, int mode, double std_scale,
                               double *__restrict__ comp, sk_prep *__restrict__ prep,
+                              uint64_t *__restrict__ maskT, int64_t mask_rows, const ListedF64 &la)
+{
+    const int64_t o0 = off[r];
+    int M = (int)(off[r + 1] - o0);
+    if (la.len) M = min(M, max(la.len[r], 0));
+    double *crow = (LISTED && mode == SK_PREP_SEGMENT) ? comp + (int64_t)blockIdx.x * la.scratch_stride : comp + o0;
+    prep_f64_core<LISTED>(sh, r, RowF64{sig + o0}, M, crow, lo, hi, mode, std_scale, prep, maskT, mask_rows, la);
+}
+
+template <bool LISTED, typename Row>
+__device__ void prep_f64_core(PrepF64Shared *sh, int r, const Row row, int M, double *__restrict__ crow,
+                              double lo, double hi, int mode, double std_scale, sk_prep *__restrict__ prep,
                               uint64_t *__restrict__ maskT, int64_t mask_rows, const ListedF64 &la)
 {
     Scratch *sc = &sh->sc;
@@ -962,11 +996,6 @@ __device__ void prep_f64_read(PrepF64Shared *sh, int r, const double *__restrict
     unsigned long long *sel_list = sh->sel_list;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t o0 = off[r];
-    int M = (int)(off[r + 1] - o0);
-    if (la.len) M = min(M, max(la.len[r], 0));
-    const double *row = sig + o0;
-    double *crow = (LISTED && mode == SK_PREP_SEGMENT) ? comp + (int64_t)blockIdx.x * la.scratch_stride : comp + o0;
     if (tid < 4) sc->sel[tid] = 0;
     if (tid == 0) sc->tree_m = -1;
 
@@ -1120,6 +1149,26 @@ void k_prep_f64(const double *__restrict__ sig, const int64_t *__restrict__ off,
         }
     } else {
         prep_f64_read<false>(&sh, blockIdx.x, sig, off, lo, hi, mode, std_scale, comp, prep, maskT, mask_rows, la);
+    }
+}
+
+// The numpy-order redo of the raw-domain pA segmenter's uncertified reads (k_seg_stats<.., PA>, sk_segstat.hip): read
+// list[k] is sig[r * stride .. + len[r]) through its own {offset, unit}; one scratch row of doubles per workgroup;
+// prep records and the {in band, kept} entries of those reads are rewritten in place.
+__global__ __launch_bounds__(TPB)
+void k_prep_pa_listed(const int16_t *__restrict__ sig, int64_t stride, const int32_t *__restrict__ len,
+                      const double *__restrict__ cal, double lo, double hi, double std_scale,
+                      double *__restrict__ scratch, sk_prep *__restrict__ prep, ListedF64 la)
+{
+    __shared__ PrepF64Shared sh;
+    const int cnt = *la.count;
+    for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
+        __syncthreads();                                   // the previous read is done with the shared scratch
+        const int r = la.list[k];
+        const int M = (int)min((int64_t)max(len[r], 0), stride);
+        prep_f64_core<true>(&sh, r, RowPA{sig + (int64_t)r * stride, cal[2 * r], cal[2 * r + 1]}, M,
+                            scratch + (int64_t)blockIdx.x * la.scratch_stride, lo, hi, SK_PREP_SEGMENT, std_scale, prep,
+                            (uint64_t *)nullptr, (int64_t)0, la);
     }
 }
 
@@ -1892,6 +1941,22 @@ int sk_launch_prep_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off, int
     la.list = nullptr; la.count = nullptr; la.mask2 = nullptr; la.row16 = 0; la.scratch_stride = 0; la.len = d_rlen;
     hipLaunchKernelGGL(k_prep_f64<false>, dim3(nreads), dim3(TPB), 0, c->stream, d_sig, d_off, nreads, lo, hi, mode,
                        std_scale, d_comp, d_prep, d_mask, mask_rows, la);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
+}
+
+// numpy-order redo of listed raw reads through the pA conversion (see k_prep_pa_listed): d_scratch holds `grid` rows of
+// scratch_stride doubles
+int sk_launch_prep_pa_listed(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, const double *d_cal,
+                             const int32_t *d_list, const int32_t *d_count, int grid, double lo, double hi, double std_scale,
+                             double *d_scratch, int64_t scratch_stride, sk_prep *d_prep, void *d_mask2, int row16)
+{
+    if (grid <= 0) return SK_OK;
+    ListedF64 la;
+    la.list = d_list; la.count = d_count; la.mask2 = (unsigned char *)d_mask2; la.row16 = row16;
+    la.scratch_stride = scratch_stride; la.len = nullptr;
+    hipLaunchKernelGGL(k_prep_pa_listed, dim3(grid), dim3(TPB), 0, c->stream, d_sig, stride, d_len, d_cal, lo, hi, std_scale,
+                       d_scratch, d_prep, la);
     SK_HIP(hipGetLastError());
     return SK_OK;
 }

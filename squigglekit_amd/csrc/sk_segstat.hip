@@ -64,6 +64,12 @@ __device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b_uniform)
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b_uniform));
     return r;
 }
+__device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b)          // signed maximum per half
+{
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ unsigned pk_min1_u16(unsigned a)                     // min(a, 1) per half
 {
     unsigned r;
@@ -139,7 +145,66 @@ struct SegStatArgs {
     int32_t       *retry;            // [0] = count, [1 ..] = reads that could not be certified
     unsigned      *hints;            // [nreads][SEG_HINTS] for k_seg_walk4 (reads of up to 4 096 samples), or nullptr
     int            e1;               // the walk's error + 1 (hints)
+    const double  *cal;              // PA: [nreads][2] = {offset, range / digitisation} of each read (else unused)
 };
+
+// ---- the pA route in the raw domain (PA = true; round 6) -----------------------------------------------------------
+// segmenter.py:345-349 / :366-370 turn a fast5 / slow5 read into v(x) = np.round((x + offset) * unit, 2) before
+// scale_outliers / get_segs see it.  np.round(y, 2) is rint(y * 100) / 100, so v(x) = c(x) / 100 with
+//     c(x) = rint(fl(fl(x + offset) * unit) * 100)        an INTEGER ("centi-pA"), non-decreasing in x for unit > 0
+// (every step is a monotone function followed by a monotone rounding).  So everything the segmenter does with v can be
+// done on the int16 samples themselves, 2 bytes per sample instead of 8:
+//   * kept   <=> lim_low < v(x) < lim_hi <=> 100 lim_low < c(x) < 100 lim_hi   (exact: RN(c / 100) > L <=> c > 100 L for
+//     an integer L, as c / 100 >= L + 0.01 cannot round down to L)            <=> xa <= x <= xb;
+//   * np.median of the kept v = (v(x1) + v(x2)) / 2 with x1, x2 the two middle kept SAMPLES (v is monotone);
+//   * np.std of the kept v: the exact integer sums C1 = sum c', C2 = sum c'^2 (c' = c - c(xa)) come out of the read's
+//     value histogram, V = n C2 - C1^2 is exact in 128 bits, std_true = sqrt(V) / (100 n) up to the roundings of the
+//     c / 100 (<= vmax eps / 2 each) and numpy's own summation error, both inside delta below;
+//   * in band <=> bot < v(x) < top <=> x inside [first x with c(x) certainly above 100 bot, last x with c(x) certainly
+//     below 100 top]: CERTIFIED when no c(x) of the window lies within Delta of 100 top / 100 bot, Delta from delta.
+// delta: |std_numpy - std_true| <= (n + 16) eps std_true (the n roundings of a sum of non-negative terms in ANY order,
+// three per term, the division, the root) + |mean_numpy - mean_true| (a shift of the mean by e changes the root of the
+// mean square deviation by at most |e|; numpy adds pairwise inside chunks of 8 192 and serially across them:
+// |e| <= (n / 8192 + 32) eps vmax); |std_true - sqrt(V) / (100 n)| <= vmax eps (the c / 100) + 4 eps std (the 128-bit
+// value to double, root, two divisions); the median's two roundings and top / bot's one: 3 eps vmax.  Hence
+//     delta = 8 eps (|spread| (n + 17) + |median| + vmax (1 + |std_scale|) (n / 8192 + 36))         (8x headroom)
+// Reads that cannot be certified (about 1e-8), whose kept samples do not fit the histogram window (a spike more than
+// HBINS - 1 raw units above xa), or whose calibration is outside the plain range go to the retry list and are redone from
+// their float64 values in numpy's order (k_prep_pa_listed, sk_prep.hip).
+constexpr double PA_UNIT_MIN = 1.0 / 64, PA_UNIT_MAX = 1.25, PA_OFFSET_MAX = 16777216.0;   // c' < 2^18 over 2 047 bins
+
+__device__ __forceinline__ double pa_centi(int x, double off, double unit)
+{
+    return rint((((double)x + off) * unit) * 100.0);      // (-ffp-contract=off: three roundings and an exact rint)
+}
+// first x in [x0, x0 + count) with c(x) >= T (STRICT: > T), or x0 + count; count <= 65 536; c non-decreasing
+template <bool STRICT>
+__device__ __forceinline__ int pa_first(double T, int x0, int count, double off, double unit, int lane)
+{
+    int base = x0, span = count;                          // the answer lies in [base, base + span] (span: none)
+#pragma unroll 1
+    for (int blk = count > 2048 ? 1024 : (count > 64 ? 32 : 1); ; blk = blk > 32 ? 16 : 1) {
+        const int x = base + blk * (lane + 1) - 1;        // the last x of my block
+        const bool inside = blk * (lane + 1) - 1 < span;
+        const double cx = pa_centi(x, off, unit);
+        const unsigned long long m = __ballot(inside && (STRICT ? cx > T : cx >= T));
+        if (m == 0ull) {
+            // nothing among the block ends: the answer lies behind the last complete block (or nowhere)
+            const int done = (span / blk) * blk;
+            if (blk == 1 || done == span) return x0 + count;
+            base += done; span -= done;
+        } else {
+            const int l1 = (int)__builtin_ctzll(m);
+            if (blk == 1) return base + l1;
+            base += blk * l1; span = blk;                 // inside block l1, whose end satisfies: always found below
+        }
+    }
+}
+__device__ __forceinline__ void umul64wide(unsigned long long a, unsigned long long b, unsigned long long &hi, unsigned long long &lo)
+{
+    lo = a * b;
+    hi = __umul64hi(a, b);
+}
 
 // NT: 512-sample tiles held in registers (one "window" of 512 NT samples)
 // NQ: 16-byte histogram chunks per lane -- 256 NQ bins per wave
@@ -151,7 +216,7 @@ struct SegStatArgs {
 // every dropped x land at t >= nbins, no aliasing), and t' = min(t, nbins) sends every dropped sample -- and the
 // slots past the read's end -- to ONE dump bin, `nbins`.  Two packed instructions per pair of samples; the exact
 // sums run over t' and are corrected by the dump bin's count afterwards.
-template <int NT, int NQ, int OCC, bool LONG>
+template <int NT, int NQ, int OCC, bool LONG, bool PA = false>
 __global__ __launch_bounds__(64 * WPB, OCC)
 void k_seg_stats(const SegStatArgs a)
 {
@@ -165,9 +230,11 @@ void k_seg_stats(const SegStatArgs a)
     unsigned char *p_in = plane_all[w][0], *p_dr = plane_all[w][1];
     const int hb0 = lane * 4 * NQ;                         // first bin this lane owns
 
-    const int nbins = a.hi - a.lo - 1;                     // 1 .. min(HBINS - 1, MAXBINS) (host)
-    const unsigned lo1p = (unsigned)((a.lo + 1) & 0xffff) * 0x10001u;
-    const unsigned nbp = (unsigned)nbins * 0x10001u, nbm1p = (unsigned)(nbins - 1) * 0x10001u;
+    // (PA: the limits, and with them the histogram window, are per read -- wave-uniform values set at the top of the loop)
+    int nbins = a.hi - a.lo - 1;                           // 1 .. min(HBINS - 1, MAXBINS) (host)
+    int lo_r = a.lo;                                       // bin t holds the sample value lo_r + 1 + t
+    unsigned lo1p = (unsigned)((a.lo + 1) & 0xffff) * 0x10001u;
+    unsigned nbp = (unsigned)nbins * 0x10001u, nbm1p = (unsigned)(nbins - 1) * 0x10001u;
     const int maxM = (int)min(a.stride, (int64_t)(LONG ? MAXLONG : WIN));
 
 #pragma unroll
@@ -202,8 +269,47 @@ void k_seg_stats(const SegStatArgs a)
         const int nwin = LONG ? (M + WIN - 1) / WIN : 1;
         const int tiles_total = (M + 511) >> 9;
 
+        // ---- PA: this read's limits in the raw domain, its histogram window -------------------------------------
+        bool pa_ok = true;
+        double pa_off = 0.0, pa_unit = 1.0, pa_c0 = 0.0;
+        int pa_span = 0;                                   // sample values the filter keeps: xa .. xa + pa_span - 1
+        if constexpr (PA) {
+            pa_off = a.cal[2 * r]; pa_unit = a.cal[2 * r + 1];
+            pa_ok = pa_unit >= PA_UNIT_MIN && pa_unit <= PA_UNIT_MAX && fabs(pa_off) <= PA_OFFSET_MAX;   // (NaN: false)
+            int xa = 0, xb = -1;
+            if (pa_ok) {
+                xa = pa_first<true>(100.0 * (double)a.lo, -32768, 65536, pa_off, pa_unit, lane);       // first kept value
+                xb = pa_first<false>(100.0 * (double)a.hi, -32768, 65536, pa_off, pa_unit, lane) - 1;  // last kept value
+            }
+            xa = __builtin_amdgcn_readfirstlane(xa); xb = __builtin_amdgcn_readfirstlane(xb);
+            pa_span = max(xb - xa + 1, 0);
+            nbins = min(pa_span, HBINS - 1);
+            lo_r = xa - 1;
+            lo1p = (unsigned)(xa & 0xffff) * 0x10001u;
+            nbp = (unsigned)nbins * 0x10001u; nbm1p = (unsigned)((nbins - 1) & 0xffff) * 0x10001u;
+            pa_c0 = pa_centi(xa, pa_off, pa_unit);
+            if (nbins > 0 && !(pa_centi(xa + nbins - 1, pa_off, pa_unit) - pa_c0 < 262144.0)) { pa_ok = false; nbins = 0; }
+            if (nbins == 0) {
+                // nothing can be kept (or a calibration outside the plain range: the redo rewrites all of this)
+                for (int wi = 0; wi < nwin; wi++) {
+                    const int ntiles = (min(M - wi * WIN, WIN) + 511) >> 9;
+                    if (lane < 8 * ntiles) a.mask2[(int64_t)r * a.row16 + wi * (8 * NT) + lane] = make_uint4(0u, 0u, 0u, 0u);
+                }
+                if (lane == 0) {
+                    sk_prep pe;
+                    const double qnan = __builtin_nan("");
+                    pe.n = 0; pe.flags = SK_FLAG_EMPTY; pe.center = qnan; pe.scale = qnan; pe.top = qnan; pe.bot = qnan;
+                    a.prep[r] = pe;
+                    if (!pa_ok) a.retry[1 + atomicAdd(&a.retry[0], 1)] = r;
+                    if (!LONG && a.hints) a.hints[(int64_t)r * SEG_HINTS] = SEG_HINT_NONE;
+                }
+                continue;
+            }
+        }
+
         // ---- first look: t' per sample, exact sums, histogram -------------------------------------------------
         long long S = 0, Q = 0;
+        unsigned mxp = 0x80008000u;                        // PA: running maximum of the raw samples (packed halves)
         for (int wi = 0; wi < nwin; wi++) {
             const int Mw = min(M - wi * WIN, WIN);
             const int ntiles = (Mw + 511) >> 9;
@@ -215,11 +321,21 @@ void k_seg_stats(const SegStatArgs a)
                 const int nvalid = min(max(Mw - (t * 512 + lane * 8), 0), 8);   // samples of this lane's eight that exist
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
+                    if constexpr (PA) {                    // a kept value above the histogram window? (the maximum tells)
+                        unsigned qm = y[t][k];
+                        if (t == ntiles - 1) {
+                            const unsigned tail = nvalid >= 2 * k + 2 ? 0xffffffffu : (nvalid == 2 * k + 1 ? 0xffffu : 0u);
+                            qm = (qm & tail) | (0x80008000u & ~tail);
+                        }
+                        mxp = pk_max_i16(mxp, qm);
+                    }
                     const unsigned tt = image(y[t][k], t, k, ntiles, nvalid);
                     y[t][k] = tt;
                     const s16x2 ts = __builtin_bit_cast(s16x2, tt);
+                    if constexpr (!PA) {
                     st = __builtin_amdgcn_sdot2(ts, __builtin_bit_cast(s16x2, 0x10001u), st, false);
                     stt = __builtin_amdgcn_sdot2(ts, ts, stt, false);
+                    }
                     const unsigned t4 = pk_shl2_u16(tt);                     // byte offsets of the two bins
                     atomicAdd((unsigned *)((char *)hist + (t4 & 0xffffu)), 1u);
                     atomicAdd((unsigned *)((char *)hist + (t4 >> 16)), 1u);
@@ -228,8 +344,10 @@ void k_seg_stats(const SegStatArgs a)
                 // before it issues the first atomic
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (!PA) {
             S += (long long)wave_sum(st);
             Q += (long long)wave_sum(stt & 0xffff) + ((long long)wave_sum((int)((unsigned)stt >> 16)) << 16);
+            }
         }
 
         // ---- exact integer totals (dump-bin entries taken out) ------------------------------------------------
@@ -254,7 +372,15 @@ void k_seg_stats(const SegStatArgs a)
         pr.n = n; pr.flags = 0; pr.center = 0.0; pr.scale = 1.0; pr.top = 0.0; pr.bot = 0.0;
         int tlo = 0, width = 0;                                              // in band: (unsigned)(t - tlo) < width
         bool certified = true;
+        // PA: a kept sample above the histogram window was counted as dropped -- the statistics are not the read's
+        bool over = false;
+        if constexpr (PA) {
+            int mx = max((int)(short)(mxp & 0xffffu), (int)(short)(mxp >> 16));
+            mx = (int)__builtin_amdgcn_readlane((int)wave_incl_max((unsigned)(mx + 32768)), 63) - 32768;
+            over = pa_span > nbins && mx >= lo_r + 1 + nbins;
+        }
         if (n == 0) {
+            certified = !over;
             pr.flags = SK_FLAG_EMPTY;
             const double qnan = __builtin_nan("");
             pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
@@ -278,6 +404,48 @@ void k_seg_stats(const SegStatArgs a)
             const unsigned long long own2 = __ballot(local > 0 && k2 >= pre && k2 < pre + local);
             const int b1 = __builtin_amdgcn_readlane(i1, own1 ? (int)__builtin_ctzll(own1) : 0);
             const int b2 = __builtin_amdgcn_readlane(i2, own2 ? (int)__builtin_ctzll(own2) : 0);
+            const double eps8 = 8.0 * 1.1102230246251565e-16;
+            if constexpr (PA) {
+                // ---- the pA values' median, their std from exact centi-pA sums, thresholds certified in the c domain ----
+                const int xa = lo_r + 1;
+                const double median = (pa_centi(xa + b1, pa_off, pa_unit) / 100.0 + pa_centi(xa + b2, pa_off, pa_unit) / 100.0) / 2.0;
+                unsigned long long V1 = 0, V2 = 0;                               // C1, C2
+                {
+                    unsigned long long c1 = 0, c2 = 0;
+                    for (int j = 0; j < 4 * NQ; j++) {                           // bin 64 j + lane (conflict-free)
+                        const unsigned k = hist[64 * j + lane];
+                        if (__ballot(k != 0u) == 0ull) continue;
+                        const unsigned cp = (unsigned)(int)(pa_centi(xa + 64 * j + lane, pa_off, pa_unit) - pa_c0);
+                        const unsigned long long pk = (unsigned long long)k * (k ? cp : 0u);
+                        c1 += pk; c2 += pk * (k ? cp : 0u);
+                    }
+#pragma unroll
+                    for (int sft = 32; sft >= 1; sft >>= 1) { c1 += __shfl_xor(c1, sft); c2 += __shfl_xor(c2, sft); }
+                    V1 = c1; V2 = c2;
+                }
+                unsigned long long ah, al, bh, bl;
+                umul64wide((unsigned long long)n, V2, ah, al);                   // n C2
+                umul64wide(V1, V1, bh, bl);                                      // C1^2
+                const unsigned long long vl = al - bl, vh = ah - bh - (al < bl ? 1ull : 0ull);   // V = n C2 - C1^2 >= 0
+                const double Vd = (double)vh * 18446744073709551616.0 + (double)vl;
+                const double sd = sqrt(Vd) / (double)n / 100.0;
+                const double spread = sd * a.std_scale;                          // segmenter.py:413-414
+                const double top = median + spread, bot = median - spread;
+                const double vmax = fmax(fabs(pa_c0), fabs(pa_centi(xa + nbins - 1, pa_off, pa_unit))) / 100.0;
+                const double delta = a.delta_scale * eps8 * (fabs(spread) * (double)(n + 17) + fabs(median) +
+                                                             vmax * (1.0 + fabs(a.std_scale)) * ((double)n / 8192.0 + 36.0));
+                const double Dl = 100.0 * delta + 100.0 * eps8 * (fabs(top) + fabs(bot) + vmax);
+                const double Tt = top * 100.0, Tb = bot * 100.0;
+                // xt: the first window value not certainly below top; xl: the first certainly above bot
+                const int xt = __builtin_amdgcn_readfirstlane(pa_first<true>(Tt - Dl, xa, nbins, pa_off, pa_unit, lane));
+                const int xl = __builtin_amdgcn_readfirstlane(pa_first<false>(Tb + Dl, xa, nbins, pa_off, pa_unit, lane));
+                const bool cert_t = xt == xa + nbins || pa_centi(xt, pa_off, pa_unit) >= Tt + Dl;
+                const bool cert_b = xl == xa || pa_centi(xl - 1, pa_off, pa_unit) <= Tb - Dl;
+                certified = cert_t && cert_b && !over;
+                pr.center = median; pr.scale = sd; pr.top = top; pr.bot = bot;
+                tlo = xl - xa;                                                   // first in-band bin
+                width = max((xt - 1 - xa) - tlo + 1, 0);
+            } else {
             const double median = (double)(b1 + b2 + 2 * (a.lo + 1)) * 0.5;  // exact (half-integer)
 
             // ---- thresholds from exact integers; certify ceil(top) / floor(bot) against numpy's rounding -------
@@ -285,7 +453,6 @@ void k_seg_stats(const SegStatArgs a)
             const double sd = sqrt((double)V) / (double)n;
             const double spread = sd * a.std_scale;                          // segmenter.py:413-414
             const double top = median + spread, bot = median - spread;
-            const double eps8 = 8.0 * 1.1102230246251565e-16;
             const double delta = a.delta_scale * eps8 * (fabs(spread) * (double)(n + 17) + fabs(median));
             const double ct = ceil(top), fb = floor(bot);
             certified = (V == 0) || (ceil(top - delta) == ct && ceil(top + delta) == ct &&
@@ -297,6 +464,7 @@ void k_seg_stats(const SegStatArgs a)
             tlo = max((int)fbc - a.lo, 0);                                   // first in-band bin: value floor(bot) + 1
             const int thi = min((int)ctc - a.lo - 2, nbins - 1);             // last in-band bin: value ceil(top) - 1
             width = max(thi - tlo + 1, 0);
+            }
         }
 #pragma unroll
         for (int j = 0; j < NQ; j++) *(uint4 *)(hist + hb0 + 4 * j) = make_uint4(0u, 0u, 0u, 0u);   // (my reads are done)
@@ -972,10 +1140,16 @@ WalkParams walk_params(const sk_seg_params *p, bool *fast)
 
 typedef void (*segstat_fn)(const SegStatArgs);
 
-segstat_fn pick_stats(int64_t stride, int nbins)
+segstat_fn pick_stats(int64_t stride, int nbins, bool pa)
 {
     const bool small = nbins <= 1023;          // 4 KB of histogram per wave
     const int NT = (int)((stride + 511) / 512);
+    if (pa) {                                  // per-read windows of up to 2 047 raw units
+        if (NT <= 2) return k_seg_stats<2, 8, 8, false, true>;
+        if (NT <= 4) return k_seg_stats<4, 8, 8, false, true>;
+        if (NT > 8) return k_seg_stats<8, 8, 8, true, true>;
+        return k_seg_stats<8, 8, 8, false, true>;
+    }
     if (NT <= 2) return small ? k_seg_stats<2, 4, 8, false> : k_seg_stats<2, 8, 8, false>;
     if (NT <= 4) return small ? k_seg_stats<4, 4, 8, false> : k_seg_stats<4, 8, 8, false>;
     if (NT > 8) return small ? k_seg_stats<8, 4, 6, true> : k_seg_stats<8, 8, 8, true>;
@@ -1001,6 +1175,15 @@ int sk_segment_fast_row16(int64_t stride)
     return 8 * (NT <= 2 ? 2 : NT <= 4 ? 4 : 8);
 }
 
+// The raw-domain pA route: any limits (they are per read, in the kernel); rows as the streaming path wants them.
+bool sk_segment_pa_applies(const void *d_sig, int64_t stride, double std_scale)
+{
+    if (sk_tune("SK_SEG_PA_F64")) return false;              // A/B switch: expand to float64, the float64 kernels
+    if (stride > MAXLONG || (stride % 8) != 0 || ((uintptr_t)d_sig & 15) != 0) return false;
+    if (!(std_scale == std_scale) || fabs(std_scale) > 1e6) return false;
+    return true;
+}
+
 // Is (stride, limits, std_scale) inside the streaming path's range?  (else: k_prep_i16 + k_segment_walk)
 bool sk_segment_fast_applies(const void *d_sig, int64_t stride, int32_t lo, int32_t hi, double std_scale)
 {
@@ -1019,11 +1202,12 @@ bool sk_segment_fast_applies(const void *d_sig, int64_t stride, int32_t lo, int3
 // other segment paths: ev[0]..ev[1] statistics of all chunks, ev[2]..ev[3] what is left of the walks after that.
 int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
                            const sk_seg_params *p, int32_t lo, int32_t hi, sk_prep *d_prep, void *d_mask2,
-                           int32_t *d_retry, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs)
+                           int32_t *d_retry, int32_t *d_segs, int32_t *d_nsegs, int32_t max_segs,
+                           const double *d_cal, double *d_scratch)
 {
-    segstat_fn fn = pick_stats(stride, hi - lo - 1);
+    segstat_fn fn = pick_stats(stride, hi - lo - 1, d_cal != nullptr);
     SegStatArgs a;
-    a.stride = stride; a.lo = lo; a.hi = hi;
+    a.stride = stride; a.lo = lo; a.hi = hi; a.cal = d_cal;
     a.std_scale = p->std_scale; a.delta_scale = 1.0;
     if (const char *e = sk_tune("SK_SEG_DELTA_SCALE")) { const double v = atof(e); if (v > 0) a.delta_scale = v; }
     a.row16 = sk_segment_fast_row16(stride);
@@ -1057,6 +1241,7 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
         a.hints = (unsigned *)c->seghints.p;
     }
     unsigned *const hints0 = a.hints;
+    if (d_cal) c->pa_retry_ptrs.clear();
     SK_HIP(hipMemsetAsync(d_retry, 0, ((size_t)nreads + 16) * sizeof(int32_t), c->stream));
     SK_HIP(hipEventRecord(c->ev[0], c->stream));
     if (nchunks > 1) {                                             // the second stream starts behind the memsets
@@ -1072,6 +1257,7 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
         a.sig = d_sig + (int64_t)r0 * stride; a.len = d_len + r0; a.nreads = nr;
         a.prep = d_prep + r0; a.mask2 = (uint4 *)d_mask2 + (int64_t)r0 * a.row16; a.retry = retry;
         a.hints = hints0 ? hints0 + (int64_t)r0 * SEG_HINTS : nullptr;
+        a.cal = d_cal ? d_cal + 2 * (int64_t)r0 : nullptr;
         // persistent grid: a whole number of "rounds" of what the chip actually holds (6 workgroups per CU at 78
         // VGPRs, not the 8 the thread limit allows) -- with 8 assumed the last round ran a third full
         int resident = per_cu;
@@ -1085,15 +1271,25 @@ int sk_launch_segment_fast(sk_ctx *c, const int16_t *d_sig, int64_t stride, cons
         SK_HIP(hipGetLastError());
         // reads whose ceil(top) / floor(bot) could not be certified: numpy-order statistics, masks rewritten in place
         // (reads too long for the redo's LDS copy: one scratch row per workgroup of its persistent grid, <= one per CU)
+        if (d_cal) {
+            c->pa_retry_ptrs.push_back(retry);
+            // (pA: the listed reads from their float64 values, one scratch row of doubles per workgroup)
+            const int g2 = nr < c->num_cu ? nr : c->num_cu;
+            int rc = sk_launch_prep_pa_listed(c, a.sig, stride, a.len, a.cal, retry + 1, retry, g2, (double)lo, (double)hi,
+                                              p->std_scale, d_scratch, stride, a.prep, a.mask2, a.row16);
+            if (rc) return rc;
+        }
         int16_t *scratch_rows = nullptr;
-        if (stride * (int64_t)sizeof(int16_t) > 24 * 1024) {
+        if (!d_cal && stride * (int64_t)sizeof(int16_t) > 24 * 1024) {
             int rc0 = sk_reserve(c, &c->comp, (size_t)c->num_cu * (size_t)stride * sizeof(int16_t));
             if (rc0) return rc0;
             scratch_rows = (int16_t *)c->comp.p;
         }
-        int rc = sk_launch_prep_i16(c, a.sig, stride, a.len, nr, lo, hi, SK_PREP_SEGMENT, p->std_scale, scratch_rows, a.prep,
-                                    nullptr, 0, 0, 0x7fffffff, retry + 1, retry, a.mask2, a.row16);
-        if (rc) return rc;
+        if (!d_cal) {
+            int rc = sk_launch_prep_i16(c, a.sig, stride, a.len, nr, lo, hi, SK_PREP_SEGMENT, p->std_scale, scratch_rows, a.prep,
+                                        nullptr, 0, 0, 0x7fffffff, retry + 1, retry, a.mask2, a.row16);
+            if (rc) return rc;
+        }
         hipStream_t ws = c->stream;
         if (nchunks > 1) {
             SK_HIP(hipEventRecord(c->ev_chunk[ci], c->stream));
