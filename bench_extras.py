@@ -322,6 +322,43 @@ def other_paths_block(a, L, main):
             "parity": {"reads_checked": int(len(rows)), "segments_bit_exact": bool(ok),
                        "segments_in_sample": int(nsegs[rows].sum())}}
 
+        # ---------------- the same reads as raw int16 rows + channel constants: the raw-domain pA route (round 6) -------------
+        def raw_pa_entry(d_raw, stride_, R_, M_, max_segs_, segs_f64, nsegs_f64, f64_secs):
+            """sk_segment_dev_i16_pa over the rows the float64 batch was made from (segmenter.py:345-349 with fast5 / slow5
+            input): EVERY record against the float64 path's (itself sampled against the oracle above)"""
+            lens_ = np.full(R_, M_, dtype=np.int32)
+            cal3 = np.tile(np.array([PA_DIGITISATION, PA_OFFSET, PA_RANGE]), (R_, 1))
+            cal2 = np.empty((R_, 2))
+            check(L.sk_pa_calib(ptr(cal3), R_, ptr(cal2)))
+            d_len_, d_cal_ = alloc(R_ * 4), alloc(R_ * 16)
+            check(L.sk_dev_upload(d_len_, ptr(lens_), lens_.nbytes))
+            check(L.sk_dev_upload(d_cal_, ptr(cal2), cal2.nbytes))
+            d_s, d_n = alloc(R_ * max_segs_ * 2 * 4), alloc(R_ * 4)
+            secs_, ev_ = best_of(lambda: check(L.sk_segment_dev_i16_pa(d_raw, stride_, d_len_, R_, d_cal_, C.byref(sp), d_s, d_n,
+                                                                      max_segs_)))
+            redone = int(L.sk_last_pa_retries())
+            s_ = np.empty((R_, max_segs_, 2), dtype=np.int32)
+            n_ = np.empty(R_, dtype=np.int32)
+            check(L.sk_dev_download(ptr(s_), d_s, s_.nbytes))
+            check(L.sk_dev_download(ptr(n_), d_n, n_.nbytes))
+            same = bool(np.array_equal(n_, nsegs_f64) and np.array_equal(s_, segs_f64))
+            for q in (d_len_, d_cal_, d_s, d_n):
+                L.sk_dev_free(q)
+                bufs.remove(q)
+            alg_ = R_ * (2 * M_ + 4 + 16 + 16)
+            return {"workload": "%d raw int16 reads x %d samples + channel constants -> pA in the raw domain "
+                                "(segmenter.py:345-349), default flags" % (R_, M_),
+                    "value": R_ / secs_, "unit": "reads/s", "ms_per_step": secs_ * 1e3,
+                    "speedup_vs_float64_route": f64_secs / secs_,
+                    "kernel_ms": {"statistics": ev_[0], "walk": ev_[1]}, "reads_redone_from_float64": redone,
+                    "roofline": {"bound": "hbm", "achieved": alg_ / secs_ / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": alg_ / secs_ / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg_,
+                                 "bytes_note": "2 B per sample resident (the float64 route: 8)",
+                                 "statistics_kernel_frac": (alg_ / (ev_[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ev_[0] > 0 else None},
+                    "parity": {"reads_checked": int(R_), "all_records_equal_float64_route": same,
+                               "float64_route_vs_oracle": "sampled above"}}
+        out["segmenter_raw_pA"] = raw_pa_entry(main.d_sig, main.stride, Rf, Mf, MAX_SEGS, segs, nsegs, secs)
+
         # ---------------- the same at real read lengths: 20 000 samples (C5-shaped) and 36 977 (the one measured read the
         # reference ships, example/slow5/0.blow5) -- segmenter AND MotifSeq: `MotifSeq.py --signal` parses every sample as a
         # float (MotifSeq.py:270), so this, not the int16 headline, is what the reference's default input looks like
@@ -363,6 +400,7 @@ def other_paths_block(a, L, main):
                              "statistics_kernel_frac": (alg / (ev[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ev[0] > 0 else None},
                 "parity": {"reads_checked": int(len(rows_l)), "segments_bit_exact": bool(ok_l),
                            "segments_in_sample": int(nsegs_l[rows_l].sum())}}
+            out["segmenter_raw_pA_%s" % tag] = raw_pa_entry(d_raw_l, MLs, RL, MLf, MAXS_L, segs_l, nsegs_l, secs)
             # MotifSeq, float64 medmad, against the example model (163 points)
             d_hits_l = alloc(RL * HIT_BYTES)
             secs, ev = best_of(lambda: check(L.sk_motifseq_dev_f64(d_pa_l, d_off_l, RL, RL * MLf, MLf, ptr(model163),
