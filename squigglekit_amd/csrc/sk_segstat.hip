@@ -1095,6 +1095,196 @@ void k_seg_walk4(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
     if (live) nsegs[r] = st.nseg;
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// the walk by runs with a WAVEFRONT per read: 64 lanes on 64 pieces of the same read (round 6)
+// ------------------------------------------------------------------------------------------------------
+// k_seg_walk4 gives every read one lane.  That is the right shape for a million short reads; for 25 000 reads of 37 000
+// samples it leaves 390 wavefronts on 1 024 SIMDs, each lane walking 580 mask entries through a chain of dependent
+// loads and ~60 dependent instructions per run: 1.4 ms, twice the statistics kernel in front of it (and the same for
+// 10 000 reads of 4 000 samples, BASELINE config 2: 157 wavefronts).  get_segs' scan (segmenter.py:420-464) is
+// sequential, but its state is KNOWN at every anchor -- an in-band sample whose E + 1 raw predecessors are all kept and
+// out of band: whatever run was open has been closed inside them, the scan is idle, the sample opens a run (the same
+// fact k_seg_walk4's jumps rest on).  So the read is cut into 64 pieces of ceil(entries / 64) mask entries; lane j finds
+// the first anchor at or behind the start of piece j (lane 0: sample 0), walks by runs from there and stops when the
+// next run would open at or behind the next lane's anchor -- where, by the anchor's definition, it is idle.  What the
+// pieces cannot know is whether the read already HAS a segment (:448: the first one needs c >= window * stall_len only)
+// and where the last one ended (:451, the merge): each lane keeps its first run with c >= min(window, first_len) and
+// every run with c >= window (at most 8: a piece of a staged row is <= 1 024 samples), and the wave combines them in
+// order -- the first lane that has anything contributes its first run, everything later contributes its long runs,
+// merged by seg_dist.  A read with more long runs in one piece than the list holds (rows beyond 65 536 samples) is
+// walked by lane 0 alone, sequentially.  Rows of up to 1 024 entries are staged in LDS with coalesced 16-byte loads.
+constexpr int WL_NB = 8;               // long runs noted per lane
+
+template <int E1C>
+__global__ __launch_bounds__(64)
+void k_seg_walkL(const uint4 *__restrict__ mask2, int row16, const int32_t *__restrict__ len, int64_t stride,
+                 int nreads, WalkParams p, int32_t *__restrict__ segs, int32_t *__restrict__ nsegs, int max_segs,
+                 int lds_entries)
+{
+    extern __shared__ __align__(16) uint4 wl_lds[];            // [lds_entries] the read's mask row, then [WL_NB][64] int2
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x;
+    const int M = min(max(len[r], 0), (int)min(stride, (int64_t)row16 * 64));
+    const uint4 *mrow = mask2 + (int64_t)r * row16;
+    int32_t *my = segs + (int64_t)r * 2 * max_segs;
+    int2 *cand = (int2 *)(wl_lds + lds_entries) + lane;        // my i-th long run at cand[64 i]
+    const int E1 = E1C ? E1C : max(p.error, 0) + 1;
+    const int nent = (M + 63) >> 6;
+    if (nent == 0) { if (lane == 0) nsegs[r] = 0; return; }
+    const bool staged = nent <= lds_entries;
+    if (staged) {
+        for (int k = lane; k < nent; k += 64) wl_lds[k] = mrow[k];
+        __syncthreads();                                       // (one wavefront: orders the LDS writes before the reads)
+    }
+    auto entry = [&](int k) __attribute__((always_inline)) -> uint4 {
+        if (k < 0 || k >= nent) return make_uint4(0u, 0u, 0u, 0u);
+        return staged ? wl_lds[k] : mrow[k];
+    };
+
+    // ---- my piece: samples dropped in it, its first anchor ----
+    const int chunk = (nent + 63) >> 6;
+    const int e_lo = lane * chunk, e_hi = min(e_lo + chunk, nent);
+    int dcnt = 0, start = 0x7fffffff, dloc = 0;
+    if (lane == 0) start = 0;
+    {
+        unsigned zprev = 0u;
+        if (e_lo > 0 && e_lo < nent) { const uint4 v = entry(e_lo - 1); zprev = ~v.y & v.w; }
+        for (int e = e_lo; e < e_hi; e++) {
+            const uint4 v = entry(e);
+            const unsigned zlo = ~v.x & v.z, zhi = ~v.y & v.w;               // kept and out of band
+            if (start == 0x7fffffff) {
+                unsigned alo = v.x & v.z, ahi = v.y & v.w;                   // kept and in band ...
+                for (int j = 1; j <= E1; j++) {                              // ... behind E1 kept out-of-band samples
+                    alo &= __builtin_amdgcn_alignbit(zlo, zprev, 32 - j);
+                    ahi &= __builtin_amdgcn_alignbit(zhi, zlo, 32 - j);
+                }
+                if (alo | ahi) { start = 64 * e + (alo ? __builtin_ctz(alo) : 32 + __builtin_ctz(ahi)); dloc = dcnt; }
+            }
+            zprev = zhi;
+            dcnt += 64 - __builtin_popcount(v.z) - __builtin_popcount(v.w);
+        }
+    }
+    const int dbase = wave_incl_scan(dcnt) - dcnt;             // samples dropped before my piece
+    int stop;                                                  // the next lane's anchor (none: the read's end)
+    {
+        int sfx = start;                                       // inclusive minimum over lanes >= mine
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_down(sfx, d);
+            if (lane + d < 64) sfx = min(sfx, t);
+        }
+        const int nxt = __shfl_down(sfx, 1);
+        stop = lane < 63 ? min(nxt, M) : M;
+    }
+
+    // ---- the walk of my piece (k_seg_walk4's step; no jumps) ----
+    const unsigned thr0 = (unsigned)min(p.window, p.first_len);
+    bool haveF = false, Fbig = false;
+    int Fs = 0, Fe = 0, nB = 0;
+    int in_run = 0, zl = 0, rstart = 0, last1 = 0;
+    int pos = start, ce = -2, dcur = 0, rundrops = 0;
+    const int jump_d = dbase + dloc;
+    bool fin = !(start < M);
+    unsigned long long Oc = 0ull, Zc = 0ull, On = 0ull, Zn = 0ull;
+    while (true) {
+        const bool act = !fin && pos < M;
+        if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+        if (!act) continue;
+        const int e = pos >> 6;
+        if (e != ce) {                                         // the two entries my window lies in
+            if (e == ce + 1) { dcur += 64 - __builtin_popcountll(Oc | Zc); Oc = On; Zc = Zn; }
+            else {
+                const uint4 v = entry(e);
+                Oc = ((unsigned long long)(v.y & v.w) << 32) | (v.x & v.z);
+                Zc = ((unsigned long long)(~v.y & v.w) << 32) | (~v.x & v.z);
+                // samples dropped before entry e: my piece's base + the entries between the anchor's and this one
+                if (ce == -2) dcur = jump_d;
+                else for (int k = ce + 1; k <= e; k++) {       // (a window step of 64 can skip an entry boundary pair)
+                    const uint4 u = entry(k - 1);
+                    dcur += 64 - __builtin_popcount(u.z) - __builtin_popcount(u.w);
+                }
+            }
+            const uint4 v = entry(e + 1);
+            On = ((unsigned long long)(v.y & v.w) << 32) | (v.x & v.z);
+            Zn = ((unsigned long long)(~v.y & v.w) << 32) | (~v.x & v.z);
+            ce = e;
+        }
+        const int sh = pos & 63;
+        unsigned long long Ow = (Oc >> sh) | ((On << 1) << (63 - sh));
+        unsigned long long Zw = (Zc >> sh) | ((Zn << 1) << (63 - sh));
+        int V = 64;
+        if (!in_run) {
+            if (Ow == 0ull) { pos += 64; if (pos >= stop) fin = true; continue; }
+            const int t = __builtin_ctzll(Ow);
+            pos += t; Ow >>= t; Zw >>= t; V -= t;
+            if (pos >= stop) { fin = true; continue; }         // that run is the next lane's
+            in_run = 1; rstart = pos; zl = E1; last1 = 0; rundrops = 0;
+        }
+        const unsigned long long Z = Zw & ((2ull << (V - 1)) - 1ull);
+        const int nz = __builtin_popcountll(Z);
+        const bool closes = nz >= zl;
+        unsigned long long Zk = Z;
+        const int kth = closes ? zl : 1;
+        for (int i = 1; i < kth; i++) Zk &= Zk - 1ull;
+        const int L = closes ? (int)__builtin_ctzll(Zk) : V;                  // samples of the piece (without the closing one)
+        const int zeros = closes ? zl - 1 : nz;                              // out-of-band samples in it
+        const unsigned long long below = (L == 64) ? ~0ull : ((1ull << L) - 1ull);
+        const unsigned long long ones = Ow & below;
+        rundrops += L - zeros - __builtin_popcountll(ones);                  // neither in band nor out of band: dropped
+        if (ones) last1 = zeros - __builtin_popcountll(Z & below & ((2ull << (63 - __builtin_clzll(ones))) - 1ull));
+        else last1 += zeros;                                                 // prev_err (:445, :449)
+        zl -= zeros;
+        if (closes) {
+            const int z = pos + L;
+            const int c = (z - rstart) - rundrops;
+            if ((unsigned)c >= thr0) {                         // :448-454, in filtered coordinates
+                const int off = z - 64 * ce;                   // z lies in one of my two entries
+                const unsigned long long dc = ~(Oc | Zc), dn = ~(On | Zn);
+                const int dz = dcur + (off >= 64 ? __builtin_popcountll(dc) + __builtin_popcountll(dn & ((1ull << (off - 64)) - 1ull))
+                                                 : __builtin_popcountll(dc & ((1ull << off) - 1ull)));
+                const int zf = z - dz;
+                const bool big = c >= p.window;
+                if (!haveF) { haveF = true; Fbig = big; Fs = zf - c; Fe = zf - last1; }
+                if (big) { if (nB < WL_NB) cand[64 * nB] = make_int2(zf - c, zf - last1); nB++; }
+            }
+            in_run = 0;
+            pos = z + 1;
+        } else pos += V;
+    }
+
+    // ---- combine, in order (uniform across the wave; lane 0 writes) ----
+    if (__builtin_amdgcn_ballot_w64(nB > WL_NB) != 0ull) {     // a piece with more long runs than the list holds
+        if (lane == 0) nsegs[r] = walk_sync_read(mrow, nent, nent, p, my, max_segs);
+        return;
+    }
+    const unsigned long long mF = __builtin_amdgcn_ballot_w64(haveF);
+    int nseg = 0, last_end = 0;
+    auto report = [&](int s0, int e0) __attribute__((always_inline)) {
+        if (nseg > 0 && s0 - last_end < p.seg_dist) {          // :451 merge
+            if (lane == 0 && nseg <= max_segs) my[2 * (nseg - 1) + 1] = e0;
+        } else {
+            if (lane == 0 && nseg < max_segs) { my[2 * nseg] = s0; my[2 * nseg + 1] = e0; }
+            nseg++;
+        }
+        last_end = e0;
+    };
+    if (mF != 0ull) {
+        const int j0 = (int)__builtin_ctzll(mF);
+        report(__builtin_amdgcn_readlane(Fs, j0), __builtin_amdgcn_readlane(Fe, j0));
+        const int skip0 = __builtin_amdgcn_readlane((int)Fbig, j0);          // its first long run IS that first run
+        unsigned long long mB = __builtin_amdgcn_ballot_w64(nB > 0) & (~0ull << j0);
+        while (mB != 0ull) {
+            const int j = (int)__builtin_ctzll(mB);
+            mB &= mB - 1ull;
+            const int n = __builtin_amdgcn_readlane(nB, j);
+            const int2 *cj = (const int2 *)(wl_lds + lds_entries) + j;
+            for (int i = (j == j0 ? skip0 : 0); i < n; i++) { const int2 q = cj[64 * i]; report(q.x, q.y); }
+        }
+    }
+    if (lane == 0) nsegs[r] = nseg;
+}
+
 // k_seg_walk4's preconditions (else: k_seg_walk3 / k_seg_walk2)
 bool walk_jumps_apply(const WalkParams &wp, bool fast, bool by_runs, int row16)
 {
@@ -1107,6 +1297,18 @@ void launch_walk(hipStream_t ws, const uint4 *mask2, int row16, const int32_t *l
                  const unsigned *d_hints = nullptr)
 {
     const int wgrid = (nr + 63) / 64;
+    // long rows, or too few reads to fill the chip with a lane each: a wavefront per read (k_seg_walkL)
+    int long_max = 24576;
+    if (const char *e = sk_tune("SK_WALK_WAVE_MAXREADS")) long_max = atoi(e);
+    if (fast && by_runs && wp.error < 32 && (row16 > 64 || nr <= long_max) && nr > 0 &&
+        sk_tune("SK_WALK_NOWAVE") == nullptr && sk_tune("SK_WALK_SYNC") == nullptr) {
+        const int lds_entries = row16 < 1024 ? row16 : 1024;
+        const size_t lds = (size_t)lds_entries * 16 + (size_t)WL_NB * 64 * sizeof(int2);
+        auto fn = wp.error == 5 ? k_seg_walkL<6> : k_seg_walkL<0>;
+        hipLaunchKernelGGL(fn, dim3(nr), dim3(64), lds, ws, mask2, row16, len, stride, nr, wp, d_segs, d_nsegs, max_segs,
+                           lds_entries);
+        return;
+    }
     if (walk_jumps_apply(wp, fast, by_runs, row16)) {
         const int use_jumps = sk_tune("SK_WALK_NOJUMP") == nullptr;
         const unsigned *h = use_jumps ? d_hints : nullptr;

@@ -11,6 +11,17 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["wave", "lane"])
+def walk_shape(request, monkeypatch):
+    """Every test of this module twice: batches this small take the wavefront-per-read walk (k_seg_walkL, round 6) by
+    default; SK_WALK_NOWAVE=1 keeps the lane-per-read walks (k_seg_walk4 / 3 / 2) that large batches of short reads take."""
+    if request.param == "lane":
+        monkeypatch.setenv("SK_WALK_NOWAVE", "1")
+    else:
+        monkeypatch.delenv("SK_WALK_NOWAVE", raising=False)
+    return request.param
+
+
 def _params(kw):
     from squigglekit_amd._lib import SegParams
     return SegParams(**kw)
@@ -250,3 +261,27 @@ def test_streaming_path_long_reads(gpu, ora, monkeypatch, M):
     monkeypatch.setenv("SK_SEG_DELTA_SCALE", "1e13")
     for kw in cases[:2]:
         _check_vs_oracle(api, ora, sig, lens, kw, "long M=%d, redo" % M, max_segs=160)
+
+
+@pytest.mark.parametrize("M", [20000, 70000, 140000])
+def test_wave_per_read_walk_on_pattern_reads_long_rows_and_overflow(gpu, ora, monkeypatch, walk_shape, M):
+    """k_seg_walkL: a wavefront per read, every lane from its piece's first anchor to the next lane's.  Pattern reads
+    (anchors thousands of samples apart, near-miss anchors, dropped samples) at lengths whose rows are staged in LDS
+    (20 000), are not (70 000, 140 000: beyond 1 024 entries), and -- with a short window -- hold more long runs in one
+    piece than a lane's list (the lane-0 sequential fallback); the same records from the lane-per-read walk."""
+    from squigglekit_amd import api, synth
+    rng = np.random.default_rng(M + 1)
+    R = 24
+    sig = synth.pattern_reads(rng, R, M)
+    lens = rng.integers(M // 2, M + 1, size=R).astype(np.int32)
+    lens[:4] = [M, M - 1, M - 63, M - 64]
+    # a read of trains: 40 in-band samples, 7 out-of-band ones -- with window 30 a 2 000-sample piece closes 40 long runs
+    tr = np.where((np.arange(M) % 47) < 40, 500, np.where(np.arange(M) % 2 == 0, 300, 700)).astype(np.int16)
+    sig[5, :] = tr
+    sig[6, :] = tr
+    sig[6, rng.integers(0, M, 50)] = 0               # ... and dropped samples in it
+    total = 0
+    for kw in (dict(), dict(window=127), dict(window=30, seg_dist=0), dict(window=30, error=0, seg_dist=5),
+               dict(error=20, corrector=30), dict(stall_len=1.5), dict(lim_low=250, lim_hi=760)):
+        total += int(_check_vs_oracle(api, ora, sig, lens, kw, "wave walk M=%d %s" % (M, walk_shape), max_segs=4096).sum())
+    assert total > 1000
