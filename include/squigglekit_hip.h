@@ -127,6 +127,11 @@ int sk_segment_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
  * sig[off[r] .. off[r+1]) (len may be NULL: whole reads) -- a parsed TSV chunk goes in as it is, no repacking. */
 int sk_segment_batch_f64_len(const double *sig, const int64_t *off, const int32_t *len, int32_t nreads,
                              const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs);
+/* the same for a ragged batch of int32 CENTI-UNITS (sk_tsv_parse_centi: decimal tokens with at most two decimals --
+ * SquigglePull's default pA output): sample = centi / 100.0 = float("ddd.dd") bit for bit (segmenter.py:198-199), made
+ * on the device; half the bytes over PCIe. */
+int sk_segment_batch_centi_len(const int32_t *centi, const int64_t *off, const int32_t *len, int32_t nreads,
+                               const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs);
 /* raw reads through the pA route -- what segmenter.py does with fast5 / slow5 input unless --raw_signal is given
  * (segmenter.py:345-349, 366-370, 385): np.round((raw + offset) * (float("%.2f" % range) / digitisation), 2), made on
  * the device from the int16 rows, then scale_outliers + get_segs on the float64 values.  calib[3 r ..] = digitisation,
@@ -221,6 +226,10 @@ int sk_motifseq_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
 int sk_motifseq_multi_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
                                 const double *motifs, const int32_t *motif_off, int32_t nmotifs,
                                 int32_t scale_mode, int32_t scale_low, int32_t scale_hi, sk_hit *out);
+/* sk_motifseq_multi_batch_f64 for int32 centi-units (see sk_segment_batch_centi_len; MotifSeq.py:270) */
+int sk_motifseq_multi_batch_centi(const int32_t *centi, const int64_t *off, int32_t nreads,
+                                  const double *motifs, const int32_t *motif_off, int32_t nmotifs,
+                                  int32_t scale_mode, int32_t scale_low, int32_t scale_hi, sk_hit *out);
 /* device-resident form (d_sig, d_len, d_out device; motif host). */
 int sk_motifseq_dev_i16(const int16_t *d_sig, int64_t stride, const int32_t *d_len, int32_t nreads,
                         const double *motif, int32_t nmotif, int32_t scale_mode,
@@ -272,7 +281,8 @@ enum {
     SK_TSV_ANY      = 2,   /* some value is non-zero (the reference skips reads where none is) */
     SK_TSV_FIRSTDOT = 4,   /* the first data token contains '.' (segmenter.py:198 picks float) */
     SK_TSV_SLOW     = 8,   /* a token is outside the plain grammar: use the fallback parser    */
-    SK_TSV_SHORT    = 16   /* the line has no data column at all                               */
+    SK_TSV_SHORT    = 16,  /* the line has no data column at all                               */
+    SK_TSV_CENTI    = 32   /* sk_tsv_parse_centi: every data token has at most two decimals     */
 };
 int64_t sk_tsv_count_lines(const char *buf, size_t len);
 int sk_tsv_count_tokens(const char *buf, size_t len, int32_t start_col, int64_t nlines, int64_t *ntok,
@@ -280,6 +290,16 @@ int sk_tsv_count_tokens(const char *buf, size_t len, int32_t start_col, int64_t 
 int sk_tsv_parse(const char *buf, size_t len, int32_t start_col, int64_t nlines, const int64_t *off,
                  double *values, int64_t *name_off, int32_t *name_len, int64_t *id_off, int32_t *id_len,
                  int32_t *flags, int32_t nthreads);
+
+/* Decimal lines as int32 centi-units (round 6): SquigglePull's default output is np.round(pA, 2)
+ * (SquigglePull.py:183-189,222), and float("ddd.dd") == (double)ddddd / 100.0 bit for bit, so a line whose data tokens
+ * all have at most two decimals travels as int32 (half the bytes, one pass) and becomes float64 on the device.  Same
+ * layout as sk_tsv_parse (values[off[i] .. off[i+1]) = line i); flags[i] & SK_TSV_CENTI says line i's values are valid --
+ * a chunk with any line without it goes through sk_tsv_parse instead.  Replaces the float() loops of
+ * segmenter.py:198-199 / MotifSeq.py:270 for such lines. */
+int sk_tsv_parse_centi(const char *buf, size_t len, int32_t start_col, int64_t nlines, const int64_t *off,
+                       int32_t *values, int64_t *name_off, int32_t *name_len, int64_t *id_off, int32_t *id_len,
+                       int32_t *flags, int32_t nthreads);
 
 /* Integer lines straight into int16 rows (the raw-signal TSVs SquigglePull writes): rows[i * stride ..] = line i's
  * data tokens, nsamp[i] their number.  flags[i] has SK_TSV_ALLINT only if every data token is [+-]digits, fits

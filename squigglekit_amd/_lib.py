@@ -115,6 +115,7 @@ ABI = {
     "sk_segment_dev_i16_pa": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, C.POINTER(SegParams), _vp, _vp, C.c_int32]),
     "sk_last_pa_retries": (C.c_int, []),
     "sk_segment_batch_f64_len": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.POINTER(SegParams), _vp, _vp, C.c_int32]),
+    "sk_segment_batch_centi_len": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.POINTER(SegParams), _vp, _vp, C.c_int32]),
     "sk_segment_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, C.POINTER(SegParams),
                                      _vp, _vp, C.c_int32]),
     "sk_segment_dev_f64": (C.c_int, [_vp, _vp, C.c_int32, C.c_int64, C.c_int64, C.POINTER(SegParams), _vp, _vp, C.c_int32]),
@@ -129,6 +130,7 @@ ABI = {
     "sk_motifseq_batch_f64": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, _vp]),
     "sk_motifseq_multi_batch_f64": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    "sk_motifseq_multi_batch_centi": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "sk_motifseq_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, _vp]),
     "sk_motifseq_multi_dev_i16": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,
@@ -144,6 +146,8 @@ ABI = {
     "sk_tsv_count_tokens": (C.c_int, [_vp, C.c_size_t, C.c_int32, C.c_int64, _vp, C.c_int32]),
     "sk_tsv_parse": (C.c_int, [_vp, C.c_size_t, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                C.c_int32]),
+    "sk_tsv_parse_centi": (C.c_int, [_vp, C.c_size_t, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     C.c_int32]),
     "sk_tsv_parse_i16": (C.c_int, [_vp, C.c_size_t, C.c_int32, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, C.c_int32]),
     "sk_fmt_rows": (_vp, [C.c_int64, C.c_int32, _vp, _vp, C.c_int32, _i64p]),
@@ -273,6 +277,7 @@ PY_TUNABLES = {
     "SK_BLOW5_ZAP": ("0", "BLOW5 reader: keep the consumed pages of the file map"),
     "SK_I16_PIN": ("1", "--i16 reader: page-locked streaming buffers"),
     "SK_I16_BLOCK_MB": ("1 8", "--i16 reader: block size in MB"),
+    "SK_TSV_NO_CENTI": ("1", "TSV reader: decimal lines through the float64 tokenizer even when every token has at most two decimals"),
 }
 
 

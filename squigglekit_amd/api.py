@@ -271,7 +271,10 @@ def segment_ragged_f64(values, off, lens=None, params=None, max_segs=64, devices
     devices (or api.set_devices / --gpus): block-sharded over the GPUs (a shard is a run of offsets into the same
     `values`: nothing is repacked)."""
     L = _lib.load()
-    values = np.ascontiguousarray(values, dtype=np.float64)
+    # int32 values are centi-units (tsvio.FloatBlock.centi: tokens with at most two decimals): sample = c / 100.0 on the GPU
+    centi = isinstance(values, np.ndarray) and values.dtype == np.int32
+    values = np.ascontiguousarray(values, dtype=np.int32 if centi else np.float64)
+    entry = L.sk_segment_batch_centi_len if centi else L.sk_segment_batch_f64_len
     off = np.ascontiguousarray(off, dtype=np.int64)
     R = off.size - 1
     params = params or SegParams()
@@ -279,7 +282,7 @@ def segment_ragged_f64(values, off, lens=None, params=None, max_segs=64, devices
     while True:
         segs = np.zeros((max(R, 1), max_segs, 2), dtype=np.int32)
         nsegs = np.zeros(max(R, 1), dtype=np.int32)
-        rc = _over_devices(devices, R, lambda lo, hi, ms=max_segs: L.sk_segment_batch_f64_len(
+        rc = _over_devices(devices, R, lambda lo, hi, ms=max_segs: entry(
             ptr(values), ptr(off[lo:hi + 1]), None if ln is None else ptr(ln[lo:hi]), hi - lo, C.byref(params),
             ptr(segs[lo:hi]), ptr(nsegs[lo:hi]), ms))
         if rc == _lib.SK_ERR_OVERFLOW:
@@ -292,7 +295,9 @@ def motifseq_multi_ragged_f64(values, off, motifs, scale="medmad", scale_low=0, 
     """Every motif against a ragged float64 batch (read r = values[off[r]:off[r+1]]): one record array per motif.
     devices (or api.set_devices / --gpus): block-sharded over the GPUs."""
     L = _lib.load()
-    values = np.ascontiguousarray(values, dtype=np.float64)
+    centi = isinstance(values, np.ndarray) and values.dtype == np.int32      # centi-units, see segment_ragged_f64
+    values = np.ascontiguousarray(values, dtype=np.int32 if centi else np.float64)
+    entry = L.sk_motifseq_multi_batch_centi if centi else L.sk_motifseq_multi_batch_f64
     off = np.ascontiguousarray(off, dtype=np.int64)
     R = off.size - 1
     ms = [np.ascontiguousarray(m, dtype=np.float64) for m in motifs]
@@ -303,8 +308,8 @@ def motifseq_multi_ragged_f64(values, off, motifs, scale="medmad", scale_low=0, 
     def call(lo, hi):
         # the shard is staged and filtered ONCE, every motif runs against it on the device (sk_motifseq_multi_batch_f64)
         part = np.zeros((len(ms), hi - lo), dtype=HIT_DTYPE)
-        rc = L.sk_motifseq_multi_batch_f64(ptr(values), ptr(off[lo:hi + 1]), hi - lo, ptr(flat), ptr(moff), len(ms),
-                                           _lib.SK_SCALE[scale], int(scale_low), int(scale_hi), ptr(part))
+        rc = entry(ptr(values), ptr(off[lo:hi + 1]), hi - lo, ptr(flat), ptr(moff), len(ms),
+                   _lib.SK_SCALE[scale], int(scale_low), int(scale_hi), ptr(part))
         if rc == 0:
             for k, hits in enumerate(out):
                 hits[lo:hi] = part[k]

@@ -404,9 +404,12 @@ int sk_motifseq_multi_batch_i16(const int16_t *sig, int64_t stride, const int32_
 
 // Stage a ragged float64 batch: samples -> c->sig, zero-based offsets -> c->off.
 // Returns the total sample count in *total and the longest read in *maxlen.
-static int stage_ragged_f64(sk_ctx *c, const double *sig, const int64_t *off, int32_t nreads,
-                            int64_t *total, int64_t *maxlen)
+// centi: `sig` holds int32 centi-units (sk_tsv_parse_centi) -- half the bytes over PCIe; the float64 image
+// (c / 100.0 = float("ddd.dd"), sk_synth.hip k_centi_to_f64) is made on the device, and what follows is the same.
+static int stage_ragged_f64(sk_ctx *c, const void *sig_any, const int64_t *off, int32_t nreads,
+                            int64_t *total, int64_t *maxlen, bool centi = false)
 {
+    const double *sig = (const double *)sig_any;
     if (!sig || !off) return sk_fail(SK_ERR_INVALID, "NULL sig/off");
     std::vector<int64_t> rel((size_t)nreads + 1);
     int64_t mx = 0;
@@ -421,7 +424,13 @@ static int stage_ragged_f64(sk_ctx *c, const double *sig, const int64_t *off, in
     int rc;
     if ((rc = sk_reserve(c, &c->sig, (size_t)(*total > 0 ? *total : 1) * sizeof(double)))) return rc;
     if ((rc = sk_reserve(c, &c->off, rel.size() * sizeof(int64_t)))) return rc;
-    SK_HIP(hipMemcpyAsync(c->sig.p, sig + off[0], (size_t)*total * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (centi) {
+        if ((rc = sk_reserve(c, &c->misc, (size_t)(*total > 0 ? *total : 1) * sizeof(int32_t) + 16))) return rc;
+        SK_HIP(hipMemcpyAsync(c->misc.p, (const int32_t *)sig_any + off[0], (size_t)*total * sizeof(int32_t),
+                              hipMemcpyHostToDevice, c->stream));
+        if ((rc = sk_launch_centi_to_f64(c, (const int32_t *)c->misc.p, *total, (double *)c->sig.p))) return rc;
+    } else
+        SK_HIP(hipMemcpyAsync(c->sig.p, sig + off[0], (size_t)*total * sizeof(double), hipMemcpyHostToDevice, c->stream));
     SK_HIP(hipMemcpyAsync(c->off.p, rel.data(), rel.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     SK_HIP(hipStreamSynchronize(c->stream));        // rel goes out of scope
     return SK_OK;
@@ -508,9 +517,24 @@ int sk_motifseq_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
 
 // Several motifs against the same ragged float64 batch (the `for name in m_order` loop of MotifSeq.py:436 on pA input):
 // the batch is staged once, filter + statistics run once, one DTW launch set per motif.  out is [nmotifs][nreads].
+static int motifseq_multi_batch_ragged(const void *sig, bool centi, const int64_t *off, int32_t nreads,
+                                       const double *motifs, const int32_t *motif_off, int32_t nmotifs,
+                                       int32_t scale_mode, int32_t scale_low, int32_t scale_hi, sk_hit *out);
 int sk_motifseq_multi_batch_f64(const double *sig, const int64_t *off, int32_t nreads,
                                 const double *motifs, const int32_t *motif_off, int32_t nmotifs,
                                 int32_t scale_mode, int32_t scale_low, int32_t scale_hi, sk_hit *out)
+{
+    return motifseq_multi_batch_ragged(sig, false, off, nreads, motifs, motif_off, nmotifs, scale_mode, scale_low, scale_hi, out);
+}
+int sk_motifseq_multi_batch_centi(const int32_t *centi, const int64_t *off, int32_t nreads,
+                                  const double *motifs, const int32_t *motif_off, int32_t nmotifs,
+                                  int32_t scale_mode, int32_t scale_low, int32_t scale_hi, sk_hit *out)
+{
+    return motifseq_multi_batch_ragged(centi, true, off, nreads, motifs, motif_off, nmotifs, scale_mode, scale_low, scale_hi, out);
+}
+static int motifseq_multi_batch_ragged(const void *sig, bool centi, const int64_t *off, int32_t nreads,
+                                       const double *motifs, const int32_t *motif_off, int32_t nmotifs,
+                                       int32_t scale_mode, int32_t scale_low, int32_t scale_hi, sk_hit *out)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
@@ -521,7 +545,7 @@ int sk_motifseq_multi_batch_f64(const double *sig, const int64_t *off, int32_t n
     if (nreads == 0) return SK_OK;
     if (!out) return sk_fail(SK_ERR_INVALID, "NULL out");
     int64_t total, maxlen;
-    if ((rc = stage_ragged_f64(c, sig, off, nreads, &total, &maxlen))) return rc;
+    if ((rc = stage_ragged_f64(c, sig, off, nreads, &total, &maxlen, centi))) return rc;
     const size_t ob = (size_t)nreads * (size_t)nmotifs * sizeof(sk_hit);
     if ((rc = sk_reserve(c, &c->out, ob))) return rc;
     rc = motifseq_multi_dev_f64(c, (const double *)c->sig.p, (const int64_t *)c->off.p, nreads, total, maxlen, motifs,
@@ -839,8 +863,20 @@ static int segment_dev_f64(sk_ctx *c, const double *d_sig, const int64_t *d_off,
     return SK_OK;
 }
 
+static int segment_batch_ragged(const void *sig, bool centi, const int64_t *off, const int32_t *len, int32_t nreads,
+                                const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs);
 int sk_segment_batch_f64_len(const double *sig, const int64_t *off, const int32_t *len, int32_t nreads,
                              const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs)
+{
+    return segment_batch_ragged(sig, false, off, len, nreads, p, segs, nsegs, max_segs);
+}
+int sk_segment_batch_centi_len(const int32_t *centi, const int64_t *off, const int32_t *len, int32_t nreads,
+                               const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs)
+{
+    return segment_batch_ragged(centi, true, off, len, nreads, p, segs, nsegs, max_segs);
+}
+static int segment_batch_ragged(const void *sig, bool centi, const int64_t *off, const int32_t *len, int32_t nreads,
+                                const sk_seg_params *p, int32_t *segs, int32_t *nsegs, int32_t max_segs)
 {
     sk_ctx *c = sk_cur();
     if (!c) return SK_ERR_NO_DEVICE;
@@ -852,7 +888,7 @@ int sk_segment_batch_f64_len(const double *sig, const int64_t *off, const int32_
     if (nreads == 0) return SK_OK;
     if (!segs || !nsegs) return sk_fail(SK_ERR_INVALID, "NULL segs/nsegs");
     int64_t total, maxlen;
-    if ((rc = stage_ragged_f64(c, sig, off, nreads, &total, &maxlen))) return rc;
+    if ((rc = stage_ragged_f64(c, sig, off, nreads, &total, &maxlen, centi))) return rc;
     const int32_t *d_rlen = nullptr;
     if (len) {                                      // the caller's sig[:Num] cut: read r is its first len[r] samples
         for (int32_t r = 0; r < nreads; r++)

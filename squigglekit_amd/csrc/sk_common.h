@@ -255,6 +255,7 @@ int sk_launch_synth_windows(sk_ctx *c, int16_t *d_sig, int64_t stride, int32_t n
                             uint64_t seed, int64_t row0, const int16_t *d_tmpl, int32_t ntmpl, float sigma);
 int sk_launch_raw_to_pa(sk_ctx *c, const int16_t *d_sig, int64_t stride, int32_t nreads, int32_t nsamples,
                         double offset, double raw_unit, double *d_out, int64_t *d_off);
+int sk_launch_centi_to_f64(sk_ctx *c, const int32_t *d_centi, int64_t total, double *d_out);
 // ragged form with per-read constants: read r's len = off[r+1] - off[r] samples, cal[2r] = offset, cal[2r+1] = raw unit
 int sk_launch_rows_to_pa(sk_ctx *c, const int16_t *d_sig, int64_t stride, int32_t nreads, const int64_t *d_off,
                          const double *d_cal, double *d_out);

@@ -164,7 +164,33 @@ void k_rows_to_pa(const int16_t *__restrict__ sig, int64_t stride, int nreads, c
     }
 }
 
+// int32 centi-units (what sk_tsv_parse_centi makes of "ddd.dd" tokens) -> float64: c / 100.0, one correctly rounded
+// division of two exact operands = float("ddd.dd") bit for bit (segmenter.py:198-199, MotifSeq.py:270)
+__global__ __launch_bounds__(256)
+void k_centi_to_f64(const int32_t *__restrict__ c, int64_t total, double *__restrict__ out)
+{
+    const int64_t n4 = total >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int4 q = ((const int4 *)c)[i];
+        double2 a, b;
+        a.x = (double)q.x / 100.0; a.y = (double)q.y / 100.0; b.x = (double)q.z / 100.0; b.y = (double)q.w / 100.0;
+        ((double2 *)out)[2 * i] = a; ((double2 *)out)[2 * i + 1] = b;
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (double)c[i] / 100.0;
+}
+
 } // namespace
+
+int sk_launch_centi_to_f64(sk_ctx *c, const int32_t *d_centi, int64_t total, double *d_out)
+{
+    if (total <= 0) return SK_OK;
+    const int64_t need = (total / 4 + 255) / 256 + 1;
+    const int grid = (int)(need < (int64_t)c->num_cu * 16 ? need : (int64_t)c->num_cu * 16);
+    hipLaunchKernelGGL(k_centi_to_f64, dim3(grid), dim3(256), 0, c->stream, d_centi, total, d_out);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
+}
 
 int sk_launch_rows_to_pa(sk_ctx *c, const int16_t *d_sig, int64_t stride, int32_t nreads, const int64_t *d_off,
                          const double *d_cal, double *d_out)

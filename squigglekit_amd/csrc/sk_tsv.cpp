@@ -260,6 +260,93 @@ int sk_tsv_parse(const char *buf, size_t len, int32_t start_col, int64_t nlines,
     return SK_OK;
 }
 
+// Decimal lines as CENTI-UNITS (round 6).  What SquigglePull writes by default is np.round(pA, 2) (SquigglePull.py:
+// 183-189, 222): tokens with at most two decimals, "96.5", "103.25", "88.0".  float("ddd.dd") is the double nearest to
+// c / 100 for the integer c = ddddd -- and so is the IEEE quotient (double)c / 100.0 (both operands exact, one correctly
+// rounded operation: the same fast path conv() above takes).  So such a line is carried as int32 centi-units: half the
+// bytes on the way to the GPU, no division and no second pass on the host; the device makes value = c / 100.0, bit for
+// bit float()'s.  Same layout and flags as sk_tsv_parse (values[off[i] .. off[i+1]) = line i's tokens) plus
+// SK_TSV_CENTI: every data token of the line is [+-]digits[.digits] with at most two decimals (further decimals must be
+// zeros), |c| < 2^31, and is not a negative zero (float("-0.0") keeps its sign; c cannot).  A line without the flag
+// holds unspecified values: the caller sends the chunk through sk_tsv_parse instead.
+int sk_tsv_parse_centi(const char *buf, size_t len, int32_t start_col, int64_t nlines, const int64_t *off,
+                       int32_t *values, int64_t *name_off, int32_t *name_len, int64_t *id_off, int32_t *id_len,
+                       int32_t *flags, int32_t nthreads)
+{
+    if (!buf || !off || !values || !flags || start_col < 0 || nlines < 0) return SK_ERR_INVALID;
+    const LineIndex &LI = line_index(buf, len);
+    if ((int64_t)LI.off.size() - 1 != nlines) return SK_ERR_INVALID;
+    const int64_t *lo = LI.off.data();
+    if (nthreads < 1) nthreads = 1;
+    auto work = [&](int t) {
+        const int64_t per = (nlines + nthreads - 1) / nthreads;         // contiguous lines: contiguous output
+        const int64_t i0 = t * per, i1 = (i0 + per < nlines) ? i0 + per : nlines;
+        for (int64_t i = i0; i < i1; i++) {
+            const char *p = buf + lo[i], *e = buf + lo[i + 1];
+            if (e > p && e[-1] == '\n') e--;
+            if (name_off) { name_off[i] = 0; name_len[i] = 0; }
+            if (id_off) { id_off[i] = 0; id_len[i] = 0; }
+            int col = 0;
+            const char *s = p;
+            while (col < start_col) {                                   // the leading columns: name, read id, ...
+                const char *q = (const char *)memchr(s, '\t', (size_t)(e - s));
+                const char *te = q ? q : e;
+                if (col == 0 && name_off) { name_off[i] = s - buf; name_len[i] = (int32_t)(te - s); }
+                if (col == 1 && id_off) { id_off[i] = s - buf; id_len[i] = (int32_t)(te - s); }
+                col++;
+                if (!q) { s = e + 1; break; }
+                s = q + 1;
+            }
+            int32_t fl = 0;
+            if (s > e) { flags[i] = SK_TSV_SHORT; continue; }          // fewer than start_col + 1 columns
+            int64_t k = off[i];
+            const int64_t kend = off[i + 1];
+            bool centi = true, anynz = false, anydot = false, firstdot = false, first = true;
+            while (true) {                                              // s: start of a data token
+                bool neg = false;
+                if (s < e && (*s == '-' || *s == '+')) { neg = (*s == '-'); s++; }
+                uint32_t ip = 0, fr = 0;
+                int nd = 0, nf = 0;
+                while (s < e && (unsigned)(*s - '0') <= 9u) { ip = ip * 10u + (unsigned)(*s - '0'); nd++; s++; }
+                bool dot = false;
+                if (s < e && *s == '.') {
+                    dot = true;
+                    s++;
+                    while (s < e && (unsigned)(*s - '0') <= 9u) {
+                        if (nf < 2) fr = fr * 10u + (unsigned)(*s - '0');
+                        else if (*s != '0') centi = false;              // a third significant decimal
+                        nf++; s++;
+                    }
+                }
+                if ((nd == 0 && nf == 0) || nd > 7 || (s < e && *s != '\t')) {
+                    centi = false;                                      // not [+-]digits[.digits] (or too long): the other parser
+                    while (s < e && *s != '\t') s++;
+                }
+                const uint32_t c = ip * 100u + (nf == 0 ? 0u : nf == 1 ? fr * 10u : fr);
+                if (neg && c == 0u) centi = false;                      // -0.0
+                if (k < kend) values[k++] = neg ? -(int32_t)c : (int32_t)c;
+                anynz = anynz || c != 0u;
+                anydot = anydot || dot;
+                if (first) { firstdot = dot; first = false; }
+                col++;
+                if (s >= e) break;
+                s++;                                                    // the tab
+            }
+            if (k != kend) centi = false;                               // (the caller's offsets are another line's)
+            if (!anydot) fl |= SK_TSV_ALLINT;
+            if (anynz) fl |= SK_TSV_ANY;
+            if (firstdot) fl |= SK_TSV_FIRSTDOT;
+            if (centi) fl |= SK_TSV_CENTI;
+            flags[i] = fl;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    return SK_OK;
+}
+
 // Lines of integer samples straight into int16 rows: the common case (SquigglePull's raw TSV), without the float64
 // detour and without a Python object per read.  rows[i * stride ..] receives line i's data tokens (columns
 // start_col ..), nsamp[i] their number.  flags[i]: SK_TSV_ALLINT only if EVERY data token is [+-]digits, fits int16

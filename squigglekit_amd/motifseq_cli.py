@@ -272,7 +272,7 @@ class _Batcher:
             from concurrent.futures import ThreadPoolExecutor
             self._worker = ThreadPoolExecutor(1)
         _mark("block of %d float64 reads to the GPU worker" % fb.n)
-        job = self._worker.submit(api.motifseq_multi_ragged_f64, fb.values, fb.off, motifs, a.scale, a.scale_low, a.scale_hi)
+        job = self._worker.submit(api.motifseq_multi_ragged_f64, fb.batch_values(), fb.off, motifs, a.scale, a.scale_low, a.scale_hi)
         prev, self._pending = self._pending, (job, fb.n, ("span", fb.buf, fb.spans("name")), ("span", fb.buf, fb.spans("id")),
                                               lambda i, b=fb: b.text("name", i), lambda i, b=fb: b.text("id", i),
                                               lambda i, b=fb: b.values[b.off[i]:b.off[i + 1]])

@@ -153,7 +153,7 @@ class _Batcher:
             from concurrent.futures import ThreadPoolExecutor
             self._worker = ThreadPoolExecutor(1)
         _mark("block of %d float64 reads to the GPU worker" % fb.n)
-        job = self._worker.submit(api.segment_ragged_f64, fb.values, fb.off, lens, self.params)
+        job = self._worker.submit(api.segment_ragged_f64, fb.batch_values(), fb.off, lens, self.params)
         prev, self._pending = self._pending, (job, fb.n, ("span", fb.buf, fb.spans("name")), lambda i, b=fb: b.text("name", i))
         if prev is not None:
             self._finish(prev)

@@ -44,10 +44,24 @@ class FloatBlock:
     buf[base:end]: bytes or a read-only memory map, nothing copied), its flags (SK_TSV_*).  What the float64 batch entry
     points take as it stands."""
 
-    def __init__(self, chunk, n, values, off, flags, name_off, name_len, id_off, id_len):
+    def __init__(self, chunk, n, values, off, flags, name_off, name_len, id_off, id_len, centi=None):
         self.buf, self.base, self.end = chunk
-        self.n, self.values, self.off, self.flags = n, values, off, flags
+        self.n, self._values, self.off, self.flags = n, values, off, flags
         self.name_off, self.name_len, self.id_off, self.id_len = name_off, name_len, id_off, id_len   # relative to base
+        # (round 6) every token of the chunk has at most two decimals -- SquigglePull's np.round(pA, 2) -- and was parsed
+        # as an int32 centi-unit (sk_tsv_parse_centi): what the batch entry points take as it stands, half the bytes
+        self.centi = centi
+
+    @property
+    def values(self):
+        """float64 values of every token; for a centi chunk made on demand: c / 100.0 IS float("ddd.dd")"""
+        if self._values is None:
+            self._values = self.centi / 100.0
+        return self._values
+
+    def batch_values(self):
+        """what the ragged batch entry points should be handed: the int32 centi-units when the chunk has them"""
+        return self.centi if self.centi is not None else self.values
 
     def clean(self):
         """Every line is a plain decimal (or integer) read with a non-zero value somewhere: the reference's own parse
@@ -80,12 +94,23 @@ def parse_block_float(chunk, start_col, nthreads):
     _lib.check(L.sk_tsv_count_tokens(cp, clen, start_col, n, _lib.ptr(ntok), nthreads))
     off = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(ntok, out=off[1:])
-    values = np.empty(max(1, int(off[-1])), dtype=np.float64)
     name_off = np.zeros(n, dtype=np.int64)
     name_len = np.zeros(n, dtype=np.int32)
     id_off = np.zeros(n, dtype=np.int64)
     id_len = np.zeros(n, dtype=np.int32)
     flags = np.zeros(n, dtype=np.int32)
+    if _lib.tune("SK_TSV_NO_CENTI") is None:
+        # decimal tokens with at most two decimals (what SquigglePull writes) as int32 centi-units, in one pass; a chunk
+        # with any other line goes through the general float64 tokenizer below
+        centi = np.empty(max(1, int(off[-1])), dtype=np.int32)
+        _lib.check(L.sk_tsv_parse_centi(cp, clen, start_col, n, _lib.ptr(off), _lib.ptr(centi),
+                                        _lib.ptr(name_off), _lib.ptr(name_len), _lib.ptr(id_off),
+                                        _lib.ptr(id_len), _lib.ptr(flags), nthreads))
+        if bool(np.all(flags & 32)):
+            flags &= ~np.int32(32)
+            return FloatBlock(chunk, n, None, off, flags, name_off, name_len, id_off, id_len, centi=centi)
+        del centi
+    values = np.empty(max(1, int(off[-1])), dtype=np.float64)
     _lib.check(L.sk_tsv_parse(cp, clen, start_col, n, _lib.ptr(off), _lib.ptr(values),
                               _lib.ptr(name_off), _lib.ptr(name_len), _lib.ptr(id_off),
                               _lib.ptr(id_len), _lib.ptr(flags), nthreads))

@@ -136,7 +136,13 @@ def oracle_backend(monkeypatch, ora):
         reads = [np.asarray(sig[r, :lens[r]]) for r in range(sig.shape[0])]
         return [mot_any(reads, m, scale, lo, hi) for m in motifs]
 
+    def as_f64(values):
+        """int32 = centi-units (tsvio.FloatBlock.centi, round 6): the device makes c / 100.0 = float("ddd.dd")"""
+        values = np.asarray(values)
+        return values / 100.0 if values.dtype == np.int32 else values
+
     def seg_ragged(values, off, lens=None, params=None, max_segs=64):
+        values = as_f64(values)
         R = len(off) - 1
         reads = [np.asarray(values[off[r]:off[r] + (int(lens[r]) if lens is not None else off[r + 1] - off[r])]) for r in range(R)]
         res = seg_any(reads, params)
@@ -150,6 +156,7 @@ def oracle_backend(monkeypatch, ora):
         return segs, nsegs
 
     def mot_ragged(values, off, motifs, scale="medmad", lo=0, hi=1200):
+        values = as_f64(values)
         reads = [np.asarray(values[off[r]:off[r + 1]]) for r in range(len(off) - 1)]
         return [mot_any(reads, m, scale, lo, hi) for m in motifs]
 

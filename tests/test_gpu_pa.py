@@ -148,3 +148,33 @@ def test_example_read_through_the_raw_domain(gpu, ora, example_read):
     calib = [[example_read["digitisation"], example_read["offset"], example_read["range"]]] * 3
     retries, total = check(ora, api, raw, lens, calib)
     assert retries == 0 and total >= 1
+
+
+def test_centi_unit_batches_equal_the_float64_ones(gpu, ora):
+    """pA TSV lines as int32 centi-units (tsvio.FloatBlock.centi, sk_tsv_parse_centi): the device makes c / 100.0 --
+    float("ddd.dd") bit for bit (segmenter.py:198-199, MotifSeq.py:270) -- so both tools' ragged batch calls must give
+    the records of the float64 batch of the same tokens, and the oracle's."""
+    from squigglekit_amd import api, synth
+    rng = np.random.default_rng(3)
+    motif = synth.synthetic_motif(120)
+    raw = synth.squiggle_batch(300, 5000, 808, motif=motif)
+    lens = rng.integers(1, 5001, 300)
+    lens[:3] = [5000, 1, 4096]
+    centi = [np.rint((raw[r, :lens[r]].astype(np.int64) + 16.0) * (1493.94 / 8192.0) * 100).astype(np.int32) for r in range(300)]
+    centi[5][:] = 0                                      # nothing survives the filter
+    centi[6][::3] = -250                                 # negative values
+    centi[7][:] = 12345                                  # constant
+    flat = np.concatenate(centi)
+    off = np.concatenate([[0], np.cumsum([c.size for c in centi])]).astype(np.int64)
+    vals = flat / 100.0
+    cut = np.minimum(lens, 3000).astype(np.int32)
+    a = api.segment_ragged_f64(flat, off, cut)
+    b = api.segment_ragged_f64(vals, off, cut)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[1].sum() > 50
+    for r in range(0, 300, 7):
+        f = ora.scale_outliers(vals[off[r]:off[r] + cut[r]], 0, 900)
+        assert a[0][r, :a[1][r]].tolist() == ((ora.get_segs(f) or []) if f.size else []), r
+    for scale in ("medmad", "zscale"):
+        ha = api.motifseq_multi_ragged_f64(flat, off, [motif, motif[10:90]], scale=scale)
+        hb = api.motifseq_multi_ragged_f64(vals, off, [motif, motif[10:90]], scale=scale)
+        assert [h.tobytes() for h in ha] == [h.tobytes() for h in hb]

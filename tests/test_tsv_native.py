@@ -194,3 +194,70 @@ def test_non_regular_input_is_streamed_not_dropped(tmp_path):
     got = list(tsvio.iter_tsv_native(str(fifo), 4, chunk_bytes=3000, nthreads=2))
     t.join()
     assert len(got) == len(lines) and got[-1][0] == "f499"
+
+
+def test_centi_tokenizer_is_float_exact_and_steps_aside(monkeypatch):
+    """sk_tsv_parse_centi (round 6): decimal tokens with at most two decimals -- what SquigglePull writes, np.round(pA, 2)
+    (SquigglePull.py:183-189,222) -- as int32 centi-units; c / 100.0 must be float(token) bit for bit
+    (segmenter.py:198-199, MotifSeq.py:270), the flags must be the float64 tokenizer's, and a chunk holding anything else
+    (a third decimal, an exponent, a negative zero, junk, too many digits) must go through the float64 tokenizer."""
+    from squigglekit_amd import tsvio
+    rng = random.Random(11)
+
+    def centi_token():
+        k = rng.randrange(7)
+        v = rng.randrange(0, 200000)
+        if k == 0:
+            return repr(v / 100.0)                                       # shortest repr: 96.5, 103.25, 88.0
+        if k == 1:
+            return "%.2f" % (v / 100.0)
+        if k == 2:
+            return str(v // 100)                                         # an integer token inside a decimal line
+        if k == 3:
+            return "-%d.%02d" % (rng.randrange(1, 3000), rng.randrange(100))
+        if k == 4:
+            return "%d.%d000" % (v // 100, rng.randrange(10))            # further decimals, all zero
+        if k == 5:
+            return rng.choice(["5.", ".5", "+7.25", "0.0", "0", "000.10", "9999999.99", "-.01"])
+        return "%d.%d" % (rng.randrange(10 ** 6), rng.randrange(10))
+
+    lines, toks = [], []
+    for i in range(300):
+        t = [centi_token() for _ in range(rng.randrange(1, 60))]
+        if i % 3 == 0:
+            t[0] = "%.2f" % rng.uniform(1, 200)                           # FIRSTDOT lines and others
+        toks.append(t)
+        lines.append("\t".join(["f%d.fast5" % i, "rid%d" % i, "a", "b"] + t) + "\n")
+    buf = "".join(lines).encode()
+    chunk = (buf, 0, len(buf))
+    fb = tsvio.parse_block_float(chunk, 4, 4)
+    assert fb.centi is not None and fb.centi.dtype == np.int32 and fb.batch_values() is fb.centi
+    want = np.array([float(x) for t in toks for x in t])
+    got = fb.values
+    assert got.dtype == np.float64 and got.size == want.size
+    assert not np.any(got.view(np.uint64) != want.view(np.uint64))
+    assert [fb.text("name", i) for i in (0, 299)] == ["f0.fast5", "f299.fast5"] and fb.text("id", 7) == "rid7"
+    monkeypatch.setenv("SK_TSV_NO_CENTI", "1")
+    ref = tsvio.parse_block_float(chunk, 4, 4)
+    monkeypatch.delenv("SK_TSV_NO_CENTI")
+    assert ref.centi is None and np.array_equal(ref.flags, fb.flags) and np.array_equal(ref.off, fb.off)
+    assert np.array_equal(ref.values.view(np.uint64), got.view(np.uint64))
+    assert np.array_equal(ref.name_off, fb.name_off) and np.array_equal(ref.id_len, fb.id_len)
+    # one odd token anywhere and the whole chunk is the float64 tokenizer's
+    for odd in ("1.234", "1e2", "-0.0", "-0", "nan", "12x", "", "12345678.5", " 3.5", "1_0.5", "3.14159"):
+        lines2 = list(lines)
+        lines2[150] = "\t".join(["g.fast5", "r", "a", "b", "1.5", odd, "2.25"]) + "\n"
+        b2 = "".join(lines2).encode()
+        f2 = tsvio.parse_block_float((b2, 0, len(b2)), 4, 3)
+        assert f2.centi is None, odd
+        monkeypatch.setenv("SK_TSV_NO_CENTI", "1")
+        r2 = tsvio.parse_block_float((b2, 0, len(b2)), 4, 3)
+        monkeypatch.delenv("SK_TSV_NO_CENTI")
+        assert np.array_equal(r2.flags, f2.flags) and np.array_equal(r2.values.view(np.uint64), f2.values.view(np.uint64)), odd
+    # lines with too few columns, and a last line without its newline
+    b3 = b"a\tb\tc\n" + b"a\tb\tc\td\t1.25\t2.5\n" + b"a\tb\tc\td\t\n" + b"x\ty\tz\tw\t7.75"
+    f3 = tsvio.parse_block_float((b3, 0, len(b3)), 4, 2)
+    monkeypatch.setenv("SK_TSV_NO_CENTI", "1")
+    r3 = tsvio.parse_block_float((b3, 0, len(b3)), 4, 2)
+    monkeypatch.delenv("SK_TSV_NO_CENTI")
+    assert np.array_equal(r3.flags, f3.flags) and np.array_equal(r3.values.view(np.uint64), f3.values.view(np.uint64))
