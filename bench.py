@@ -78,6 +78,11 @@ def parse(argv=None):
                     help="also write headline + every extra block as ONE JSON object to PATH (tools/)")
     ap.add_argument("--ranks-on-device", type=int, default=None, metavar="D",
                     help="dry run: all --gpus ranks share device D (own context slot each, host-backend gather)")
+    ap.add_argument("--allow-host-gather", action="store_true",
+                    help="N > 1: do not fail the run when the gather fell back to host concatenation (RCCL missing) or a "
+                         "rank is not seen -- by default such a run exits non-zero instead of printing a clean-looking line")
+    ap.add_argument("--no-baseline-configs", action="store_true",
+                    help="N = 1: skip the extra lines for the other BASELINE.json configs (c2_10k, c3, c5)")
     ap.add_argument("--force-comm", action="store_true",
                     help="N = 1: still create the RCCL communicator and gather every step (exercises the N > 1 path)")
     return ap.parse_args(argv)
@@ -661,6 +666,66 @@ def extras_single_gpu(a, L, main):
     return out
 
 
+def baseline_config_extra(a, L, kind, reads, samples, motif, steps, warmup, label):
+    """One of BASELINE.json's other configs as a bench line of its own (N = 1): the same Workload / timed / oracle
+    parity / roofline code as the headline, at that config's size.  C2: segmenter 10 000 x 4 000; C3: MotifSeq
+    10 000 x 4 000 vs a ~200-pt model (163 points: the size of example/CATCTATCCAGGGTTAAATT.model expanded); C5:
+    MotifSeq 100 000 x 20 000 vs a 500-pt motif (on one GPU)."""
+    sa = argparse.Namespace(**vars(a))
+    sa.workload, sa.reads, sa.samples, sa.motif = kind, reads, samples, motif
+    w = Workload(sa, L, 0, 1, reads, workload=kind)
+    try:
+        el, prof = timed(w, None, steps, warmup)
+        par, _, mean_n = parity_and_cpu(sa, w, False)
+        par["oracle_pinned"] = ORACLE_PINNED[kind]
+        ms = el / steps * 1e3
+        if kind == "motifseq":
+            roof = motifseq_roofline(sa, w, prof, steps, mean_n)
+            roof = headline_roofline_labels(roof)
+        else:
+            roof = segmenter_roofline(w, prof, steps, step_ms=ms)
+        return {"config": label, "metric": "reads/sec " + ("MotifSeq DTW" if kind == "motifseq" else "segmenter"),
+                "value": reads * steps / el, "unit": "reads/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+                "ms_per_step": ms, "workload": workload_name(kind, reads, samples, motif if kind == "motifseq" else None, "strong",
+                                                             sa.scale),
+                "roofline": roof, "parity": par}
+    finally:
+        w.free()
+
+
+def baseline_configs_block(a, L):
+    out = {}
+    for key, args in (("c2_10k", ("segmenter", 10_000, 4000, 200, 20, 3, "BASELINE config 2: segmenter, 10 000 synthetic int16 reads x 4 000 samples")),
+                      ("c3", ("motifseq", 10_000, 4000, 163, 20, 3, "BASELINE config 3: MotifSeq, 10 000 reads x 4 000 samples vs a 163-pt model")),
+                      ("c5", ("motifseq", 100_000, 20000, 500, 3, 1, "BASELINE config 5: MotifSeq long-read stress, 100 000 reads x 20 000 samples vs a 500-pt motif (one GPU)"))):
+        try:
+            out[key] = baseline_config_extra(a, L, *args)
+        except Exception as e:                                        # noqa: BLE001 -- report, keep the other lines
+            out[key] = {"config": args[-1], "error": repr(e)}
+    return out
+
+
+# what pins the oracle each parity block compares with (SURVEY 8(c)): the segmenter path and the normalisations are pinned
+# by outputs of the reference itself (tools/gen_golden.py imports /root/reference; tests/golden/*); the DTW core restates
+# mlpy 3.5.0's cdtw.c, and mlpy is in neither /root/reference nor this image -- unpinned until tools/pin_mlpy.py has run
+ORACLE_PINNED = {"segmenter": True, "motifseq": False}
+
+
+def headline_roofline_labels(roof):
+    """SURVEY 8(d) names two fractions for the DTW path; both, side by side, with where each peak comes from"""
+    v = roof.get("valu", {})
+    sp, ws = v.get("screening_pass", {}), v.get("whole_step", {})
+    roof["hbm_frac"] = roof["frac"]
+    roof["hbm_peak_source"] = "/opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s"
+    roof["valu_frac"] = sp.get("frac") if sp.get("frac") is not None else sp.get("frac_at_2.4_ghz")
+    roof["valu_frac_whole_step"] = ws.get("frac") if ws.get("frac") is not None else ws.get("frac_at_2.4_ghz")
+    roof["valu_peak_source"] = ("profiles/r05_valu_rate.txt (tools/ubench/valu_rate.hip): v_min3_u32 / v_sad_u32 issue in "
+                                "4.1-4.3 shader cycles on a SIMD => 1024 SIMDs x 64 lanes / 8 cycles per cell x the measured clock")
+    roof["limiter"] = "valu_frac (VALU issue rate of the min-plus recurrence); hbm_frac is what SURVEY 8(d) also asks for"
+    roof.pop("binding", None)
+    return roof
+
+
 # ----------------------------------------------------------------------------------------------------
 # one rank
 # ----------------------------------------------------------------------------------------------------
@@ -722,8 +787,13 @@ def rank_body(a, comm, rank, world, shape):
         for key in ("dist_bit_identical", "start_end_exact", "segments_bit_exact"):
             if key in parity:
                 parity[key] = bool(parity[key] and gv["every_rank_ok"])
+    parity["oracle_pinned"] = ORACLE_PINNED[a.workload]
+    parity["oracle_pinned_note"] = ("filter / medmad / zscale are pinned by reference-made goldens; the DTW core (D1-D3) restates "
+                                    "mlpy 3.5.0, absent here: *_bit_identical means identical to oracle/sk_oracle.c "
+                                    "(tools/pin_mlpy.py pins it where mlpy imports)") if a.workload == "motifseq" else \
+        "pinned by outputs of the reference itself (tools/gen_golden.py, tests/golden/)"
     if a.workload == "motifseq":
-        roofline = motifseq_roofline(a, w, prof, a.steps, mean_n)
+        roofline = headline_roofline_labels(motifseq_roofline(a, w, prof, a.steps, mean_n))
         name = "reads/sec MotifSeq DTW (4k-sample read x 200-sample motif)"
         wl = workload_name("motifseq", a.reads, a.samples, a.motif, a.scaling, a.scale)
     else:
@@ -733,7 +803,8 @@ def rank_body(a, comm, rank, world, shape):
         wl = workload_name("segmenter", a.reads, a.samples, None, a.scaling)
     line = {"metric": name, "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": a.scaling,
-            "vs_baseline": None, "dtype": "f64" if a.workload == "motifseq" else "int16/f64",
+            "vs_baseline": None,
+            "dtype": "f64 results; u32 fixed-point screening" if a.workload == "motifseq" else "int16 samples; f64 thresholds",
             "data": "synthetic",
             "config": {"workload": wl, "reads_per_gpu": w.R, "total_reads": total_reads, "samples": a.samples,
                        "motif_points": a.motif if a.workload == "motifseq" else None, "seed": w.seed,
@@ -752,6 +823,17 @@ def rank_body(a, comm, rank, world, shape):
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity}
     line["ranks_seen"] = ranks_seen
     line["gather_backend"] = use_comm.backend if use_comm is not None else None
+    # a silent fallback must not produce a clean-looking scaling line: fewer ranks than asked for, or the gather done by
+    # host concatenation because RCCL could not be used, fail the run (dry runs on one device say --allow-host-gather or
+    # --ranks-on-device, where the host backend is the point)
+    if world > 1 and a.ranks_on_device is None and not a.allow_host_gather:
+        problems = []
+        if ranks_seen != world:
+            problems.append("ranks_seen = %d of %d" % (ranks_seen, world))
+        if use_comm is not None and use_comm.backend != "rccl":
+            problems.append("gather_backend = %s (%s)" % (use_comm.backend, getattr(use_comm, "why_host", "?")))
+        if problems:
+            line["failed"] = "; ".join(problems)
     line["per_rank"] = {"ms_per_step": per_rank_ms, "h2d_GBps": h2d,
                         "note": "each rank's own wall clock of the timed steps (the line's ms_per_step is their maximum); "
                                 "h2d_GBps: its host-to-device rate in the every-rank end-to-end leg -- a slow PCIe root "
@@ -774,6 +856,8 @@ def rank_body(a, comm, rank, world, shape):
     if world == 1 and a.only_other_paths:
         extras["other_paths"] = bench_extras.other_paths_block(a, L, w)
     elif world == 1 and not a.no_extras:
+        if a.workload == "motifseq" and not a.no_baseline_configs and a.reads == 1_000_000 and a.samples == 4000:
+            extras.update(baseline_configs_block(a, L))               # c2_10k, c3, c5: lines of their own
         extras.update(extras_single_gpu(a, L, w))
         extras["sweep"] = bench_extras.sweep_block(a, L, w)
         if a.workload == "motifseq" and not a.no_sensitivity:
@@ -851,6 +935,9 @@ def main(argv=None):
             with open(a.full_json, "w") as fh:
                 json.dump(dict(line, **extras), fh)
         print(json.dumps(line), flush=True)
+        if line.get("failed"):
+            sys.stderr.write("bench.py: FAILED multi-GPU sanity: %s (pass --allow-host-gather for a dry run)\n" % line["failed"])
+            sys.exit(4)
 
 
 if __name__ == "__main__":

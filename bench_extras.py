@@ -210,6 +210,21 @@ def sweep_block(a, L, main):
             "what": "C4 (%d reads in total) over N GPUs from one GPU's rate at %d / N reads per call; gather and ingest not included" % (main.R, main.R),
             "efficiency": {str(main.R // r["reads_per_call"]): r["vs_full_batch_rate"] for r in rows},
             "reads_per_s": {str(main.R // r["reads_per_call"]): r["reads_per_s"] * (main.R // r["reads_per_call"]) for r in rows}}
+        # ... with the one exchange put back in as a MODEL (it has never run on more than one rank): an all-gather of
+        # 24 B per read in total, every rank receiving (N - 1) / N of it, priced at one xGMI link's ~48 GB/s per direction
+        # (a third of the 153 GB/s the guide quotes, ring-style, no overlap with the kernels) plus 30 us of launch /
+        # synchronisation latency per step.  The measured rate of this is what SCALE_rNN.json is for.
+        link_gbs, lat_ms = 48.0, 0.030
+        eff = {}
+        for r in rows:
+            n = main.R // r["reads_per_call"]
+            gather_ms = 0.0 if n == 1 else lat_ms + (main.R * 24.0 * (n - 1) / n) / (link_gbs * 1e9) * 1e3
+            eff[str(n)] = (rows[0]["ms"] / n) / (r["ms"] + gather_ms)
+        out["predicted_strong_scaling"]["efficiency_with_gather_model"] = eff
+        out["predicted_strong_scaling"]["gather_model"] = (
+            "all-gather of 24 B/read priced at %.0f GB/s per rank + %.0f us per step, not overlapped; ingest (PCIe) is per GPU "
+            "and does not enter a device-resident step -- bench.py --gpus N times it on every rank at once (end_to_end)"
+            % (link_gbs, lat_ms * 1e3))
     return out
 
 
