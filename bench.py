@@ -512,6 +512,22 @@ def motifseq_roofline(a, w, prof, steps, mean_n):
                               "frac_at_2.4_ghz": step_ach / nominal,
                               "note": "screening (+ prologue) + pre-roll + certified window + retries, against the "
                                       "screening pass's own roof"}
+        # the exact window pass against ITS roof: mlpy's recurrence with start tracking is 8 instructions per cell
+        # (|x - y|, two compares, two v_min_f64, two selects, one add; six of them FP64, 4.1 issue cycles each --
+        # profiles/r05_valu_rate.txt), the wavefronts' steps are counted by the kernel itself (sk_last_dtw_window_steps)
+        ws = (C.c_uint64 * 2)()
+        w.L.sk_last_dtw_window_steps(ws)
+        win_ms = prof["start_ms"] / steps
+        if ws[0] and win_ms > 0:
+            G = 64 // Lg
+            simd_cycles = win_ms * 1e-3 * (clk or 2.4) * 1e9 * (WAVE_ISSUE_SLOTS / 2.4e9 / 64.0)   # SIMDs x cycles in the pass
+            used = float(ws[0]) * Rg * 8 * 4.0
+            valu["window_pass"] = {
+                "bound": "valu_issue", "instructions_per_cell": 8, "wave_steps": int(ws[0]), "read_steps_asked": int(ws[1]),
+                "steps_per_read": float(ws[1]) / R, "lockstep_efficiency": float(ws[1]) / (float(ws[0]) * G),
+                "frac": used / simd_cycles,
+                "note": "k_sdtw_w + k_sdtw_p, all tiers: cell instructions the wavefronts issued x 4 cycles / (SIMDs x cycles of "
+                        "the passes' summed HIP-event time); the pre-roll (k_sdtw_p) and the per-step overhead are not in the numerator"}
         valu["passes_ms_per_call"] = {"prep": prep_ms, "screen": prof["dist_ms"] / steps,
                                       "window": prof["start_ms"] / steps,
                                       "retried_reads": prof["retries"] / steps,

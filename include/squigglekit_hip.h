@@ -399,6 +399,11 @@ int sk_last_dtw_tier2(void);
 int sk_last_dtw_guard(int32_t *out /* [8] */);
 int sk_last_dtw_premise_violations(void);
 int sk_last_dtw_audit_mismatches(void);
+/* Steps of the exact window pass in the most recent DTW call: out[0] = steps its wavefronts ran (the read groups of a
+ * wavefront step together), out[1] = steps the reads asked for, summed over the groups.  bench.py prices the pass's own
+ * issue roof with these (8 instructions per cell and step; mlpy's exact recurrence with start tracking,
+ * /root/reference/MotifSeq.py:437-439).  Zeros when the call did not take the screening scheme. */
+int sk_last_dtw_window_steps(uint64_t *out /* [2] */);
 /* Reads of the most recent float64 call (sk_segment_*_f64, sk_motifseq_*_f64 with medmad) whose comparisons /
  * selection the streaming statistics kernel could not certify and that were redone in numpy's order (diagnostic);
  * -1 when the call did not use the streaming kernel (reads longer than 4 096 samples, zscale). */

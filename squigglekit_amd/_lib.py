@@ -169,6 +169,7 @@ ABI = {
     "sk_last_dtw_retries": (C.c_int, []),
     "sk_last_dtw_tier2": (C.c_int, []),
     "sk_last_dtw_guard": (C.c_int, [_i32p]),
+    "sk_last_dtw_window_steps": (C.c_int, [_vp]),
     "sk_last_dtw_premise_violations": (C.c_int, []),
     "sk_last_dtw_audit_mismatches": (C.c_int, []),
     "sk_last_f64_retries": (C.c_int, []),

@@ -89,6 +89,7 @@ static const sk_tunable SK_TUNABLES[] = {
     {"SK_SEG_OLD",            "1",           "segmenter: numpy-order statistics kernels for every read"},
     {"SK_SEG_DELTA_SCALE",    "1e13",        "segmenter: certification margin multiplier (large: every read takes the numpy-order redo)"},
     {"SK_SEG_PA_F64",         "1",           "segmenter, raw reads through the pA conversion: expand to float64 and take the float64 kernels instead of the raw-domain kernel"},
+    {"SK_SEG_NO_WG",          "1",           "segmenter, reads of 4 097 .. 65 536 samples: the wavefront-per-read statistics kernel (two looks at a read) instead of the workgroup-per-read one"},
     {"SK_SEG_OCC",            "7 8",         "segmenter statistics kernel: waves per SIMD the registers are sized for"},
     {"SK_SEG_CHUNKS",         "2 8",         "segmenter: chunks of a large batch (walk of one beside the statistics of the next)"},
     {"SK_WALK_STEP",          "1",           "segmenter walk: per-sample straight-line step instead of run hopping"},
@@ -414,6 +415,22 @@ int sk_last_dtw_audit_mismatches(void)
     int32_t g[8];
     const int rc = sk_last_dtw_guard(g);
     return rc ? rc : g[2];
+}
+
+// out[0] = steps the wavefronts of the window pass (k_sdtw_w, every tier) ran in the last DTW call, out[1] = the steps their
+// reads asked for, summed over the read groups (a wavefront's groups step together: out[0] * groups per wave >= out[1])
+int sk_last_dtw_window_steps(uint64_t *out)
+{
+    sk_ctx *c = sk_cur();
+    if (!c) return SK_ERR_NO_DEVICE;
+    sk_ctx_guard c_lock(c);
+    if (!out) return sk_fail(SK_ERR_INVALID, "NULL pointer");
+    out[0] = out[1] = 0;
+    if (!(c->retry_dev && c->dtwcnt.p && c->dtwcnt.cap >= 128)) return SK_OK;
+    if (hipMemcpyAsync(out, (const char *)c->dtwcnt.p + 64, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return sk_fail(SK_ERR_HIP, "reading the window-step counters failed");
+    return SK_OK;
 }
 
 int sk_last_dtw_tier2(void)

@@ -599,12 +599,12 @@ int sk_launch_sdtw(sk_ctx *c, const sk_sdtw_args *a_in)
     // entries are swept with each read spread over 64 lanes; whatever lies beyond uses the batch layout.
     int rc;
     if ((rc = sk_reserve(c, &c->retry, 2 * ((size_t)a->nreads + 2) * sizeof(int32_t)))) return rc;
-    if ((rc = sk_reserve(c, &c->dtwcnt, 64))) return rc;
+    if ((rc = sk_reserve(c, &c->dtwcnt, 128))) return rc;
     int32_t *cnt = (int32_t *)c->retry.p;                  // [0] = counter, [2..] = read indices
     int32_t *ecnt = cnt + a->nreads + 2;                   // a second list of the same shape: the early retry's
     SK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), c->stream));
     SK_HIP(hipMemsetAsync(ecnt, 0, sizeof(int32_t), c->stream));
-    if (!a->accumulate) SK_HIP(hipMemsetAsync(c->dtwcnt.p, 0, 64, c->stream));   // [0] retried, [1] second tier, +16: clock, +32: guard counters
+    if (!a->accumulate) SK_HIP(hipMemsetAsync(c->dtwcnt.p, 0, 128, c->stream));  // [0] retried, [1] second tier, +16: clock, +32: guard counters, +64: window-pass steps
     c->retry_dev = true;
     // the motif laid out for 64 lanes (the short retry list is swept with a read per wavefront): uploaded here, ahead
     // of everything the call enqueues, because the early retry runs on another stream

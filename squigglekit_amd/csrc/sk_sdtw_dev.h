@@ -102,6 +102,8 @@ struct sdtw_kargs {
     int            lds_wave_words; // pass Q: words of dynamic LDS per wavefront (the prologue's histogram, then the interval's last-row values)
     int32_t       *early;       // reads pass Q already knows cannot be screened (candidate range too wide, samples out of
     int32_t       *early_cnt;   // range): their exact retry starts right behind pass Q, beside the window passes
+    unsigned long long *wsteps; // pass W: [0] += steps this wavefront ran (all its read groups in lockstep), [1] += steps its
+                                // reads asked for (sum over the groups); or nullptr
     unsigned long long *clk;    // pass Q: {shader cycles, 100 MHz reference ticks} of the first wave's sweep, or nullptr
     int            force_retry; // sensitivity runs: reads whose hash (10 bits) is below this take the exact retry
     // run-time guard of the screening certificate: counters in device memory, see SK_GUARD_*

@@ -700,10 +700,15 @@ void k_sdtw_w(const sdtw_kargs a)
 
     int nsteps = tlast - tbase + 1;
     if (nsteps < 0) nsteps = 0;
+    const int own_steps = nsteps;                   // what MY read asks for (before the wavefront's maximum)
 #pragma unroll
     for (int d = L; d < 64; d <<= 1) nsteps = max(nsteps, __shfl_xor(nsteps, d));
     nsteps = __builtin_amdgcn_readfirstlane(nsteps);
     const int nblk = (nsteps + L - 1) / L;
+    if (a.wsteps) {                                 // diagnostic: the pass's issue roof is counted in these (bench.py)
+        if (lane == 0 && nblk > 0) atomicAdd(&a.wsteps[0], (unsigned long long)(nblk * L));
+        if (live && l == 0 && own_steps > 0) atomicAdd(&a.wsteps[1], (unsigned long long)own_steps);
+    }
 
     double x[XLDS ? 1 : R];
     constexpr int RP = R | 1;                       // odd row pitch: the lanes of a group land in different LDS banks
@@ -1151,6 +1156,7 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
     k.wmax = 4 * ck;
     k.lds_wave_words = (64 / L) * ck;                   // pass Q, per wave: the interval's last-row values of its read groups
     k.guard = sk_tune("SK_DTW_NOGUARD") ? nullptr : (int32_t *)c->dtwcnt.p + 8;
+    k.wsteps = (unsigned long long *)((char *)c->dtwcnt.p + 64);
     if (const char *e = sk_tune("SK_DTW_HOLE")) {                 // tests: a known hole back in, for the guard to find
         k.hole = strcmp(e, "qerr1") == 0 ? SK_HOLE_QERR1 : strcmp(e, "fma64") == 0 ? SK_HOLE_FMA64
                : strcmp(e, "fma64x") == 0 ? SK_HOLE_FMA64_UNGUARDED : SK_HOLE_NONE;

@@ -52,7 +52,7 @@ def squiggles(R, M, seed, base=0, scale=1.0):
     return np.clip(np.rint(x * scale + base), -32768, 32767).astype(np.int16)
 
 
-@pytest.mark.parametrize("M", [1000, 2048, 4000, 4096, 19999, 36977])
+@pytest.mark.parametrize("M", [1000, 2048, 4000, 4096, 4100, 16384, 19999, 36977, 50000, 65536, 70000])
 def test_raw_domain_pa_matches_float64_oracle(gpu, ora, M):
     """MinION and PromethION channel constants at every kernel shape (2 / 4 / 8 tiles, reads longer than a window),
     ragged lengths: no read takes the redo, every boundary equals the oracle's on the float64 values."""

@@ -239,7 +239,7 @@ def test_streaming_path_retry_list_and_old_kernels_agree(gpu, ora, monkeypatch):
         monkeypatch.delenv(env)
 
 
-@pytest.mark.parametrize("M", [4104, 9000, 20000, 36984])
+@pytest.mark.parametrize("M", [4104, 9000, 16384, 16392, 20000, 36984, 49160, 65536, 65544])
 def test_streaming_path_long_reads(gpu, ora, monkeypatch, M):
     """Reads longer than one 4 096-sample window: the statistics kernel looks at them twice (window by window);
     with the certification margin blown up, the numpy-order redo runs on them too (LDS-resident copy up to
@@ -261,6 +261,13 @@ def test_streaming_path_long_reads(gpu, ora, monkeypatch, M):
     monkeypatch.setenv("SK_SEG_DELTA_SCALE", "1e13")
     for kw in cases[:2]:
         _check_vs_oracle(api, ora, sig, lens, kw, "long M=%d, redo" % M, max_segs=160)
+    monkeypatch.delenv("SK_SEG_DELTA_SCALE")
+    # rows of up to 65 536 samples take the workgroup-per-read statistics kernel (one look, round 6): the
+    # wavefront-per-read one (two looks) must give the same records
+    monkeypatch.setenv("SK_SEG_NO_WG", "1")
+    for kw in cases[:2]:
+        _check_vs_oracle(api, ora, sig, lens, kw, "long M=%d, wavefront per read" % M, max_segs=160)
+    monkeypatch.delenv("SK_SEG_NO_WG")
 
 
 @pytest.mark.parametrize("M", [20000, 70000, 140000])
