@@ -90,6 +90,7 @@ static const sk_tunable SK_TUNABLES[] = {
     {"SK_SEG_DELTA_SCALE",    "1e13",        "segmenter: certification margin multiplier (large: every read takes the numpy-order redo)"},
     {"SK_SEG_PA_F64",         "1",           "segmenter, raw reads through the pA conversion: expand to float64 and take the float64 kernels instead of the raw-domain kernel"},
     {"SK_SEG_NO_WG",          "1",           "segmenter, reads of 4 097 .. 65 536 samples: the wavefront-per-read statistics kernel (two looks at a read) instead of the workgroup-per-read one"},
+    {"SK_SEG_WG_ALL",         "1",           "segmenter: the workgroup-per-read statistics kernel for every row of 4 097 .. 65 536 samples (default: where it is faster)"},
     {"SK_SEG_OCC",            "7 8",         "segmenter statistics kernel: waves per SIMD the registers are sized for"},
     {"SK_SEG_CHUNKS",         "2 8",         "segmenter: chunks of a large batch (walk of one beside the statistics of the next)"},
     {"SK_WALK_STEP",          "1",           "segmenter walk: per-sample straight-line step instead of run hopping"},

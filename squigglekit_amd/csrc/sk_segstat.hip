@@ -571,14 +571,14 @@ void k_seg_stats(const SegStatArgs a)
 // wave derives the same statistics from it -- redundantly: a few hundred instructions against thousands per window --
 // and classifies its own windows out of its registers.  The read is fetched once.  Same arithmetic, same certificate,
 // same masks as k_seg_stats (the per-read part is the same code, parameterised by where the histogram lives).
-template <int KW, bool PA>
+template <int KT, bool PA>
 __global__ __launch_bounds__(256, 2)
 void k_seg_stats_wg(const SegStatArgs a)
 {
-    constexpr int NT = 8, NQ = 8, HBINS = 64 * 4 * NQ, WIN = 512 * NT;
+    constexpr int NQ = 8, HBINS = 64 * 4 * NQ;
     __shared__ __align__(16) unsigned hist[HBINS];
-    __shared__ __align__(16) unsigned char plane_all[4][2][64 * NT];
-    __shared__ unsigned long long red[2];                  // sum t', sum t'^2 over the read (not PA)
+    __shared__ __align__(16) unsigned char plane_all[4][2][64];
+    __shared__ unsigned long long red[2];                  // not PA: sum t', sum t'^2;  PA: sum c', sum c'^2
     __shared__ int red_mx;                                 // PA: largest raw sample + 32 768
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -589,30 +589,27 @@ void k_seg_stats_wg(const SegStatArgs a)
     int lo_r = a.lo;
     unsigned lo1p = (unsigned)((a.lo + 1) & 0xffff) * 0x10001u;
     unsigned nbp = (unsigned)nbins * 0x10001u, nbm1p = (unsigned)(nbins - 1) * 0x10001u;
-    const int maxM = (int)min(a.stride, (int64_t)(4 * KW * WIN));
+    const int maxM = (int)min(a.stride, (int64_t)(4 * KT * 512));
 
     for (int i = threadIdx.x; i < HBINS; i += 256) hist[i] = 0u;
     if (threadIdx.x == 0) { red[0] = 0ull; red[1] = 0ull; red_mx = 0; }
     __syncthreads();
 
-    unsigned y[KW][NT][4];
+    // The read's 512-sample tiles are dealt round robin: wave w holds tiles w, w + 4, ... (1 KB each, 4 VGPRs a tile) --
+    // whatever the read's length the four waves carry the same load to within one tile.
+    unsigned y[KT][4];
     for (int r = blockIdx.x; r < a.nreads; r += gridDim.x) {
         const int M = __builtin_amdgcn_readfirstlane(min(max(a.len[r], 0), maxM));
         const int16_t *row = a.sig + (int64_t)r * a.stride;
-        const int nwin = (M + WIN - 1) / WIN;
         const int tiles_total = (M + 511) >> 9;
 
-        // ---- all loads of my windows first ----
+        // ---- all loads of my tiles first ----
 #pragma unroll
-        for (int k = 0; k < KW; k++) {
-            const int wi = w + 4 * k;
-            const int Mw = min(M - wi * WIN, WIN);
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                uint4 q = make_uint4(0u, 0u, 0u, 0u);
-                if (wi < nwin && t * 512 + lane * 8 < Mw) q = *(const uint4 *)(row + (int64_t)wi * WIN + t * 512 + lane * 8);
-                y[k][t][0] = q.x; y[k][t][1] = q.y; y[k][t][2] = q.z; y[k][t][3] = q.w;
-            }
+        for (int k = 0; k < KT; k++) {
+            const int g = w + 4 * k;
+            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            if (g * 512 + lane * 8 < M) q = *(const uint4 *)(row + (int64_t)g * 512 + lane * 8);
+            y[k][0] = q.x; y[k][1] = q.y; y[k][2] = q.z; y[k][3] = q.w;
         }
 
         // ---- PA: this read's limits in the raw domain (every wave the same) ----
@@ -638,85 +635,57 @@ void k_seg_stats_wg(const SegStatArgs a)
         }
         const bool skip = PA && nbins == 0;                // nothing can be kept / calibration outside the plain range
 
-        auto image = [&](unsigned q, bool last_tile, int k2, int nvalid) -> unsigned {
-            unsigned tt = pk_min_u16(pk_sub_u16(q, lo1p), nbp);
-            if (last_tile) {
-                const unsigned tail = nvalid >= 2 * k2 + 2 ? 0xffffffffu : (nvalid == 2 * k2 + 1 ? 0xffffu : 0u);
-                tt = (tt & tail) | (nbp & ~tail);
-            }
-            return tt;
-        };
-
         // ---- first look: t' per sample, histogram, sums / maximum ----
         if (!skip) {
-            long long S = 0, Q = 0;
+            int st = 0;
+            unsigned stt = 0u;                             // (8 x 2047^2 x 32 tiles < 2^31)
             unsigned mxp = 0x80008000u;
 #pragma unroll
-            for (int k = 0; k < KW; k++) {
-                const int wi = w + 4 * k;
-                if (wi >= nwin) continue;
-                const int Mw = min(M - wi * WIN, WIN);
-                const int ntiles = (Mw + 511) >> 9;
-                int st = 0, stt = 0;
+            for (int k = 0; k < KT; k++) {
+                const int g = w + 4 * k;
+                if (g >= tiles_total) continue;            // (wave-uniform)
+                const bool last = g == tiles_total - 1;
+                const int nvalid = min(max(M - (g * 512 + lane * 8), 0), 8);
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    if (t >= ntiles) continue;
-                    const int nvalid = min(max(Mw - (t * 512 + lane * 8), 0), 8);
-#pragma unroll
-                    for (int k2 = 0; k2 < 4; k2++) {
-                        if constexpr (PA) {
-                            unsigned qm = y[k][t][k2];
-                            if (t == ntiles - 1) {
-                                const unsigned tail = nvalid >= 2 * k2 + 2 ? 0xffffffffu : (nvalid == 2 * k2 + 1 ? 0xffffu : 0u);
-                                qm = (qm & tail) | (0x80008000u & ~tail);
-                            }
-                            mxp = pk_max_i16(mxp, qm);
-                        }
-                        const unsigned tt = image(y[k][t][k2], t == ntiles - 1, k2, nvalid);
-                        y[k][t][k2] = tt;
-                        if constexpr (!PA) {
-                            const s16x2 ts = __builtin_bit_cast(s16x2, tt);
-                            st = __builtin_amdgcn_sdot2(ts, __builtin_bit_cast(s16x2, 0x10001u), st, false);
-                            stt = __builtin_amdgcn_sdot2(ts, ts, stt, false);
-                        }
-                        const unsigned t4 = pk_shl2_u16(tt);
-                        atomicAdd((unsigned *)((char *)hist + (t4 & 0xffffu)), 1u);
-                        atomicAdd((unsigned *)((char *)hist + (t4 >> 16)), 1u);
+                for (int k2 = 0; k2 < 4; k2++) {
+                    const unsigned tail = !last ? 0xffffffffu : nvalid >= 2 * k2 + 2 ? 0xffffffffu : (nvalid == 2 * k2 + 1 ? 0xffffu : 0u);
+                    if constexpr (PA) mxp = pk_max_i16(mxp, (y[k][k2] & tail) | (0x80008000u & ~tail));
+                    unsigned tt = pk_min_u16(pk_sub_u16(y[k][k2], lo1p), nbp);
+                    if (last) tt = (tt & tail) | (nbp & ~tail);
+                    y[k][k2] = tt;
+                    if constexpr (!PA) {
+                        const s16x2 ts = __builtin_bit_cast(s16x2, tt);
+                        st = __builtin_amdgcn_sdot2(ts, __builtin_bit_cast(s16x2, 0x10001u), st, false);
+                        stt = (unsigned)__builtin_amdgcn_sdot2(ts, ts, (int)stt, false);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned t4 = pk_shl2_u16(tt);
+                    atomicAdd((unsigned *)((char *)hist + (t4 & 0xffffu)), 1u);
+                    atomicAdd((unsigned *)((char *)hist + (t4 >> 16)), 1u);
                 }
-                if constexpr (!PA) {
-                    S += (long long)wave_sum(st);
-                    Q += (long long)wave_sum(stt & 0xffff) + ((long long)wave_sum((int)((unsigned)stt >> 16)) << 16);
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (PA) {
                 int mx = max((int)(short)(mxp & 0xffffu), (int)(short)(mxp >> 16));
                 mx = (int)__builtin_amdgcn_readlane((int)wave_incl_max((unsigned)(mx + 32768)), 63);
                 if (lane == 0) atomicMax(&red_mx, mx);
-            } else if (lane == 0) {
-                atomicAdd(&red[0], (unsigned long long)S);
-                atomicAdd(&red[1], (unsigned long long)Q);
+            } else {
+                unsigned long long S = (unsigned long long)(unsigned)st, Q = (unsigned long long)stt;
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) { S += __shfl_xor(S, sft); Q += __shfl_xor(Q, sft); }
+                if (lane == 0) { atomicAdd(&red[0], S); atomicAdd(&red[1], Q); }
             }
         }
-        __syncthreads();                                   // the read's histogram and sums are complete
+        __syncthreads();                                   // the read's histogram (and sums / maximum) are complete
 
-        sk_prep pr;
-        pr.n = 0; pr.flags = 0; pr.center = 0.0; pr.scale = 1.0; pr.top = 0.0; pr.bot = 0.0;
-        int tlo = 0, width = 0;
-        bool certified = true;
-        if (skip) {
-            certified = pa_ok;
-            pr.flags = SK_FLAG_EMPTY;
-            const double qnan = __builtin_nan("");
-            pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
-        } else {
-            const long long D = (long long)__builtin_amdgcn_readfirstlane((int)hist[nbins]);   // dropped + slots past the end of every window
-            const int n = tiles_total * 512 - (int)D;
-            pr.n = n;
-            bool over = false;
+        // ---- D, n, the two middle values: every wave for itself (a few hundred instructions) ----
+        long long D = 0;
+        int n = 0, b1 = 0, b2 = 0;
+        bool over = false;
+        if (!skip) {
+            D = (long long)__builtin_amdgcn_readfirstlane((int)hist[nbins]);   // dropped + slots past the read's end
+            n = tiles_total * 512 - (int)D;
             if constexpr (PA) over = pa_span > nbins && (red_mx - 32768) >= lo_r + 1 + nbins;
-            // the dump bin sits ABOVE every kept value: a rank below n never reaches it, the sweeps need not skip it
+            // (the dump bin sits ABOVE every kept value: a rank below n never reaches it, the sweeps need not skip it)
             int local = 0;
 #pragma unroll
             for (int j = 0; j < NQ; j++) {
@@ -724,12 +693,7 @@ void k_seg_stats_wg(const SegStatArgs a)
                 local += (int)(q.x + q.y + q.z + q.w);
             }
             asm volatile("" ::: "memory");
-            if (n == 0) {
-                certified = !over;
-                pr.flags = SK_FLAG_EMPTY;
-                const double qnan = __builtin_nan("");
-                pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
-            } else {
+            if (n > 0) {
                 const int inc = wave_incl_scan(local);
                 const int k1 = (n - 1) / 2, k2 = n / 2;
                 const int pre = inc - local;
@@ -747,14 +711,15 @@ void k_seg_stats_wg(const SegStatArgs a)
                 }
                 const unsigned long long own1 = __ballot(local > 0 && k1 >= pre && k1 < pre + local);
                 const unsigned long long own2 = __ballot(local > 0 && k2 >= pre && k2 < pre + local);
-                const int b1 = __builtin_amdgcn_readlane(i1, own1 ? (int)__builtin_ctzll(own1) : 0);
-                const int b2 = __builtin_amdgcn_readlane(i2, own2 ? (int)__builtin_ctzll(own2) : 0);
-                const double eps8 = 8.0 * 1.1102230246251565e-16;
-                if constexpr (PA) {
+                b1 = __builtin_amdgcn_readlane(i1, own1 ? (int)__builtin_ctzll(own1) : 0);
+                b2 = __builtin_amdgcn_readlane(i2, own2 ? (int)__builtin_ctzll(own2) : 0);
+            }
+            if constexpr (PA) {
+                // the centi-pA sums off the histogram: wave w takes bins [512 w, 512 w + 512)
+                if (n > 0) {
                     const int xa = lo_r + 1;
-                    const double median = (pa_centi(xa + b1, pa_off, pa_unit) / 100.0 + pa_centi(xa + b2, pa_off, pa_unit) / 100.0) / 2.0;
                     unsigned long long c1 = 0, c2 = 0;
-                    for (int j = 0; j < 4 * NQ; j++) {
+                    for (int j = 8 * w; j < 8 * w + 8; j++) {
                         const int b = 64 * j + lane;
                         const unsigned k = b < nbins ? hist[b] : 0u;
                         if (__ballot(k != 0u) == 0ull) continue;
@@ -764,47 +729,68 @@ void k_seg_stats_wg(const SegStatArgs a)
                     }
 #pragma unroll
                     for (int sft = 32; sft >= 1; sft >>= 1) { c1 += __shfl_xor(c1, sft); c2 += __shfl_xor(c2, sft); }
-                    unsigned long long ah, al, bh, bl;
-                    umul64wide((unsigned long long)n, c2, ah, al);
-                    umul64wide(c1, c1, bh, bl);
-                    const unsigned long long vl = al - bl, vh = ah - bh - (al < bl ? 1ull : 0ull);
-                    const double Vd = (double)vh * 18446744073709551616.0 + (double)vl;
-                    const double sd = sqrt(Vd) / (double)n / 100.0;
-                    const double spread = sd * a.std_scale;
-                    const double top = median + spread, bot = median - spread;
-                    const double vmax = fmax(fabs(pa_c0), fabs(pa_centi(xa + nbins - 1, pa_off, pa_unit))) / 100.0;
-                    const double delta = a.delta_scale * eps8 * (fabs(spread) * (double)(n + 17) + fabs(median) +
-                                                                 vmax * (1.0 + fabs(a.std_scale)) * ((double)n / 8192.0 + 36.0));
-                    const double Dl = 100.0 * delta + 100.0 * eps8 * (fabs(top) + fabs(bot) + vmax);
-                    const double Tt = top * 100.0, Tb = bot * 100.0;
-                    const int xt = __builtin_amdgcn_readfirstlane(pa_first<true>(Tt - Dl, xa, nbins, pa_off, pa_unit, lane));
-                    const int xl = __builtin_amdgcn_readfirstlane(pa_first<false>(Tb + Dl, xa, nbins, pa_off, pa_unit, lane));
-                    const bool cert_t = xt == xa + nbins || pa_centi(xt, pa_off, pa_unit) >= Tt + Dl;
-                    const bool cert_b = xl == xa || pa_centi(xl - 1, pa_off, pa_unit) <= Tb - Dl;
-                    certified = cert_t && cert_b && !over;
-                    pr.center = median; pr.scale = sd; pr.top = top; pr.bot = bot;
-                    tlo = xl - xa;
-                    width = max((xt - 1 - xa) - tlo + 1, 0);
-                } else {
-                    long long S = (long long)red[0], Q = (long long)red[1];
-                    S -= D * nbins;
-                    Q -= D * nbins * nbins;
-                    const double median = (double)(b1 + b2 + 2 * (a.lo + 1)) * 0.5;
-                    const long long V = (long long)n * Q - S * S;
-                    const double sd = sqrt((double)V) / (double)n;
-                    const double spread = sd * a.std_scale;
-                    const double top = median + spread, bot = median - spread;
-                    const double delta = a.delta_scale * eps8 * (fabs(spread) * (double)(n + 17) + fabs(median));
-                    const double ct = ceil(top), fb = floor(bot);
-                    certified = (V == 0) || (ceil(top - delta) == ct && ceil(top + delta) == ct &&
-                                             floor(bot - delta) == fb && floor(bot + delta) == fb);
-                    pr.center = median; pr.scale = sd; pr.top = top; pr.bot = bot;
-                    const double ctc = fmin(fmax(ct, (double)a.lo - 4.0), (double)a.hi + 4.0);
-                    const double fbc = fmin(fmax(fb, (double)a.lo - 4.0), (double)a.hi + 4.0);
-                    tlo = max((int)fbc - a.lo, 0);
-                    const int thi = min((int)ctc - a.lo - 2, nbins - 1);
-                    width = max(thi - tlo + 1, 0);
+                    if (lane == 0 && (c1 | c2)) { atomicAdd(&red[0], c1); atomicAdd(&red[1], c2); }
                 }
+            }
+        }
+        if constexpr (PA) __syncthreads();                 // the four partial sums are in
+
+        sk_prep pr;
+        pr.n = n; pr.flags = 0; pr.center = 0.0; pr.scale = 1.0; pr.top = 0.0; pr.bot = 0.0;
+        int tlo = 0, width = 0;
+        bool certified = true;
+        if (skip || n == 0) {
+            certified = skip ? pa_ok : !over;
+            pr.n = 0;
+            pr.flags = SK_FLAG_EMPTY;
+            const double qnan = __builtin_nan("");
+            pr.center = qnan; pr.scale = qnan; pr.top = qnan; pr.bot = qnan;
+        } else {
+            const double eps8 = 8.0 * 1.1102230246251565e-16;
+            if constexpr (PA) {
+                const int xa = lo_r + 1;
+                const double median = (pa_centi(xa + b1, pa_off, pa_unit) / 100.0 + pa_centi(xa + b2, pa_off, pa_unit) / 100.0) / 2.0;
+                const unsigned long long c1 = red[0], c2 = red[1];
+                unsigned long long ah, al, bh, bl;
+                umul64wide((unsigned long long)n, c2, ah, al);
+                umul64wide(c1, c1, bh, bl);
+                const unsigned long long vl = al - bl, vh = ah - bh - (al < bl ? 1ull : 0ull);
+                const double Vd = (double)vh * 18446744073709551616.0 + (double)vl;
+                const double sd = sqrt(Vd) / (double)n / 100.0;
+                const double spread = sd * a.std_scale;
+                const double top = median + spread, bot = median - spread;
+                const double vmax = fmax(fabs(pa_c0), fabs(pa_centi(xa + nbins - 1, pa_off, pa_unit))) / 100.0;
+                const double delta = a.delta_scale * eps8 * (fabs(spread) * (double)(n + 17) + fabs(median) +
+                                                             vmax * (1.0 + fabs(a.std_scale)) * ((double)n / 8192.0 + 36.0));
+                const double Dl = 100.0 * delta + 100.0 * eps8 * (fabs(top) + fabs(bot) + vmax);
+                const double Tt = top * 100.0, Tb = bot * 100.0;
+                const int xt = __builtin_amdgcn_readfirstlane(pa_first<true>(Tt - Dl, xa, nbins, pa_off, pa_unit, lane));
+                const int xl = __builtin_amdgcn_readfirstlane(pa_first<false>(Tb + Dl, xa, nbins, pa_off, pa_unit, lane));
+                const bool cert_t = xt == xa + nbins || pa_centi(xt, pa_off, pa_unit) >= Tt + Dl;
+                const bool cert_b = xl == xa || pa_centi(xl - 1, pa_off, pa_unit) <= Tb - Dl;
+                certified = cert_t && cert_b && !over;
+                pr.center = median; pr.scale = sd; pr.top = top; pr.bot = bot;
+                tlo = xl - xa;
+                width = max((xt - 1 - xa) - tlo + 1, 0);
+            } else {
+                long long S = (long long)red[0], Q = (long long)red[1];
+                S -= D * nbins;
+                Q -= D * nbins * nbins;
+                const double median = (double)(b1 + b2 + 2 * (a.lo + 1)) * 0.5;
+                const long long V = (long long)n * Q - S * S;
+                const double sd = sqrt((double)V) / (double)n;
+                const double spread = sd * a.std_scale;
+                const double top = median + spread, bot = median - spread;
+                const double delta = a.delta_scale * eps8 * (fabs(spread) * (double)(n + 17) + fabs(median));
+                const double ct = ceil(top), fb = floor(bot);
+                certified = (V == 0) || (ceil(top - delta) == ct && ceil(top + delta) == ct &&
+                                         floor(bot - delta) == fb && floor(bot + delta) == fb);
+                pr.center = median; pr.scale = sd; pr.top = top; pr.bot = bot;
+                const double ctc = fmin(fmax(ct, (double)a.lo - 4.0), (double)a.hi + 4.0);
+                const double fbc = fmin(fmax(fb, (double)a.lo - 4.0), (double)a.hi + 4.0);
+                tlo = max((int)fbc - a.lo, 0);
+                const int thi = min((int)ctc - a.lo - 2, nbins - 1);
+                width = max(thi - tlo + 1, 0);
             }
         }
         if (threadIdx.x == 0) {
@@ -812,37 +798,29 @@ void k_seg_stats_wg(const SegStatArgs a)
             if (!certified) a.retry[1 + atomicAdd(&a.retry[0], 1)] = r;
         }
 
-        // ---- second look, out of the registers: the masks of my windows ----
+        // ---- second look, out of the registers: the masks of my tiles (8 entries = 128 bytes a tile) ----
         const unsigned tlop = (unsigned)__builtin_amdgcn_readfirstlane(tlo) * 0x10001u;
         const unsigned wm1p = (unsigned)((__builtin_amdgcn_readfirstlane(width) - 1) & 0xffff) * 0x10001u;
+        const bool nothing = skip || n == 0;
 #pragma unroll
-        for (int k = 0; k < KW; k++) {
-            const int wi = w + 4 * k;
-            if (wi >= nwin) continue;
-            const int Mw = min(M - wi * WIN, WIN);
-            const int ntiles = (Mw + 511) >> 9;
-            if (skip) {
-                if (lane < 8 * ntiles) a.mask2[(int64_t)r * a.row16 + wi * (8 * NT) + lane] = make_uint4(0u, 0u, 0u, 0u);
-                continue;
+        for (int k = 0; k < KT; k++) {
+            const int g = w + 4 * k;
+            if (g >= tiles_total) continue;
+            unsigned drop8 = 0, out8 = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2++) {
+                const unsigned wts = (1u << (2 * k2)) | (2u << (2 * k2 + 16));
+                drop8 = udot2(pk_subsat_u16(y[k][k2], nbm1p), wts, drop8);
+                const unsigned ov = pk_subsat_u16(pk_sub_u16(y[k][k2], tlop), wm1p);
+                out8 = udot2(pk_min1_u16(ov), wts, out8);
             }
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                if (t >= ntiles) continue;
-                unsigned drop8 = 0, out8 = 0;
-#pragma unroll
-                for (int k2 = 0; k2 < 4; k2++) {
-                    const unsigned wts = (1u << (2 * k2)) | (2u << (2 * k2 + 16));
-                    drop8 = udot2(pk_subsat_u16(y[k][t][k2], nbm1p), wts, drop8);
-                    const unsigned ov = pk_subsat_u16(pk_sub_u16(y[k][t][k2], tlop), wm1p);
-                    out8 = udot2(pk_min1_u16(ov), wts, out8);
-                }
-                p_in[t * 64 + lane] = (unsigned char)((width > 0) ? ~out8 : 0u);
-                p_dr[t * 64 + lane] = (unsigned char)drop8;
-                __builtin_amdgcn_sched_barrier(0);
+            p_in[lane] = (unsigned char)((width > 0 && !nothing) ? ~out8 : 0u);
+            p_dr[lane] = (unsigned char)(nothing ? 0xffu : drop8);
+            if (lane < 8) {
+                const uint2 vi = *(const uint2 *)(p_in + 8 * lane), vd = *(const uint2 *)(p_dr + 8 * lane);
+                a.mask2[(int64_t)r * a.row16 + g * 8 + lane] = make_uint4(vi.x, vi.y, ~vd.x, ~vd.y);
             }
-            const uint2 vi = *(const uint2 *)(p_in + 8 * lane), vd = *(const uint2 *)(p_dr + 8 * lane);
-            if (lane < 8 * ntiles)
-                a.mask2[(int64_t)r * a.row16 + wi * (8 * NT) + lane] = make_uint4(vi.x, vi.y, ~vd.x, ~vd.y);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                                   // everybody is done with this read's histogram
         for (int i = threadIdx.x; i < HBINS; i += 256) hist[i] = 0u;
@@ -1638,9 +1616,22 @@ segstat_fn pick_stats_wg(int64_t stride, int nbins, bool pa)
 {
     if (stride <= 4096 || stride > 65536 || sk_tune("SK_SEG_NO_WG")) return nullptr;
     if (!pa && nbins > MAXBINS) return nullptr;
-    const int KW = (int)((stride + 16383) / 16384);
-    if (pa) return KW == 1 ? k_seg_stats_wg<1, true> : KW == 2 ? k_seg_stats_wg<2, true> : KW == 3 ? k_seg_stats_wg<3, true> : k_seg_stats_wg<4, true>;
-    return KW == 1 ? k_seg_stats_wg<1, false> : KW == 2 ? k_seg_stats_wg<2, false> : KW == 3 ? k_seg_stats_wg<3, false> : k_seg_stats_wg<4, false>;
+    // Where it pays (same box, statistics kernel alone, ms; wavefront per read / workgroup per read): int16 rows
+    // 100 000 x 8 192: 0.67 / 0.89; 50 000 x 20 000: 0.69 / 0.78; 25 000 x 36 977: 0.78 / 0.64; 20 000 x 65 535: 1.17 / 0.94;
+    // pA rows 0.70 / 0.95, 0.75 / 0.85, 1.17 / 0.94 at the last three -- one look halves the fetched bytes, but a read's
+    // loads, its barrier and its statistics are a latency chain that three or four resident workgroups per CU hide
+    // worse than sixteen independent wavefronts do.  SK_SEG_WG_ALL=1 takes it for every long row (tests).
+    if (!sk_tune("SK_SEG_WG_ALL") && stride <= (pa ? 49152 : 32768)) return nullptr;
+    const int tiles = (int)((stride + 511) / 512);         // 512-sample tiles, dealt to the four waves
+    const int KT = tiles <= 32 ? 8 : tiles <= 48 ? 12 : tiles <= 64 ? 16 : tiles <= 80 ? 20 : tiles <= 96 ? 24 : 32;
+    switch (KT) {
+    case 8:  return pa ? k_seg_stats_wg<8, true> : k_seg_stats_wg<8, false>;
+    case 12: return pa ? k_seg_stats_wg<12, true> : k_seg_stats_wg<12, false>;
+    case 16: return pa ? k_seg_stats_wg<16, true> : k_seg_stats_wg<16, false>;
+    case 20: return pa ? k_seg_stats_wg<20, true> : k_seg_stats_wg<20, false>;
+    case 24: return pa ? k_seg_stats_wg<24, true> : k_seg_stats_wg<24, false>;
+    default: return pa ? k_seg_stats_wg<32, true> : k_seg_stats_wg<32, false>;
+    }
 }
 
 segstat_fn pick_stats(int64_t stride, int nbins, bool pa)

@@ -53,10 +53,15 @@ def squiggles(R, M, seed, base=0, scale=1.0):
 
 
 @pytest.mark.parametrize("M", [1000, 2048, 4000, 4096, 4100, 16384, 19999, 36977, 50000, 65536, 70000])
-def test_raw_domain_pa_matches_float64_oracle(gpu, ora, M):
+@pytest.mark.parametrize("wg", ["default", "SK_SEG_WG_ALL", "SK_SEG_NO_WG"])
+def test_raw_domain_pa_matches_float64_oracle(gpu, ora, monkeypatch, M, wg):
     """MinION and PromethION channel constants at every kernel shape (2 / 4 / 8 tiles, reads longer than a window),
     ragged lengths: no read takes the redo, every boundary equals the oracle's on the float64 values."""
     from squigglekit_amd import api
+    if wg != "default":
+        if M <= 4096:
+            pytest.skip("the switch concerns rows beyond 4 096 samples")
+        monkeypatch.setenv(wg, "1")                  # statistics kernel: workgroup per read (one look) / wavefront per read
     R = 96 if M > 5000 else 320
     rng = np.random.default_rng(M)
     S = (M + 7) & ~7                                  # (rows as the readers lay them out: a multiple of 8 samples)

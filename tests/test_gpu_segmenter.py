@@ -264,10 +264,11 @@ def test_streaming_path_long_reads(gpu, ora, monkeypatch, M):
     monkeypatch.delenv("SK_SEG_DELTA_SCALE")
     # rows of up to 65 536 samples take the workgroup-per-read statistics kernel (one look, round 6): the
     # wavefront-per-read one (two looks) must give the same records
-    monkeypatch.setenv("SK_SEG_NO_WG", "1")
-    for kw in cases[:2]:
-        _check_vs_oracle(api, ora, sig, lens, kw, "long M=%d, wavefront per read" % M, max_segs=160)
-    monkeypatch.delenv("SK_SEG_NO_WG")
+    for env in ("SK_SEG_NO_WG", "SK_SEG_WG_ALL"):
+        monkeypatch.setenv(env, "1")
+        for kw in cases[:2]:
+            _check_vs_oracle(api, ora, sig, lens, kw, "long M=%d, %s" % (M, env), max_segs=160)
+        monkeypatch.delenv(env)
 
 
 @pytest.mark.parametrize("M", [20000, 70000, 140000])
