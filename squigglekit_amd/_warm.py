@@ -51,6 +51,48 @@ def mark(label):
         sys.stderr.write("[t+%.3f s] %s\n" % (time.time() - float(t0), label))
 
 
+class Stats:
+    """Throughput of a command-line run (SURVEY section 5 "metrics"): reads, GPU calls, wall time, input bytes -> one JSON
+    object in the file --stats-json PATH (or $SK_STATS_JSON) names, and one line on stderr with --stats.  The reference
+    prints nothing of the kind (its loops, segmenter.py:189-230 / MotifSeq.py:261-298, are one read at a time); the
+    side file keeps stdout / stderr byte-identical to the reference's."""
+
+    def __init__(self, tool):
+        import time
+        self.tool, self.reads, self.calls, self.t0 = tool, 0, 0, time.time()
+
+    def batch(self, nreads):
+        self.reads += int(nreads)
+        self.calls += 1
+
+    def finish(self, args, inputs):
+        import json
+        import sys
+        import time
+        path = getattr(args, "stats_json", None) or os.environ.get("SK_STATS_JSON")
+        if not path and not getattr(args, "stats", False):
+            return
+        dt = time.time() - self.t0
+        nbytes = 0
+        for f in inputs:
+            try:
+                nbytes += os.path.getsize(f) if f and os.path.isfile(f) else 0
+            except OSError:
+                pass
+        t_launch = os.environ.get("SK_T0")
+        rec = {"tool": self.tool, "reads": self.reads, "gpu_calls": self.calls,
+               "reads_per_gpu_call": (self.reads / self.calls) if self.calls else None,
+               "seconds_in_main": dt, "reads_per_s": (self.reads / dt) if dt > 0 else None,
+               "input_bytes": nbytes, "input_GB_per_s": (nbytes / dt / 1e9) if dt > 0 else None,
+               "seconds_since_launch": (time.time() - float(t_launch)) if t_launch else None}
+        if path:
+            with open(path, "w") as fh:
+                json.dump(rec, fh)
+        if getattr(args, "stats", False):
+            sys.stderr.write("\n[stats] %s: %d reads in %.3f s = %.0f reads/s, %.2f GB/s in, %d GPU calls\n"
+                             % (self.tool, self.reads, dt, rec["reads_per_s"] or 0, rec["input_GB_per_s"] or 0, self.calls))
+
+
 def fast_exit(code=0):
     """Leave a finished command-line tool at once: flush the text streams, then os._exit.  The interpreter's and the
     HIP runtime's orderly teardown (unloading code objects, destroying the context, unmapping the input) costs

@@ -16,7 +16,7 @@ import sys
 import numpy as np
 
 from . import _lib, api, fastio, tsvio
-from ._warm import mark as _mark
+from ._warm import mark as _mark, Stats as _Stats
 
 _KEEP = []       # input mappings / page-locked buffers of a finished reader: released with the process
 
@@ -73,6 +73,10 @@ def build_parser():
     p.add_argument("--batch", type=int, default=2048, help="[extension] reads per GPU call")
     p.add_argument("--gpus", type=int, default=1,
                    help="[extension] shard every batch of reads over this many GPUs of the node")
+    p.add_argument("--stats-json", dest="stats_json", default=None, metavar="PATH",
+                   help="[extension] write reads / reads per second / input GB per second / GPU calls of this run to PATH "
+                        "as JSON (also $SK_STATS_JSON); stdout and stderr stay the reference's")
+    p.add_argument("--stats", action="store_true", help="[extension] the same as one line on stderr at the end")
     p.add_argument("--strict-compat", action="store_true",
                    help="[extension] keep the reference's -m defect (empty model order: header only)")
     return p
@@ -108,6 +112,9 @@ def load_models(args):
     return {}, [], []
 
 
+_STATS = [_Stats("MotifSeq")]       # this run's throughput counters (--stats-json / --stats)
+
+
 class _Batcher:
     def __init__(self, args, models, order, lens):
         self.args, self.models, self.order, self.lens = args, models, order, lens
@@ -138,6 +145,8 @@ class _Batcher:
             sigs = [np.asarray(s)[c:] for s, c in zip(sigs, cuts)]
             for i, s in zip(live, sigs):
                 self.sigs[i] = s
+        if sigs:
+            _STATS[0].batch(len(sigs))
         hits = (api.motifseq_multi(sigs, [np.asarray(self.models[name], dtype=np.float64) for name in self.order],
                                    a.scale, a.scale_low, a.scale_hi) if sigs else [[] for _ in self.order])
         slot = {i: k for k, i in enumerate(live)}
@@ -287,6 +296,7 @@ class _Batcher:
     def _finish(self, p):
         job, n, fast5_col, id_col, name_of, id_of, sig_of = p
         hits = job.result()
+        _STATS[0].batch(n)
         _mark("block of %d reads back from the GPU" % n)
         if self.table(n, fast5_col, id_col, hits):
             _mark("table written")
@@ -395,6 +405,7 @@ def main(argv=None):
         sys.stderr.write("MotifSeq: -v/--save plotting is not part of this build; ignoring\n")
 
     _mark("main() entered")
+    _STATS[0] = _Stats("MotifSeq")
     del _KEEP[:]                                     # (a previous call in this process: its buffers can go now)
     models, order, lens = load_models(args)
     _mark("models loaded")
@@ -496,6 +507,7 @@ def main(argv=None):
     out.drain()
     out.flush()
     _mark("end of main()")
+    _STATS[0].finish(args, [args.signal, getattr(args, "blow5", None), getattr(args, "i16", None)] + list(getattr(args, "ind", None) or []))
 
 
 if __name__ == "__main__":

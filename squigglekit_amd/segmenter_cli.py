@@ -13,7 +13,7 @@ from struct import error as struct_error
 import numpy as np
 
 from . import api, fastio, tsvio
-from ._warm import mark as _mark
+from ._warm import mark as _mark, Stats as _Stats
 
 _KEEP = []       # input mappings / page-locked buffers of a finished reader: released with the process
 from ._lib import SegParams
@@ -60,7 +60,14 @@ def build_parser():
     p.add_argument("--batch", type=int, default=4096, help="[extension] reads per GPU call")
     p.add_argument("--gpus", type=int, default=1,
                    help="[extension] shard every batch of reads over this many GPUs of the node")
+    p.add_argument("--stats-json", dest="stats_json", default=None, metavar="PATH",
+                   help="[extension] write reads / reads per second / input GB per second / GPU calls of this run to PATH "
+                        "as JSON (also $SK_STATS_JSON); stdout and stderr stay the reference's")
+    p.add_argument("--stats", action="store_true", help="[extension] the same as one line on stderr at the end")
     return p
+
+
+_STATS = [_Stats("segmenter")]      # this run's throughput counters (--stats-json / --stats)
 
 
 class _Batcher:
@@ -101,6 +108,8 @@ class _Batcher:
         if not self.sigs:
             return
         live = [s for s in self.sigs if s is not None]
+        if live:
+            _STATS[0].batch(len(live))
         results = iter(api.segment_any(live, self.params) if live else [])
         for (name, miss), sig in zip(self.names, self.sigs):
             if sig is None:
@@ -166,6 +175,7 @@ class _Batcher:
     def _finish(self, p):
         job, n, name_col, name_of = p
         segs, nsegs = job.result()
+        _STATS[0].batch(n)
         _mark("block of %d reads back from the GPU" % n)
         if self.args.test:
             for i in range(n):
@@ -200,6 +210,7 @@ class _Batcher:
             lens = (np.maximum(ns + Num, 0) if Num < 0 else np.minimum(ns, Num)).astype(np.int32)   # sig[:Num]
             rows = blk.rows[idx] if idx.size != blk.n else blk.rows
             segs, nsegs = api.segment_batch(rows, lens, self.params)
+            _STATS[0].batch(idx.size)
             res = {int(i): k for k, i in enumerate(idx)}
         for i in range(blk.n):
             k = res.get(i)
@@ -232,6 +243,7 @@ def main(argv=None):
         sys.stderr.write("segmenter: -v/--view plotting is not part of this build; ignoring\n")
 
     _mark("main() entered")
+    _STATS[0] = _Stats("segmenter")
     del _KEEP[:]                                     # (a previous call in this process: its buffers can go now)
     if not (args.f5_path or args.ind or args.signal or args.blow5 or args.i16):
         sys.stderr.write("Unknown file or path input")
@@ -354,6 +366,7 @@ def main(argv=None):
     out.drain()
     out.flush()
     _mark("end of main()")
+    _STATS[0].finish(args, [args.signal, args.blow5, args.i16] + list(args.ind or []))
     sys.stderr.write("Done")                        # segmenter.py:297
 
 

@@ -232,6 +232,31 @@ def test_motifseq_cli_harness_cpu(oracle_backend, scrappy_stub, tsv_files):
     check_motifseq(tsv_files)
 
 
+def test_stats_json_side_file_leaves_the_output_alone(oracle_backend, scrappy_stub, tsv_files, tmp_path):
+    """[extension] --stats-json PATH / --stats (SURVEY section 5 "metrics"): reads, reads per second, input GB per second
+    and GPU calls of the run go to a side file / one stderr line; stdout is the reference's, byte for byte."""
+    import json as _json
+    from squigglekit_amd.segmenter_cli import main as seg_main
+    from squigglekit_amd.motifseq_cli import main as mot_main
+    gold = load_golden("segmenter_cli.json.gz")
+    run = [r for r in gold["runs"] if r["tsv"] == "pA_noinfo" and r["flags"] == []][0]
+    js = str(tmp_path / "seg.json")
+    so, se, code = run_cli(seg_main, ["-s", tsv_files["pA_noinfo"], "--stats-json", js, "--stats"])
+    assert so == run["stdout"] and code == run["exit"]
+    assert se.startswith(run["stderr"][:-4] if run["stderr"].endswith("Done") else run["stderr"][:10]) and "[stats] segmenter:" in se
+    rec = _json.load(open(js))
+    assert rec["tool"] == "segmenter" and rec["reads"] >= 1 and rec["gpu_calls"] >= 1 and rec["reads_per_s"] > 0
+    assert rec["input_bytes"] == os.path.getsize(tsv_files["pA_noinfo"])
+    gm = load_golden("motifseq_cli.json.gz")
+    mrun = [r for r in gm["runs"] if r["tsv"] == "real_raw" and r["flags"] == ["-l", "medmad"]][0]
+    jm = str(tmp_path / "mot.json")
+    model = os.path.join(GOLD, "CATCTATCCAGGGTTAAATT.model")
+    so, se, code = run_cli(mot_main, ["-s", tsv_files["m_real_raw"], "-m", model, "-l", "medmad", "--stats-json", jm])
+    rec = _json.load(open(jm))
+    assert rec["tool"] == "MotifSeq" and rec["reads"] == 1 and rec["gpu_calls"] == 1 and "[stats]" not in se
+    assert so.strip().split("\n")[1].split("\t")[3:5] == mrun["stdout"].strip().split("\n")[1].split("\t")[3:5]
+
+
 @pytest.mark.gpu
 def test_segmenter_cli_gpu(gpu, tsv_files):
     check_segmenter(tsv_files)
