@@ -13,7 +13,8 @@ import time
 import numpy as np
 
 from bench_common import (HBM_PEAK_GBS, HIT_BYTES, MAX_SEGS, ROOT, WAVE_ISSUE_SLOTS, download_rows, strided_rows,
-                          workload_name)
+                          workload_name,
+                          counters_from_profiles, roof_with_counters)
 
 
 def cli_block(a, L, main):
@@ -369,6 +370,10 @@ def other_paths_block(a, L, main):
                     "roofline": {"bound": "hbm", "achieved": alg_ / secs_ / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": alg_ / secs_ / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg_,
                                  "bytes_note": "2 B per sample resident (the float64 route: 8)",
+                                 "statistics_kernel_valu_issue_frac": counters_from_profiles(
+                                     "k_seg_stats<8, 8, 8, true, true" if stride_ > 4096 else "k_seg_stats<8, 8, 8, false, true")["valu_issue_frac"],
+                                 "walk_kernel_valu_issue_frac": counters_from_profiles("k_seg_walkL" if stride_ > 4096 else "k_seg_walk4<6, true")["valu_issue_frac"],
+                                 "counters_source": "profiles/sq1_other_paths.json",
                                  "statistics_kernel_frac": (alg_ / (ev_[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ev_[0] > 0 else None},
                     "parity": {"reads_checked": int(R_), "all_records_equal_float64_route": same,
                                "float64_route_vs_oracle": "sampled above"}}
@@ -444,7 +449,10 @@ def other_paths_block(a, L, main):
                 "roofline": {"bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
                              "prep_kernel_frac": (alg / (ev[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ev[0] > 0 else None,
-                             "valu": dtw_view(RL, cells, secs)},
+                             "valu": dtw_view(RL, cells, secs),
+                             "screening_pass_valu_issue_frac": counters_from_profiles(
+                                 "k_sdtw_q<8, 21, 1" if RL >= 49152 else "k_sdtw_q<16, 11, 1")["valu_issue_frac"],
+                             "counters_source": "profiles/sq1_other_paths.json"},
                 "parity": {"reads_checked": int(len(rows_m)),
                            "dist_bit_identical": bool(all(got_m["dist"][k] == w[0] for k, w in enumerate(want_m))),
                            "start_end_exact": bool(all((got_m["start"][k], got_m["end"][k]) == (w[1], w[2])
@@ -498,9 +506,8 @@ def other_paths_block(a, L, main):
                         "device resident" % (RD, int(lens_d.mean())),
             "value": RD / secs, "unit": "reads/s", "ms_per_step": secs * 1e3,
             "kernel_ms": {"statistics": ev[0], "scan": ev[1]},
-            "roofline": {"bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "kernels_only_frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_step": alg},
+            "roofline": dict(roof_with_counters(alg, secs, ev[0], "k_drna_stats"),
+                             kernels_only_frac=alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS),
             "parity": {"reads_checked": int(len(rows_d)), "segments_bit_exact": bool(ok1)}}
         secs, ev = best_of(lambda: check(L.sk_drna_roll_dev_i16(d_sig_d, MD, d_len_d, RD, C.byref(rp), d_xy, d_found)))
         xy = np.zeros((RD, 2), dtype=np.int32)
@@ -522,9 +529,8 @@ def other_paths_block(a, L, main):
                         % (RD, int(lens_d.mean())),
             "value": RD / secs, "unit": "reads/s", "ms_per_step": secs * 1e3,
             "kernel_ms": {"filter_prefix_sums_statistics": ev[0], "scan": ev[1]},
-            "roofline": {"bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "kernels_only_frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_step": alg},
+            "roofline": dict(roof_with_counters(alg, secs, ev[0], "k_roll_stream"),
+                             kernels_only_frac=alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS),
             "parity": {"reads_checked": int(len(rows_d)), "pairs_exact": bool(ok2), "found_in_sample": int(found[rows_d].sum())}}
         del host_b
         for q in (d_sig_d, d_len_d, d_dsegs, d_dn, d_xy, d_found):
