@@ -157,6 +157,73 @@ def main():
         os.environ.pop("SK_F64_OLD", None)
         os.environ.pop("SK_F64_LONG_LOOKS", None)
         os.environ.pop("SK_SEG_DELTA_SCALE", None)
+        # ---- round 6: raw rows through the pA conversion in the RAW domain (k_seg_stats<.., PA> / k_seg_stats_wg), the
+        # wavefront-per-read walk, centi-unit batches -- against the oracle on the float64 values numpy makes the reference's way
+        # (segmenter.py:345-349, :385) ----
+        if rounds % 2 == 1:
+            Rp = int(rng.choice([1, 5, 64, 200]))
+            Mp = int(rng.choice([8, 512, 4000, 4096, 4104, 9000, 16384, 20000, 33000, 50000, 66000]))
+            Sp = (Mp + 7) // 8 * 8
+            praw = synth.squiggle_batch(Rp, Sp, int(rng.integers(1 << 30)))
+            kind = int(rng.integers(5))
+            if kind == 1:                                         # PromethION-like: raw window starts high
+                praw = np.clip(np.rint(praw * 0.6 + 237), -32768, 32767).astype(np.int16)
+            elif kind == 2 and Mp >= 512:
+                praw = synth.pattern_reads(rng, Rp, Sp)
+            elif kind == 3:                                       # spikes: kept ones above the window, dropped ones, negatives
+                k2 = int(rng.integers(1, 60))
+                praw[rng.integers(0, Rp, k2), rng.integers(0, Sp, k2)] = rng.choice([2500, 3000, 6000, 32767, -5, -300], k2)
+            plens = rng.integers(0, Mp + 1, Rp).astype(np.int32)
+            plens[rng.integers(0, Rp)] = Mp
+            cal = np.empty((Rp, 3))
+            cal[:, 0] = rng.choice([8192.0, 2048.0, 4096.0], Rp)
+            cal[:, 1] = np.round(rng.uniform(-250, 40, Rp), 1) if kind == 1 else np.round(rng.uniform(-40, 40, Rp), 1)
+            cal[:, 2] = rng.uniform(600, 1600, Rp)
+            if rng.random() < 0.2:
+                cal[rng.integers(0, Rp)] = [[8192.0, 16.0, 8192.0 * 5], [8192.0, 16.0, -1493.94], [8192.0, np.nan, 1493.94],
+                                            [8192.0, 16.0, 8192.0 * 0.012]][int(rng.integers(4))]
+            pkw = [dict(), dict(lim_low=60, lim_hi=140), dict(std_scale=0.3), dict(window=40, error=2), dict(error=40, corrector=10),
+                   dict(lim_low=-50, lim_hi=2000), dict(std_scale=2.5, stall_len=0.9)][int(rng.integers(7))]
+            for key, val in (("SK_SEG_DELTA_SCALE", "1e13" if rng.random() < 0.15 else None),
+                             ("SK_WALK_NOWAVE", "1" if rng.random() < 0.3 else None),
+                             ("SK_SEG_WG_ALL", "1" if rng.random() < 0.4 else None),
+                             ("SK_SEG_NO_WG", "1" if rng.random() < 0.2 else None)):
+                if val is None:
+                    os.environ.pop(key, None)
+                else:
+                    os.environ[key] = val
+            pp = SegParams(**pkw)
+            psegs, pn = api.segment_batch_pa(praw, plens, cal, pp)
+            opp = ora.SegParams(**{a: b for a, b in pkw.items() if a not in ("lim_low", "lim_hi")})
+            for r in range(Rp):
+                unit = float("{0:.2f}".format(cal[r, 2])) / cal[r, 0]
+                pa = np.round((praw[r, :plens[r]].astype(np.int64) + cal[r, 1]) * unit, 2)
+                f = ora.scale_outliers(pa, pp.lim_low, pp.lim_hi)
+                w = (ora.get_segs(f, opp) or []) if f.size else []
+                if psegs[r, :pn[r]].tolist() != w:
+                    bad += 1
+                    print("PA mismatch R=%d M=%d kind %d read %d cal %s %s env %s" % (Rp, Mp, kind, r, cal[r].tolist(), pkw,
+                          {k: os.environ.get(k) for k in ("SK_SEG_DELTA_SCALE", "SK_WALK_NOWAVE", "SK_SEG_WG_ALL", "SK_SEG_NO_WG")}))
+                    break
+            # the same rows as --raw_signal input (int16 route) through the same kernel choices
+            if Mp <= 50000:
+                isegs, inn = api.segment_batch(praw, plens, SegParams(**{a: b for a, b in pkw.items() if a not in ("lim_low", "lim_hi")}), max_segs=64)
+                osegs2, onn2 = ora.segment_batch_i16(praw, plens, opp, lo=0, hi=900, max_segs=isegs.shape[1])
+                if not np.array_equal(inn, onn2) or any(not np.array_equal(isegs[r, :inn[r]], osegs2[r, :inn[r]]) for r in range(Rp)):
+                    bad += 1
+                    print("LONG I16 SEGMENTER mismatch R=%d M=%d kind %d %s" % (Rp, Mp, kind, pkw))
+            for key in ("SK_SEG_DELTA_SCALE", "SK_WALK_NOWAVE", "SK_SEG_WG_ALL", "SK_SEG_NO_WG"):
+                os.environ.pop(key, None)
+            # centi-unit batch == float64 batch of the same tokens (both tools)
+            cn = [rng.integers(-2000, 120000, int(rng.choice([1, 50, 3000, 4097]))).astype(np.int32) for _ in range(int(rng.choice([1, 7, 40])))]
+            cflat = np.concatenate(cn)
+            coff = np.concatenate([[0], np.cumsum([c.size for c in cn])]).astype(np.int64)
+            ca, cb = api.segment_ragged_f64(cflat, coff), api.segment_ragged_f64(cflat / 100.0, coff)
+            cm = synth.synthetic_motif(int(rng.choice([5, 60])), seed=3)
+            ha, hb = api.motifseq_multi_ragged_f64(cflat, coff, [cm]), api.motifseq_multi_ragged_f64(cflat / 100.0, coff, [cm])
+            if not (np.array_equal(ca[0], cb[0]) and np.array_equal(ca[1], cb[1]) and ha[0].tobytes() == hb[0].tobytes()):
+                bad += 1
+                print("CENTI mismatch: %d reads" % len(cn))
         # ---- dRNA_segmenter: both branches on a few long ragged reads ----
         if rounds % 2 == 0:
             from squigglekit_amd._lib import DrnaParams, RollParams
