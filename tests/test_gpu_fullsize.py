@@ -151,3 +151,34 @@ def test_f64_route_full_size_250k_pa_reads(gpu, ora):
     finally:
         for q in bufs:
             L.sk_dev_free(q)
+
+
+def test_pa_route_long_reads_full_length(gpu, ora):  # noqa: D401
+    """fast5 / BLOW5-shaped input at the length of the read the reference ships (example/slow5/0.blow5: 36 978 samples):
+    6 000 raw rows + channel constants through the raw-domain pA route (k_seg_stats<.., PA> + k_seg_walkL, round 6) --
+    every record equal to the float64 route's (SK_SEG_PA_F64: the float64 image on the device, then the float64 kernels),
+    and a strided sample against the oracle on the float64 values numpy makes the reference's way (segmenter.py:345-349)."""
+    import os
+    from conftest import strided_rows
+    from squigglekit_amd import api, synth
+    R, M = 6000, 36977
+    S = (M + 7) // 8 * 8
+    raw = synth.squiggle_batch(R, S, 20260929)
+    rng = np.random.default_rng(9)
+    lens = rng.integers(M // 2, M + 1, R).astype(np.int32)
+    lens[:3] = [M, M - 1, 4097]
+    calib = np.empty((R, 3))
+    calib[:, 0], calib[:, 1], calib[:, 2] = 8192.0, np.round(rng.uniform(0, 30, R), 0), rng.uniform(1400, 1500, R)
+    segs, nsegs = api.segment_batch_pa(raw, lens, calib, max_segs=128)
+    assert api.last_pa_retries() == 0
+    os.environ["SK_SEG_PA_F64"] = "1"
+    try:
+        fsegs, fn = api.segment_batch_pa(raw, lens, calib, max_segs=128)
+        assert api.last_pa_retries() == -1
+    finally:
+        del os.environ["SK_SEG_PA_F64"]
+    assert np.array_equal(nsegs, fn) and np.array_equal(segs, fsegs) and int(nsegs.sum()) > R
+    for r in strided_rows(R, 48):
+        unit = float("{0:.2f}".format(calib[r, 2])) / calib[r, 0]
+        pa = np.round((raw[r, :lens[r]].astype(np.int64) + calib[r, 1]) * unit, 2)
+        assert segs[r, :nsegs[r]].tolist() == (ora.get_segs(ora.scale_outliers(pa, 0, 900)) or []), r
