@@ -278,6 +278,7 @@ PY_TUNABLES = {
     "SK_BLOW5_ZAP": ("0", "BLOW5 reader: keep the consumed pages of the file map"),
     "SK_I16_PIN": ("1", "--i16 reader: page-locked streaming buffers"),
     "SK_I16_BLOCK_MB": ("1 8", "--i16 reader: block size in MB"),
+    "SK_TSV_THREADS": ("4 64", "TSV reader: worker threads of the native tokenizer (default 32)"),
     "SK_TSV_NO_CENTI": ("1", "TSV reader: decimal lines through the float64 tokenizer even when every token has at most two decimals"),
 }
 

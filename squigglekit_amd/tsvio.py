@@ -13,6 +13,17 @@ import math
 import numpy as np
 
 
+def _default_threads():
+    """worker threads of the native tokenizer: 32, never more than the host has (SK_TSV_THREADS under SK_TUNING=1:
+    measurement runs -- 16 / 32 / 64 / 128 threads on the 256-thread bench host: 349 k / 392 k / 328 k / 245 k reads/s for
+    400 000 integer reads through segmenter.py, 210 k / 225 k / 207 k / 154 k for 200 000 pA reads: the threads are
+    created per chunk, and beyond 32 that costs more than the parallelism returns)"""
+    import os
+    from . import _lib
+    want = int(_lib.tune("SK_TSV_THREADS", 32))
+    return max(1, min(want, os.cpu_count() or 1))
+
+
 def open_text(path):
     """Plain or gzip text (the reference's dicSwitch, segmenter.py:300-308; its
     segmenter is broken on .gz under Python 3 -- here .gz simply works)."""
@@ -147,7 +158,7 @@ def iter_tsv_native(path, start_col, chunk_bytes=64 << 20, nthreads=None):
                caller to re-parse it the reference's way.
     No GPU is involved; the library only has to be loadable."""
     import os
-    nthreads = nthreads or min(32, os.cpu_count() or 1)
+    nthreads = nthreads or _default_threads()
     for chunk in _line_blocks(path, chunk_bytes):
         yield from _parse_block_float(chunk, start_col, nthreads)
 
@@ -241,12 +252,12 @@ class TsvBlock:
 
     def float_lines(self, start_col, nthreads=None):
         import os
-        return _parse_block_float((self.buf, self.base, self.end), start_col, nthreads or min(32, os.cpu_count() or 1))
+        return _parse_block_float((self.buf, self.base, self.end), start_col, nthreads or _default_threads())
 
     def float_block(self, start_col, nthreads=None):
         """The chunk through the float64 tokenizer as ONE FloatBlock (flat values + offsets), or None."""
         import os
-        return parse_block_float((self.buf, self.base, self.end), start_col, nthreads or min(32, os.cpu_count() or 1))
+        return parse_block_float((self.buf, self.base, self.end), start_col, nthreads or _default_threads())
 
 
 def _parse_chunk_i16(chunk, start_col, nthreads):
@@ -287,7 +298,7 @@ def iter_tsv_blocks_i16(path, start_col, chunk_bytes=48 << 20, nthreads=None, pr
     import os
     from . import _lib
     L = _lib.load()
-    nthreads = nthreads or min(32, os.cpu_count() or 1)
+    nthreads = nthreads or _default_threads()
     for chunk in _line_blocks(path, chunk_bytes):
         blk = _parse_chunk_i16(chunk, start_col, nthreads)
         if blk is not None:
@@ -311,7 +322,7 @@ def iter_tsv_blocks(path, start_col, chunk_bytes=48 << 20, nthreads=None, prefet
         yield from _prefetched(iter_tsv_blocks(path, start_col, chunk_bytes, nthreads, prefetch=False))
         return
     import os
-    nthreads = nthreads or min(32, os.cpu_count() or 1)
+    nthreads = nthreads or _default_threads()
     for chunk in _line_blocks(path, chunk_bytes):
         src, start, end = chunk
         if _first_token_has_dot(src, start, end, start_col):
