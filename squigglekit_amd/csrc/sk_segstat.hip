@@ -1385,7 +1385,7 @@ void k_seg_walk4(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
 // walked by lane 0 alone, sequentially.  Rows of up to 1 024 entries are staged in LDS with coalesced 16-byte loads.
 constexpr int WL_NB = 8;               // long runs noted per lane
 
-template <int E1C>
+template <int E1C, bool STAGED>        // STAGED: the row fits the LDS staging area (rows of up to lds_entries mask entries)
 __global__ __launch_bounds__(64)
 void k_seg_walkL(const uint4 *__restrict__ mask2, int row16, const int32_t *__restrict__ len, int64_t stride,
                  int nreads, WalkParams p, int32_t *__restrict__ segs, int32_t *__restrict__ nsegs, int max_segs,
@@ -1401,14 +1401,14 @@ void k_seg_walkL(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
     const int E1 = E1C ? E1C : max(p.error, 0) + 1;
     const int nent = (M + 63) >> 6;
     if (nent == 0) { if (lane == 0) nsegs[r] = 0; return; }
-    const bool staged = nent <= lds_entries;
-    if (staged) {
+    if constexpr (STAGED) {
         for (int k = lane; k < nent; k += 64) wl_lds[k] = mrow[k];
         __syncthreads();                                       // (one wavefront: orders the LDS writes before the reads)
     }
     auto entry = [&](int k) __attribute__((always_inline)) -> uint4 {
         if (k < 0 || k >= nent) return make_uint4(0u, 0u, 0u, 0u);
-        return staged ? wl_lds[k] : mrow[k];
+        if constexpr (STAGED) return wl_lds[k];
+        else return mrow[k];
     };
 
     // ---- my piece: samples dropped in it, its first anchor ----
@@ -1462,17 +1462,13 @@ void k_seg_walkL(const uint4 *__restrict__ mask2, int row16, const int32_t *__re
         if (!act) continue;
         const int e = pos >> 6;
         if (e != ce) {                                         // the two entries my window lies in
-            if (e == ce + 1) { dcur += 64 - __builtin_popcountll(Oc | Zc); Oc = On; Zc = Zn; }
+            // (a position never advances by more than 64 samples: after the first visit the new entry is the next one)
+            if (ce != -2) { dcur += 64 - __builtin_popcountll(Oc | Zc); Oc = On; Zc = Zn; }
             else {
                 const uint4 v = entry(e);
                 Oc = ((unsigned long long)(v.y & v.w) << 32) | (v.x & v.z);
                 Zc = ((unsigned long long)(~v.y & v.w) << 32) | (~v.x & v.z);
-                // samples dropped before entry e: my piece's base + the entries between the anchor's and this one
-                if (ce == -2) dcur = jump_d;
-                else for (int k = ce + 1; k <= e; k++) {       // (a window step of 64 can skip an entry boundary pair)
-                    const uint4 u = entry(k - 1);
-                    dcur += 64 - __builtin_popcount(u.z) - __builtin_popcount(u.w);
-                }
+                dcur = jump_d;                                 // samples dropped before the anchor's entry
             }
             const uint4 v = entry(e + 1);
             On = ((unsigned long long)(v.y & v.w) << 32) | (v.x & v.z);
@@ -1571,9 +1567,12 @@ void launch_walk(hipStream_t ws, const uint4 *mask2, int row16, const int32_t *l
     if (const char *e = sk_tune("SK_WALK_WAVE_MAXREADS")) long_max = atoi(e);
     if (fast && by_runs && wp.error < 32 && (row16 > 64 || nr <= long_max) && nr > 0 &&
         sk_tune("SK_WALK_NOWAVE") == nullptr && sk_tune("SK_WALK_SYNC") == nullptr) {
-        const int lds_entries = row16 < 1024 ? row16 : 1024;
+        // rows of up to 1 024 entries are staged in LDS; longer rows (only some of whose reads may fit) read global memory
+        const bool staged = row16 <= 1024;
+        const int lds_entries = staged ? row16 : 0;
         const size_t lds = (size_t)lds_entries * 16 + (size_t)WL_NB * 64 * sizeof(int2);
-        auto fn = wp.error == 5 ? k_seg_walkL<6> : k_seg_walkL<0>;
+        auto fn = wp.error == 5 ? (staged ? k_seg_walkL<6, true> : k_seg_walkL<6, false>)
+                                : (staged ? k_seg_walkL<0, true> : k_seg_walkL<0, false>);
         hipLaunchKernelGGL(fn, dim3(nr), dim3(64), lds, ws, mask2, row16, len, stride, nr, wp, d_segs, d_nsegs, max_segs,
                            lds_entries);
         return;
