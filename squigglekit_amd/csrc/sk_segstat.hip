@@ -241,13 +241,23 @@ void k_seg_stats(const SegStatArgs a)
     for (int j = 0; j < NQ; j++) *(uint4 *)(hist + hb0 + 4 * j) = make_uint4(0u, 0u, 0u, 0u);
 
     unsigned y[NT][4];                                     // one window of the read: packed samples, then their t'
+    // LONG (round 6): a second window.  The second look walks the read backwards and finds the t' of its last two windows
+    // still in registers -- 8 192 of a 20 000-sample read's samples are not fetched a second time (the kernel sits at the
+    // HBM ceiling because of that second look: profiles/r06_pa_long_counters.txt); 32 more VGPRs, same four waves per SIMD
+    // (the LDS histograms hold it there anyway).
+    unsigned y2[NT][4];                                    // (unused, and dropped by the compiler, when !LONG or KEEP == 1)
+    // KEEP windows stay in registers between the looks: 2 on the int16 route (statistics kernel of 50 000 x 20 000 samples
+    // 0.69 -> 0.54 ms, of 100 000 x 8 192 -- both windows kept, one look -- 0.67 -> 0.40); none on the pA route, whose
+    // statistics need ~80 registers of their own: one kept window is 144 VGPRs (three waves per SIMD: 0.70 -> 0.77 ms at
+    // 20 000 samples, 0.74 -> 0.67 at 37 000), two spill.
+    constexpr int KEEP = PA ? 0 : 2;
     // the window's samples into registers: NT x 16-byte loads per lane, all in flight at once
-    auto load_window = [&](const int16_t *wrow, int Mw) {
+    auto load_window = [&](unsigned (&yy)[NT][4], const int16_t *wrow, int Mw) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             uint4 q = make_uint4(0u, 0u, 0u, 0u);
             if (t * 512 + lane * 8 < Mw) q = *(const uint4 *)(wrow + t * 512 + lane * 8);   // (rows are 16-byte aligned)
-            y[t][0] = q.x; y[t][1] = q.y; y[t][2] = q.z; y[t][3] = q.w;
+            yy[t][0] = q.x; yy[t][1] = q.y; yy[t][2] = q.z; yy[t][3] = q.w;
         }
     };
     // t' of one packed pair; the read's last tile also sends the slots past its end to the dump bin
@@ -310,10 +320,10 @@ void k_seg_stats(const SegStatArgs a)
         // ---- first look: t' per sample, exact sums, histogram -------------------------------------------------
         long long S = 0, Q = 0;
         unsigned mxp = 0x80008000u;                        // PA: running maximum of the raw samples (packed halves)
-        for (int wi = 0; wi < nwin; wi++) {
+        auto first_window = [&](unsigned (&yy)[NT][4], int wi) __attribute__((always_inline)) {
             const int Mw = min(M - wi * WIN, WIN);
             const int ntiles = (Mw + 511) >> 9;
-            load_window(row + (int64_t)wi * WIN, Mw);
+            load_window(yy, row + (int64_t)wi * WIN, Mw);
             int st = 0, stt = 0;
 #pragma unroll
             for (int t = 0; t < NT; t++) {
@@ -322,15 +332,15 @@ void k_seg_stats(const SegStatArgs a)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if constexpr (PA) {                    // a kept value above the histogram window? (the maximum tells)
-                        unsigned qm = y[t][k];
+                        unsigned qm = yy[t][k];
                         if (t == ntiles - 1) {
                             const unsigned tail = nvalid >= 2 * k + 2 ? 0xffffffffu : (nvalid == 2 * k + 1 ? 0xffffu : 0u);
                             qm = (qm & tail) | (0x80008000u & ~tail);
                         }
                         mxp = pk_max_i16(mxp, qm);
                     }
-                    const unsigned tt = image(y[t][k], t, k, ntiles, nvalid);
-                    y[t][k] = tt;
+                    const unsigned tt = image(yy[t][k], t, k, ntiles, nvalid);
+                    yy[t][k] = tt;
                     const s16x2 ts = __builtin_bit_cast(s16x2, tt);
                     if constexpr (!PA) {
                     st = __builtin_amdgcn_sdot2(ts, __builtin_bit_cast(s16x2, 0x10001u), st, false);
@@ -348,7 +358,17 @@ void k_seg_stats(const SegStatArgs a)
             S += (long long)wave_sum(st);
             Q += (long long)wave_sum(stt & 0xffff) + ((long long)wave_sum((int)((unsigned)stt >> 16)) << 16);
             }
-        }
+        
+        };
+        if constexpr (LONG) {
+            // (three call sites instead of a choice inside the loop: with `wi == nwin - 2 ? y2 : y` in the loop body the
+            // compiler kept both buffers and both sets of loads live across it -- 257 VGPRs)
+            // KEEP: windows whose t' stay in registers for the second look.  The pA variant's statistics need ~80 registers
+            // of their own: with two windows kept it spills them (107 VGPRs), with one it fits 128
+            for (int wi = 0; wi < nwin - KEEP; wi++) first_window(y, wi);
+            if constexpr (KEEP == 2) { if (nwin >= 2) first_window(y2, nwin - 2); }
+            if constexpr (KEEP >= 1) { if (nwin >= 1) first_window(y, nwin - 1); }
+        } else first_window(y, 0);
 
         // ---- exact integer totals (dump-bin entries taken out) ------------------------------------------------
         const long long D = (long long)__builtin_amdgcn_readfirstlane((int)hist[nbins]);   // dropped samples + slots past the end
@@ -480,17 +500,20 @@ void k_seg_stats(const SegStatArgs a)
         // per lane (1 KB contiguous).
         const unsigned tlop = (unsigned)__builtin_amdgcn_readfirstlane(tlo) * 0x10001u;
         const unsigned wm1p = (unsigned)((__builtin_amdgcn_readfirstlane(width) - 1) & 0xffff) * 0x10001u;
-        for (int wi = 0; wi < nwin; wi++) {
+        // LONG: backwards -- the last window (in y) and the one before it (in y2) are classified out of the registers, the
+        // others are fetched again
+        uint2 vi = make_uint2(0u, 0u), vd = make_uint2(0u, 0u);
+        auto classify_window = [&](unsigned (&yy)[NT][4], int wi, bool reload) __attribute__((always_inline)) {
             const int Mw = min(M - wi * WIN, WIN);
             const int ntiles = (Mw + 511) >> 9;
-            if (LONG) {                                    // (one window: the t' are still in the registers)
-                load_window(row + (int64_t)wi * WIN, Mw);
+            if (reload) {
+                load_window(yy, row + (int64_t)wi * WIN, Mw);
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
                     if (t >= ntiles) continue;
                     const int nvalid = min(max(Mw - (t * 512 + lane * 8), 0), 8);
 #pragma unroll
-                    for (int k = 0; k < 4; k++) y[t][k] = image(y[t][k], t, k, ntiles, nvalid);
+                    for (int k = 0; k < 4; k++) yy[t][k] = image(yy[t][k], t, k, ntiles, nvalid);
                 }
             }
 #pragma unroll
@@ -500,17 +523,24 @@ void k_seg_stats(const SegStatArgs a)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const unsigned wts = (1u << (2 * k)) | (2u << (2 * k + 16));
-                    drop8 = udot2(pk_subsat_u16(y[t][k], nbm1p), wts, drop8);                    // t' - (nbins - 1) is 0 or 1
-                    const unsigned over = pk_subsat_u16(pk_sub_u16(y[t][k], tlop), wm1p);        // > 0: outside the band
+                    drop8 = udot2(pk_subsat_u16(yy[t][k], nbm1p), wts, drop8);                   // t' - (nbins - 1) is 0 or 1
+                    const unsigned over = pk_subsat_u16(pk_sub_u16(yy[t][k], tlop), wm1p);       // > 0: outside the band
                     out8 = udot2(pk_min1_u16(over), wts, out8);
                 }
                 p_in[t * 64 + lane] = (unsigned char)((width > 0) ? ~out8 : 0u);
                 p_dr[t * 64 + lane] = (unsigned char)drop8;
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const uint2 vi = *(const uint2 *)(p_in + 8 * lane), vd = *(const uint2 *)(p_dr + 8 * lane);
+            vi = *(const uint2 *)(p_in + 8 * lane); vd = *(const uint2 *)(p_dr + 8 * lane);
             if (lane < 8 * ntiles)
                 a.mask2[(int64_t)r * a.row16 + wi * (8 * NT) + lane] = make_uint4(vi.x, vi.y, ~vd.x, ~vd.y);   // {in band, kept}
+        };
+        {
+            if constexpr (LONG) {
+                if constexpr (KEEP >= 1) { if (nwin >= 1) classify_window(y, nwin - 1, false); }
+                if constexpr (KEEP == 2) { if (nwin >= 2) classify_window(y2, nwin - 2, false); }
+                for (int wi = nwin - 1 - KEEP; wi >= 0; wi--) classify_window(y, wi, true);
+            } else classify_window(y, 0, false);
             if (!LONG && a.hints) {
                 // What k_seg_walk4 would otherwise read the whole mask row for (see there): lane e holds entry e, so
                 // the stretches of quiet entries, their anchors and the drop counts are a few wave-wide operations.
@@ -1616,7 +1646,8 @@ segstat_fn pick_stats_wg(int64_t stride, int nbins, bool pa)
     if (stride <= 4096 || stride > 65536 || sk_tune("SK_SEG_NO_WG")) return nullptr;
     if (!pa && nbins > MAXBINS) return nullptr;
     // Where it pays (same box, statistics kernel alone, ms; wavefront per read / workgroup per read): int16 rows
-    // 100 000 x 8 192: 0.67 / 0.89; 50 000 x 20 000: 0.69 / 0.78; 25 000 x 36 977: 0.78 / 0.64; 20 000 x 65 535: 1.17 / 0.94;
+    // 100 000 x 8 192: 0.67 / 0.89; 50 000 x 20 000: 0.69 / 0.78; 25 000 x 36 977: 0.78 / 0.64; 20 000 x 65 535: 1.17 / 0.94
+    // (with the wavefront kernel keeping its last two windows in registers, later in round 6: 0.40, 0.54, 0.65, 0.99);
     // pA rows 0.70 / 0.95, 0.75 / 0.85, 1.17 / 0.94 at the last three -- one look halves the fetched bytes, but a read's
     // loads, its barrier and its statistics are a latency chain that three or four resident workgroups per CU hide
     // worse than sixteen independent wavefronts do.  SK_SEG_WG_ALL=1 takes it for every long row (tests).
@@ -1645,7 +1676,7 @@ segstat_fn pick_stats(int64_t stride, int nbins, bool pa)
     }
     if (NT <= 2) return small ? k_seg_stats<2, 4, 8, false> : k_seg_stats<2, 8, 8, false>;
     if (NT <= 4) return small ? k_seg_stats<4, 4, 8, false> : k_seg_stats<4, 8, 8, false>;
-    if (NT > 8) return small ? k_seg_stats<8, 4, 6, true> : k_seg_stats<8, 8, 8, true>;
+    if (NT > 8) return small ? k_seg_stats<8, 4, 4, true> : k_seg_stats<8, 8, 8, true>;   // (two kept windows: 126 VGPRs)
     if (small) {
         if (const char *e = sk_tune("SK_SEG_OCC")) {         // tuning: registers per lane vs reads in flight
             const int v = atoi(e);
