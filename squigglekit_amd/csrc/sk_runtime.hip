@@ -99,7 +99,7 @@ static const sk_tunable SK_TUNABLES[] = {
     {"SK_WALK_OWNPASS",       "1",           "segmenter walk: finds the quiet stretches and anchors in a pass of its own instead of taking the statistics kernel's hints"},
     {"SK_WALK_NOJUMP",        "1",           "segmenter walk: every run is hopped through, no jumps between the stretches of quiet entries"},
     {"SK_WALK_NOWAVE",        "1",           "segmenter walk: a lane per read also for long rows / small batches (no wavefront-per-read walk)"},
-    {"SK_WALK_WAVE_MAXREADS", "0 1000000",   "segmenter walk: batches of up to this many reads take the wavefront-per-read walk whatever the row length (default 24576)"},
+    {"SK_WALK_WAVE_MAXREADS", "0 1000000",   "segmenter walk: batches of up to this many reads take the wavefront-per-read walk (default: 16384, 131072 for rows beyond 4 096 samples)"},
     {"SK_DRNA_STEP",          "1",           "dRNA_segmenter, both branches: the per-sample scans instead of the scans by runs / by transitions"},
     {"SK_ROLL_TWO_KERNELS",   "1",           "dRNA_segmenter rolling-mean branch: filter kernel + prefix sums through HBM instead of the one-look kernel (prefix sums in LDS)"},
     {"SK_ROLL_ONE_LOOK",      "1",           "dRNA_segmenter rolling-mean branch: the workgroup-per-read kernel in numpy's order for every read instead of the streaming kernel with certified thresholds"},

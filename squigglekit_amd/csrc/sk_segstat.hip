@@ -1593,9 +1593,13 @@ void launch_walk(hipStream_t ws, const uint4 *mask2, int row16, const int32_t *l
 {
     const int wgrid = (nr + 63) / 64;
     // long rows, or too few reads to fill the chip with a lane each: a wavefront per read (k_seg_walkL)
-    int long_max = 24576;
+    // (measured crossovers against the lane-per-read walk, same box: rows of 4 000 samples between 10 000 and 25 000
+    // reads -- 0.039 / 0.055 ms at 10 000, 0.076 / 0.057 at 25 000 --, rows of 20 000 samples near 200 000 reads -- 0.35 / 0.76
+    // at 50 000, 1.29 / 1.23 at 200 000, 2.54 / 1.96 at 400 000: the wave-per-read walk is bound by vector issue and grows
+    // with the batch, the lane-per-read one by one lane's latency chain and barely does)
+    int long_max = row16 > 64 ? 131072 : 16384;
     if (const char *e = sk_tune("SK_WALK_WAVE_MAXREADS")) long_max = atoi(e);
-    if (fast && by_runs && wp.error < 32 && (row16 > 64 || nr <= long_max) && nr > 0 &&
+    if (fast && by_runs && wp.error < 32 && nr <= long_max && nr > 0 &&
         sk_tune("SK_WALK_NOWAVE") == nullptr && sk_tune("SK_WALK_SYNC") == nullptr) {
         // rows of up to 1 024 entries are staged in LDS; longer rows (only some of whose reads may fit) read global memory
         const bool staged = row16 <= 1024;
