@@ -451,7 +451,7 @@ def other_paths_block(a, L, main):
                              "prep_kernel_frac": (alg / (ev[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ev[0] > 0 else None,
                              "valu": dtw_view(RL, cells, secs),
                              "screening_pass_valu_issue_frac": counters_from_profiles(
-                                 "k_sdtw_q<8, 21, 1" if RL >= 49152 else "k_sdtw_q<16, 11, 1")["valu_issue_frac"],
+                                 "k_sdtw_q<8, 21, 1" if RL >= 65536 else "k_sdtw_q<16, 11, 1")["valu_issue_frac"],
                              "counters_source": "profiles/sq1_other_paths.json"},
                 "parity": {"reads_checked": int(len(rows_m)),
                            "dist_bit_identical": bool(all(got_m["dist"][k] == w[0] for k, w in enumerate(want_m))),

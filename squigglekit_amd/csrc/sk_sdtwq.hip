@@ -938,7 +938,9 @@ void *sk_sdtwq_pick_feed2(int which, int L, int R);
 // 8 ahead at 1 M).
 static void screen_layout(int N, int64_t nreads, int *L, int *R)
 {
-    int l = (N <= 8 * 32 && nreads >= 49152) ? 8 : (N <= 16 * 32) ? 16 : 64;
+    // (round 6, float64 reads of 20 000 / 37 000 samples vs 163 points: 50 000 reads 15.9 ms with 8 lanes against 15.5 with
+    // 16, 25 000 reads 15.3 against 14.0 -- the threshold moved from 49 152 to 65 536 reads)
+    int l = (N <= 8 * 32 && nreads >= 65536) ? 8 : (N <= 16 * 32) ? 16 : 64;
     if (const char *e = sk_tune("SK_DTW_QL")) {
         const int v = atoi(e);
         if ((v == 8 && N <= 8 * 32) || (v == 16 && N <= 16 * 32) || v == 64) l = v;
