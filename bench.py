@@ -481,7 +481,7 @@ def motifseq_roofline(a, w, prof, steps, mean_n):
     if prof["launches"] > 0:
         # dominant kernel = the fixed-point screening pass k_sdtw_q<L,R,feed>; one launch per chunk
         per_step = prof["launches"] / steps
-        Lg = int(os.environ.get("SK_DTW_QL", 0)) or (8 if (N <= 256 and R >= 65536) else 16 if N <= 512 else 64)   # sk_sdtwq.hip screen_layout
+        Lg = int(os.environ.get("SK_DTW_QL", 0)) or (8 if (N <= 256 and R >= (65536 if M > 8192 else 49152)) else 16 if N <= 512 else 64)   # sk_sdtwq.hip screen_layout
         Rg = (N + Lg - 1) // Lg
         dominant = "k_sdtw_q<%d,%d,0> (screening pass%s, %d launches per call)" % (
             Lg, Rg, " with the filter + medmad prologue" if prep_ms < 0.05 else "", per_step)

@@ -936,11 +936,12 @@ void *sk_sdtwq_pick_feed2(int which, int L, int R);
 // of L = 8 pay off once the batch fills the chip with them (8 reads per wavefront: measured 1.75 / 1.45 / 1.50 ms
 // with 8 / 16 / 64 lanes at 10 000 reads x 163 points, 2.06 / 1.80 / 2.45 at 20 000 x 200, level from 40 000 on,
 // 8 ahead at 1 M).
-static void screen_layout(int N, int64_t nreads, int *L, int *R)
+static void screen_layout(int N, int64_t nreads, int64_t maxlen, int *L, int *R)
 {
     // (round 6, float64 reads of 20 000 / 37 000 samples vs 163 points: 50 000 reads 15.9 ms with 8 lanes against 15.5 with
-    // 16, 25 000 reads 15.3 against 14.0 -- the threshold moved from 49 152 to 65 536 reads)
-    int l = (N <= 8 * 32 && nreads >= 65536) ? 8 : (N <= 16 * 32) ? 16 : 64;
+    // 16, 25 000 reads 15.3 against 14.0 -- while 62 500 reads of 4 000 samples vs 200 points take 4.39 ms with 8 lanes and
+    // 4.54 with 16: long reads switch at 65 536 reads, short ones at 49 152 as before)
+    int l = (N <= 8 * 32 && nreads >= (maxlen > 8192 ? 65536 : 49152)) ? 8 : (N <= 16 * 32) ? 16 : 64;
     if (const char *e = sk_tune("SK_DTW_QL")) {
         const int v = atoi(e);
         if ((v == 8 && N <= 8 * 32) || (v == 16 && N <= 16 * 32) || v == 64) l = v;
@@ -1073,7 +1074,7 @@ int sk_launch_sdtw_screen(sk_ctx *c, const sk_sdtw_args *a, int ck, int span, in
 {
     const int N = a->nmotif;
     int L, R;
-    screen_layout(N, a->nreads, &L, &R);
+    screen_layout(N, a->nreads, a->max_len, &L, &R);
     const int P = L * R - N;
     // quantised motif and the exact one in this scheme's per-lane layout (the exact kernels keep their own);
     // resident like them (the caller invalidates when the motif changes), so a call makes no host-side synchronisation
