@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <condition_variable>
+#include <pthread.h>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -28,13 +29,17 @@ namespace {
 // 48 MB chunk, about 2 of the 4.5 ms a chunk took on the 256-thread bench host.  run(n, f) executes f(0) .. f(n - 1),
 // f(0) on the caller; the workers sleep on a condition variable between jobs.  One job at a time: a second host thread
 // that arrives while the pool is busy runs its job on freshly created threads, as before.
+// (a forked child inherits the pool's bookkeeping but none of its threads: it creates threads per call, as before round 6)
+static bool g_forked_child = false;
 class Pool {
 public:
+    Pool() { pthread_atfork(nullptr, nullptr, [] { g_forked_child = true; }); }
     void run(int n, const std::function<void(int)> &f)
     {
         if (n <= 1) { f(0); return; }
-        std::unique_lock<std::mutex> own(busy_, std::try_to_lock);
-        if (!own.owns_lock()) {                              // pool in use by another host thread
+        std::unique_lock<std::mutex> own(busy_, std::defer_lock);
+        if (!g_forked_child) own.try_lock();
+        if (!own.owns_lock()) {                              // pool in use by another host thread (or not usable: forked child)
             std::vector<std::thread> th;
             for (int t = 1; t < n; t++) th.emplace_back(f, t);
             f(0);
@@ -55,12 +60,8 @@ public:
         done_.wait(lk, [this] { return pending_ == 0; });
         job_ = nullptr;
     }
-    ~Pool()
-    {
-        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
-        cv_.notify_all();
-        for (auto &x : workers_) x.join();
-    }
+    // (never destroyed: the object lives on the heap for the life of the process, its sleeping workers end with it --
+    // no join at exit, nothing to unwind in a forked child)
 private:
     void loop(int id)
     {
@@ -88,7 +89,7 @@ private:
     unsigned long gen_ = 0;
     bool stop_ = false;
 };
-Pool g_pool;
+Pool &g_pool = *new Pool;
 
 const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14,
                         1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
