@@ -93,6 +93,9 @@ def main():
         size = os.path.getsize(os.path.join(d, "reads.blow5")) / 1e6
         run("segmenter.py --blow5 --raw_signal", [py, seg, "--blow5", os.path.join(d, "reads.blow5"), "--raw_signal"],
             RP, size, out)
+        # without --raw_signal the reference converts every slow5 read to pA first (segmenter.py:366-370): since round 6 the
+        # rows stay int16 on the device (raw-domain pA route)
+        run("segmenter.py --blow5 (pA route)", [py, seg, "--blow5", os.path.join(d, "reads.blow5")], RP, size, out)
         run("MotifSeq.py --blow5 -m", [py, mot, "--blow5", os.path.join(d, "reads.blow5"), "-m", model], RP, size, out)
         os.remove(os.path.join(d, "reads.blow5"))
     os.rmdir(d)
